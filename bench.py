@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py -- ELBO iterations/s of the brie-quant hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+A "step" is one fused ELBO-gradient + Adam pass over every (cell, gene) element
+of the workload (= one iteration of tfp.math.minimize in
+/root/reference/brie/models/model_TFProb.py:239-241).  Workload = BASELINE.json
+configs[2] (the headline): 50k cells x 20k genes, 2 count layers, 3 cell
+covariates + gene intercept, MC_size=1, fp32; synthetic counts generated on the
+device with the SURVEY 8(d) recipe and resident in HBM before the timed region.
+With N>1 the 20k genes are sharded over the ranks (BASELINE configs[3]); there
+is no collective inside the timed loop (genes are independent), so `value` is
+total element-iterations of all ranks / max-over-ranks time.
+
+One JSON line on stdout (rank 0) with `roofline` (HIP-event time of the
+dominant kernel, algorithmic bytes 48+4L per element) and `cpu_baseline`
+(the oracle's eager torch-CPU restatement in the reference's execution shape).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # name: Nc, Ng, Kc, L, theta, depth
+    "c1": dict(Nc=200, Ng=500, Kc=0, L=2, theta=3.0, depth=2.0, desc="200x500, 2 isoforms (BASELINE configs[0])"),
+    "c2": dict(Nc=10000, Ng=5000, Kc=1, L=3, theta=1.5, depth=2.0, desc="10k x 5k SE events, effLen, Kc=1 (configs[1])"),
+    "c3": dict(Nc=50000, Ng=20000, Kc=3, L=2, theta=1.5, depth=2.0, desc="50k x 20k, Kc=3 + gene intercept (configs[2], headline)"),
+    "c5": dict(Nc=100000, Ng=30000, Kc=5, L=2, theta=1.5, depth=1.0, desc="DMG 100k x 30k spliced/unspliced, Kc=5 (configs[4])"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+GEN_CHUNK = 500                # genes per generation chunk (seeded per chunk => shard-invariant data)
+
+
+def gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed):
+    """Synthetic counts for genes [c0, c1) on the device (SURVEY 8d recipe)."""
+    Nc, Kc, L = cfg["Nc"], cfg["Kc"], cfg["L"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed * 1000003 + c0)
+    n = c1 - c0
+    W = torch.randn(Kc, n, generator=g, device=dev) * (torch.rand(Kc, n, generator=g, device=dev) < 0.2)
+    b = torch.randn(n, generator=g, device=dev) * cfg["theta"]
+    sig = torch.rand(n, generator=g, device=dev) * 1.5 + 0.5
+    Z = b[None, :] + sig[None, :] * torch.randn(Nc, n, generator=g, device=dev)
+    if Kc:
+        Z = Z + Xc @ W
+    psi = torch.sigmoid(Z.clamp_(-9, 9))
+    lam = torch.exp(torch.randn(n, generator=g, device=dev)) * cfg["depth"]
+    N = torch.poisson(size[:, None] * lam[None, :], generator=g)
+    eff = None
+    if L == 2:
+        c_1 = torch.binomial(N, psi, generator=g)
+        return [c_1, N - c_1], None
+    l = torch.randint(50, 301, (3, n), generator=g, device=dev).float()
+    rlen, eh, jh = 76.0, 10.0, 2.0
+    eff = torch.zeros(n, 6, device=dev)
+    eff[:, 0] = l[1] + rlen - 2 * jh
+    eff[:, 4] = rlen - 2 * jh
+    eff[:, 2] = l[0] + l[2] - 2 * eh + 2 * jh
+    eff[:, 5] = eff[:, 2]
+    p1, p2, p3 = psi * eff[:, 0], (1 - psi) * eff[:, 4], eff[:, 5][None, :].expand_as(psi)
+    tot = p1 + p2 + p3
+    c_1 = torch.binomial(N, p1 / tot, generator=g)
+    c_2 = torch.binomial(N - c_1, (p2 / (p2 + p3)).clamp_(0, 1), generator=g)
+    return [c_1, c_2, N - c_1 - c_2], eff
+
+
+def psi_delta_check(seed=11):
+    """'PSI delta vs CPU ref' on a config-1-sized problem (oracle fp64 as the CPU reference)."""
+    from brie_amd import _capi
+    from tests import util
+    Nc, Ng, Kc = 200, 500, 1
+    P = util.problem(Nc, Ng, Kc, 2, theta=3.0)
+    o = util.oracle_model(P, Nc, Ng, Kc, seed, np.float64)
+    sh = util.device_shard(P, Nc, Ng, Kc, seed)
+    for n, lr in util.staged_schedule(300):
+        o.reset_optimizer()
+        o.minimize(P["counts_pc"], P["Xc"], n, lr, 1)
+        sh.reset_optimizer()
+        sh.step(n, lr, 1)
+    d = np.abs(sh.read(_capi.PSI) - o.Psi)
+    sh.close()
+    return {"workload": "200x500 Kc=1, 300 staged steps, same init + noise stream",
+            "max": float(d.max()), "p99": float(np.percentile(d, 99))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+    ap.add_argument("--mc", type=int, default=1, help="MC_size (API default 1, CLI default 3)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="strong: the config's genes are sharded over ranks (BASELINE configs[3]); "
+                         "weak: every rank fits the whole config")
+    ap.add_argument("--rows-per-chunk", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-psi-check", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    from brie_amd import _capi
+    from brie_amd.sharding import gene_shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = dict(CONFIGS[args.config])
+    Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
+    if args.scaling == "strong":
+        g0, g1 = gene_shard(Ng, rank, world)
+    else:
+        g0, g1 = 0, Ng
+    ng = g1 - g0
+    seed = 20240617 + {"c1": 1, "c2": 2, "c3": 3, "c5": 5}[args.config]
+
+    # ---- synthetic inputs, generated on the device, resident before the timed region
+    t_gen = time.time()
+    gx = torch.Generator(device=dev)
+    gx.manual_seed(seed)
+    Xc = torch.zeros(Nc, Kc, device=dev)
+    if Kc:
+        Xc[:, 0] = (torch.rand(Nc, generator=gx, device=dev) < 0.5).float()
+        if Kc > 1:
+            Xc[:, 1:] = torch.randn(Nc, Kc - 1, generator=gx, device=dev)
+    size = torch.exp(0.5 * torch.randn(Nc, generator=gx, device=dev))
+    layers = [torch.empty(Nc, ng, device=dev) for _ in range(L)]
+    eff_all = torch.zeros(ng, 6, device=dev) if L == 3 else None
+    c0 = (g0 // GEN_CHUNK) * GEN_CHUNK
+    while c0 < g1:
+        c1 = min(c0 + GEN_CHUNK, Ng)
+        cnt, eff = gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
+        a, b = max(c0, g0), min(c1, g1)
+        for l in range(L):
+            layers[l][:, a - g0:b - g0] = cnt[l][:, a - c0:b - c0]
+        if eff is not None:
+            eff_all[a - g0:b - g0] = eff[a - c0:b - c0]
+        c0 = c1
+    torch.cuda.synchronize()
+
+    sh = _capi.Shard(Nc, ng, Kc, n_layers=L, has_efflen=L == 3, seed=seed, device=local_rank, gene_offset=g0)
+    for l in range(L):
+        sh.upload(_capi.COUNT1 + l, layers[l])           # device -> device
+    sh.add_pseudo_count(0.01)
+    if L == 3:
+        sh.upload(_capi.EFFLEN, eff_all.cpu().numpy())
+    if Kc:
+        sh.upload(_capi.XC, Xc)
+    sample_layers = [layers[l][:, :min(ng, 64)].cpu().numpy() for l in range(L)] if rank == 0 else None
+    Xc_host = Xc.cpu().numpy()
+    del layers
+    torch.cuda.empty_cache()
+    sh.init_state()
+    if args.rows_per_chunk:
+        sh.set_tiling(args.rows_per_chunk)
+    sh.synchronize()
+    t_gen = time.time() - t_gen
+
+    lr = 0.005
+    sh.step(args.warmup, lr, args.mc, trace=False)
+    sh.synchronize()
+    sh.profile_enable(True)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    sh.step(args.steps, lr, args.mc, trace=False)
+    sh.synchronize()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms, n_launch = sh.profile_read()
+    sh.profile_enable(False)
+    last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
+    assert np.isfinite(last).all(), last
+    total_elems = Nc * (Ng if args.scaling == "strong" else Ng * world)
+    value = args.steps * total_elems / elapsed
+
+    out = None
+    if rank == 0:
+        alg_bytes = sh.step_algorithmic_bytes()
+        avg_ms = kern_ms / max(n_launch, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "ELBO iterations/sec (cells x genes)",
+            "value": value,
+            "unit": "cell*gene*iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "iterations_per_s": args.steps / elapsed,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "Nc": Nc, "Ng": Ng, "Kc": Kc, "count_layers": L,
+                       "MC_size": args.mc, "genes_per_rank": ng, "parallelism": "gene-shard x%d" % world,
+                       "inputs": "generated on device, resident in HBM (%.1f s, untimed)" % t_gen},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch},
+        }
+    sh.close()
+
+    if rank == 0 and world == 1:
+        if not args.no_psi_check:
+            out["psi_delta_vs_cpu_ref"] = psi_delta_check()
+        if not args.no_cpu_baseline:
+            from oracle.brie_oracle_torch import time_reference_shape
+            import torch as _t
+            cores = min(6, os.cpu_count() or 1)          # reference default --nproc 6 (bin/quant.py:183)
+            n_gene = int(math.ceil(500000 / float(Nc)))
+            nb = max(1, min(3, sample_layers[0].shape[1] // n_gene))
+
+            def counts_fn(a, b):
+                return [np.ascontiguousarray(c[:, a:b]) for c in sample_layers]
+            # calibrate so the sample costs ~cpu_seconds
+            eps_s, el = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, 1, 3, args.mc, threads=cores,
+                                             warmup_steps=1)
+            n_steps = int(max(5, min(400, args.cpu_seconds * eps_s / (Nc * n_gene * nb))))
+            eps_s, el = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, nb, n_steps, args.mc, threads=cores)
+            out["cpu_baseline"] = {
+                "value": eps_s, "unit": "cell*gene*iterations/s", "cores": cores, "kind": "port",
+                "sample": "%d reference-sized gene batches (%d genes x %d cells each, model_wrap.py:242) x %d Adam "
+                          "steps, eager torch-CPU autograd restatement (TF absent), %.1f s"
+                          % (nb, n_gene, Nc, n_steps, el),
+                "gpu_over_cpu": value / eps_s,
+            }
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

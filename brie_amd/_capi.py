@@ -1,0 +1,210 @@
+"""ctypes binding of include/brie_amd.h (the C ABI of libbrie_amd.so).
+
+The north star names cffi; cffi is not installed in this image, ctypes is, and
+both bind the same C header in ABI mode.  There is NO CPU fallback: if the HIP
+library is missing or no GPU is visible the calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .build import LIB_PATH
+
+# brie_array ids (include/brie_amd.h)
+COUNT1, COUNT2, COUNT3, XC, EFFLEN = 0, 1, 2, 3, 4
+Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG = 8, 9, 10, 11, 12
+PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
+ABI_VERSION = 1
+MAX_KC = 8
+
+EXPORTS = [
+    "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
+    "brie_reset_optimizer", "brie_step", "brie_loss_gene", "brie_read", "brie_get_draw",
+    "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
+    "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_last_error", "brie_abi_version",
+]
+
+
+class BrieProblem(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("Nc", ctypes.c_int64), ("Ng", ctypes.c_int64), ("gene_offset", ctypes.c_int64),
+        ("Kc", ctypes.c_int32), ("Kg", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+        ("has_efflen", ctypes.c_int32), ("intercept_mode", ctypes.c_int32),
+        ("train_intercept", ctypes.c_int32), ("train_sigma", ctypes.c_int32),
+        ("reserved", ctypes.c_int32), ("seed", ctypes.c_uint64),
+    ]
+
+
+class BrieError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libbrie_amd.so and declare every prototype of include/brie_amd.h."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or os.environ.get("BRIE_AMD_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise ImportError(
+            "libbrie_amd.so not found at %s -- build it with `python -m brie_amd.build` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback." % path)
+    lib = ctypes.CDLL(path)
+    vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    lib.brie_create.argtypes = [ctypes.POINTER(BrieProblem), ctypes.POINTER(vp)]
+    lib.brie_destroy.argtypes = [vp]
+    lib.brie_upload.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
+    lib.brie_add_pseudo_count.argtypes = [vp, f32]
+    lib.brie_init_state.argtypes = [vp, f32, f32]
+    lib.brie_reset_optimizer.argtypes = [vp]
+    lib.brie_step.argtypes = [vp, i32, f32, i32, vp]
+    lib.brie_loss_gene.argtypes = [vp, i32, vp]
+    lib.brie_read.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
+    lib.brie_get_draw.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
+    lib.brie_set_draw.argtypes = [vp, ctypes.c_uint32]
+    lib.brie_synchronize.argtypes = [vp]
+    lib.brie_profile_enable.argtypes = [vp, i32]
+    lib.brie_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    lib.brie_set_tiling.argtypes = [vp, i32]
+    lib.brie_step_algorithmic_bytes.argtypes = [vp]
+    lib.brie_step_algorithmic_bytes.restype = i64
+    lib.brie_last_error.restype = ctypes.c_char_p
+    lib.brie_abi_version.restype = ctypes.c_int
+    for name in EXPORTS:
+        if name not in ("brie_step_algorithmic_bytes", "brie_last_error", "brie_abi_version"):
+            getattr(lib, name).restype = ctypes.c_int
+    if lib.brie_abi_version() != ABI_VERSION:
+        raise ImportError("libbrie_amd.so ABI %d != binding %d" % (lib.brie_abi_version(), ABI_VERSION))
+    if path == os.environ.get("BRIE_AMD_LIB", LIB_PATH):
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        msg = lib.brie_last_error().decode("utf-8", "replace")
+        if rc in (-1,):
+            raise ValueError("brie_amd: " + msg)
+        if rc == -4:
+            raise NotImplementedError("brie_amd: " + msg)
+        raise BrieError("brie_amd (status %d): %s" % (rc, msg))
+
+
+def _matrix_pointer(x):
+    """(pointer, rows, cols, ld, keepalive) of a float32 row-major matrix.
+
+    Accepts numpy arrays (host) and anything exposing `data_ptr()`/`stride()`
+    (e.g. a torch tensor already resident in HBM) -- the library copies with
+    hipMemcpyDefault, so both kinds of pointer are fine.
+    """
+    if hasattr(x, "data_ptr") and hasattr(x, "stride"):
+        import torch
+        if x.dtype != torch.float32:
+            x = x.float()
+        if x.dim() == 1:
+            x = x.reshape(1, -1)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        return ctypes.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], max(x.stride(0), x.shape[1]), x
+    a = np.asarray(x, dtype=np.float32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a)
+    return a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.shape[1], a
+
+
+class Shard(object):
+    """Thin object wrapper over one `brie_handle` (one gene shard on one GPU)."""
+
+    def __init__(self, Nc, Ng, Kc=0, n_layers=2, has_efflen=False, train_intercept=True,
+                 train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0):
+        self.lib = load_library()
+        self.Nc, self.Ng, self.Kc = int(Nc), int(Ng), int(Kc)
+        p = BrieProblem(ABI_VERSION, int(device), int(Nc), int(Ng), int(gene_offset), int(Kc), int(Kg),
+                        int(n_layers), int(bool(has_efflen)), int(intercept_mode),
+                        int(bool(train_intercept)), int(bool(train_sigma)), 0, int(seed) & (2 ** 64 - 1))
+        self._h = ctypes.c_void_p()
+        _check(self.lib, self.lib.brie_create(ctypes.byref(p), ctypes.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.brie_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, which, x):
+        ptr, rows, cols, ld, keep = _matrix_pointer(x)
+        _check(self.lib, self.lib.brie_upload(self._h, which, ptr, rows, cols, ld))
+        del keep
+
+    def add_pseudo_count(self, pc):
+        _check(self.lib, self.lib.brie_add_pseudo_count(self._h, float(pc)))
+
+    def init_state(self, intercept=None, sigma=None):
+        nan = float("nan")
+        _check(self.lib, self.lib.brie_init_state(
+            self._h, nan if intercept is None else float(intercept), nan if sigma is None else float(sigma)))
+
+    def reset_optimizer(self):
+        _check(self.lib, self.lib.brie_reset_optimizer(self._h))
+
+    def step(self, n_steps, lr, mc_size=1, trace=True):
+        if trace:
+            out = np.empty(int(n_steps), np.float32)
+            _check(self.lib, self.lib.brie_step(self._h, int(n_steps), float(lr), int(mc_size),
+                                                out.ctypes.data_as(ctypes.c_void_p)))
+            return out
+        _check(self.lib, self.lib.brie_step(self._h, int(n_steps), float(lr), int(mc_size), None))
+        return None
+
+    def loss_gene(self, n_repeats=500):
+        out = np.empty(self.Ng, np.float32)
+        _check(self.lib, self.lib.brie_loss_gene(self._h, int(n_repeats), out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def read(self, which):
+        shape = {XC: (self.Nc, self.Kc), WC_LOC: (self.Kc, self.Ng), INTERCEPT: (1, self.Ng),
+                 SIGMA_LOG: (1, self.Ng), SIGMA: (1, self.Ng)}.get(which, (self.Nc, self.Ng))
+        out = np.empty(shape, np.float32)
+        if out.size:
+            _check(self.lib, self.lib.brie_read(self._h, which, out.ctypes.data_as(ctypes.c_void_p),
+                                                shape[0], shape[1], shape[1]))
+        return out
+
+    @property
+    def draw(self):
+        d = ctypes.c_uint32()
+        _check(self.lib, self.lib.brie_get_draw(self._h, ctypes.byref(d)))
+        return d.value
+
+    @draw.setter
+    def draw(self, value):
+        _check(self.lib, self.lib.brie_set_draw(self._h, int(value)))
+
+    def synchronize(self):
+        _check(self.lib, self.lib.brie_synchronize(self._h))
+
+    def profile_enable(self, enable=True):
+        _check(self.lib, self.lib.brie_profile_enable(self._h, int(bool(enable))))
+
+    def profile_read(self):
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _check(self.lib, self.lib.brie_profile_read(self._h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def set_tiling(self, rows_per_chunk=0):
+        _check(self.lib, self.lib.brie_set_tiling(self._h, int(rows_per_chunk)))
+
+    def step_algorithmic_bytes(self):
+        return int(self.lib.brie_step_algorithmic_bytes(self._h))

@@ -1,0 +1,560 @@
+// brie_capi.hip -- host side of the C ABI declared in include/brie_amd.h.
+// One handle = one gene shard resident in the HBM of one MI355X, driven on its
+// own HIP stream.  No torch, no C++ types across the boundary.
+#include "brie_amd.h"
+#include "brie_kernels.hip.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess)                                                              \
+            return fail(BRIE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct brie_handle {
+    brie_problem p{};
+    int64_t ld = 0;
+    int S = 0;                      // statistics per gene per chunk = Kc + 4
+    int mode = 0;                   // likelihood mode (brie::kLik2 ...)
+    hipStream_t stream = nullptr;
+    // (Nc, ld)
+    float *c[3] = {nullptr, nullptr, nullptr};
+    float *mu = nullptr, *rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr,
+          *v_rho = nullptr;
+    float *Xc = nullptr;            // (Nc, Kc)
+    float *W = nullptr, *m_W = nullptr, *v_W = nullptr;              // (Kc, ld)
+    float *b = nullptr, *m_b = nullptr, *v_b = nullptr;              // (ld)
+    float *lam = nullptr, *m_lam = nullptr, *v_lam = nullptr;        // (ld)
+    float *effL = nullptr;          // (6, ld)
+    float *gene_tmp = nullptr;      // (ld) scratch per-gene output
+    float *partials = nullptr;
+    size_t partials_elems = 0;
+    double *loss_parts = nullptr;
+    size_t loss_parts_elems = 0;
+    int rows_per_chunk = 0, n_chunks = 0, gene_blocks = 0, fin_blocks = 0;
+    int user_rows_per_chunk = 0;
+    uint32_t draw = 0;
+    int64_t t = 0;                  // Adam iteration of the current optimiser
+    bool have_c[3] = {false, false, false}, have_xc = false, have_eff = false, have_state = false;
+    // profiling of the dominant kernel
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+};
+
+namespace {
+
+int set_device(const brie_handle *h) {
+    HIP_TRY(hipSetDevice(h->p.device));
+    return BRIE_OK;
+}
+
+int alloc_f32(float **p, size_t elems, hipStream_t s) {
+    if (elems == 0) { *p = nullptr; return BRIE_OK; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), elems * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(*p, 0, elems * sizeof(float), s));
+    return BRIE_OK;
+}
+
+void configure_tiling(brie_handle *h) {
+    const int64_t Nc = h->p.Nc;
+    h->gene_blocks = static_cast<int>((h->p.Ng + brie::kGenesPerBlock - 1) / brie::kGenesPerBlock);
+    int rpc = h->user_rows_per_chunk;
+    if (rpc <= 0) {
+        rpc = 256;
+        // keep >= ~8 workgroups per CU in flight when the problem allows it
+        while (rpc > 16 && static_cast<int64_t>(h->gene_blocks) * ((Nc + rpc - 1) / rpc) < 2048) rpc /= 2;
+    }
+    h->rows_per_chunk = rpc;
+    h->n_chunks = static_cast<int>((Nc + rpc - 1) / rpc);
+    h->fin_blocks = static_cast<int>((h->p.Ng + brie::kBlock - 1) / brie::kBlock);
+}
+
+int ensure_partials(brie_handle *h) {
+    const size_t need = static_cast<size_t>(h->n_chunks) * h->S * h->ld;
+    if (need > h->partials_elems) {
+        if (h->partials) HIP_TRY(hipFree(h->partials));
+        h->partials = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->partials), need * sizeof(float)));
+        h->partials_elems = need;
+    }
+    return BRIE_OK;
+}
+
+int check_ready(const brie_handle *h) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    for (int l = 0; l < h->p.n_layers; ++l)
+        if (!h->have_c[l]) return fail(BRIE_ERR_STATE, "count layer %d not uploaded", l + 1);
+    if (h->p.Kc > 0 && !h->have_xc) return fail(BRIE_ERR_STATE, "Xc not uploaded (Kc=%d)", h->p.Kc);
+    if (h->p.has_efflen && !h->have_eff) return fail(BRIE_ERR_STATE, "effLen not uploaded");
+    if (!h->have_state)
+        return fail(BRIE_ERR_STATE, "state not initialised: call brie_init_state or upload Z_loc..sigma_log");
+    return BRIE_OK;
+}
+
+template <int KC>
+void launch_step_kc(const brie_handle *h, const brie::StepArgs &a, dim3 grid) {
+    switch (h->mode) {
+        case brie::kLik2:
+            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLik2>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+        case brie::kLikEff2:
+            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLikEff2>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLikEff3>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+    }
+}
+
+template <int KC>
+void launch_lg_kc(const brie_handle *h, const brie::LossGeneArgs &a, dim3 grid) {
+    switch (h->mode) {
+        case brie::kLik2:
+            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLik2>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+        case brie::kLikEff2:
+            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLikEff2>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+        default:
+            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLikEff3>), grid, dim3(brie::kBlock), 0, h->stream, a);
+            break;
+    }
+}
+
+#define BRIE_DISPATCH_KC(fn, h, a, grid)                 \
+    switch ((h)->p.Kc) {                                 \
+        case 0: fn<0>(h, a, grid); break;                \
+        case 1: fn<1>(h, a, grid); break;                \
+        case 2: fn<2>(h, a, grid); break;                \
+        case 3: fn<3>(h, a, grid); break;                \
+        case 4: fn<4>(h, a, grid); break;                \
+        case 5: fn<5>(h, a, grid); break;                \
+        case 6: fn<6>(h, a, grid); break;                \
+        case 7: fn<7>(h, a, grid); break;                \
+        default: fn<8>(h, a, grid); break;               \
+    }
+
+int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t *cols, int64_t *ldd) {
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    switch (which) {
+        case BRIE_COUNT1: case BRIE_COUNT2: case BRIE_COUNT3:
+            if (which - BRIE_COUNT1 >= h->p.n_layers)
+                return fail(BRIE_ERR_INVALID, "count layer %d outside n_layers=%d", which + 1, h->p.n_layers);
+            *dev = h->c[which - BRIE_COUNT1]; *rows = Nc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_Z_LOC: *dev = h->mu; *rows = Nc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_Z_STD_LOG: *dev = h->rho; *rows = Nc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_XC: *dev = h->Xc; *rows = Nc; *cols = h->p.Kc; *ldd = h->p.Kc; return BRIE_OK;
+        case BRIE_WC_LOC: *dev = h->W; *rows = h->p.Kc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_INTERCEPT: *dev = h->b; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_SIGMA_LOG: *dev = h->lam; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        default: return fail(BRIE_ERR_INVALID, "array id %d is not a stored matrix", which);
+    }
+}
+
+int grid_1d(int64_t n) {
+    int64_t g = (n + 255) / 256;
+    return static_cast<int>(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *brie_last_error(void) { return g_last_error.c_str(); }
+int brie_abi_version(void) { return BRIE_AMD_ABI_VERSION; }
+
+int brie_create(const brie_problem *p, brie_handle **out) {
+    if (!p || !out) return fail(BRIE_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (p->abi_version != BRIE_AMD_ABI_VERSION)
+        return fail(BRIE_ERR_INVALID, "abi_version %d != %d", p->abi_version, BRIE_AMD_ABI_VERSION);
+    if (p->Nc <= 0 || p->Ng <= 0 || p->Nc > INT32_MAX || p->Ng > INT32_MAX - 1024)
+        return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
+    if (p->Kc < 0 || p->Kc > BRIE_MAX_KC)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC);
+    if (p->Kg != 0)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d: gene-feature prior couples genes (SURVEY 8f-4), not built", p->Kg);
+    if (p->intercept_mode != 0)
+        return fail(BRIE_ERR_UNSUPPORTED, "intercept_mode='cell' couples genes (SURVEY 8f-4), not built");
+    if (p->n_layers != 2 && p->n_layers != 3)
+        return fail(BRIE_ERR_INVALID, "n_layers=%d (must be 2 or 3)", p->n_layers);
+    if (p->n_layers == 3 && !p->has_efflen)
+        return fail(BRIE_ERR_INVALID, "a third count layer is only used with effLen (model_TFProb.py:184)");
+    if (p->gene_offset < 0 || p->gene_offset % 4 != 0)
+        return fail(BRIE_ERR_INVALID, "gene_offset=%lld must be a non-negative multiple of 4", (long long)p->gene_offset);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (p->device < 0 || p->device >= ndev)
+        return fail(BRIE_ERR_HIP, "device %d not present (%d visible)", p->device, ndev);
+
+    brie_handle *h = new brie_handle();
+    h->p = *p;
+    h->ld = round_up(p->Ng, 64);
+    h->S = p->Kc + 4;
+    h->mode = !p->has_efflen ? brie::kLik2 : (p->n_layers == 3 ? brie::kLikEff3 : brie::kLikEff2);
+    int rc = set_device(h);
+    if (rc != BRIE_OK) { delete h; return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete h; return fail(BRIE_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    const size_t mat = static_cast<size_t>(p->Nc) * h->ld;
+    const size_t vec = static_cast<size_t>(h->ld);
+#define A(ptr, n)                                            \
+    if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) { brie_destroy(h); return rc; }
+    for (int l = 0; l < p->n_layers; ++l) A(h->c[l], mat);
+    A(h->mu, mat); A(h->rho, mat); A(h->m_mu, mat); A(h->v_mu, mat); A(h->m_rho, mat); A(h->v_rho, mat);
+    A(h->Xc, static_cast<size_t>(p->Nc) * p->Kc);
+    A(h->W, vec * p->Kc); A(h->m_W, vec * p->Kc); A(h->v_W, vec * p->Kc);
+    A(h->b, vec); A(h->m_b, vec); A(h->v_b, vec);
+    A(h->lam, vec); A(h->m_lam, vec); A(h->v_lam, vec);
+    A(h->effL, vec * 6);
+    A(h->gene_tmp, vec);
+#undef A
+    configure_tiling(h);
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
+    *out = h;
+    return BRIE_OK;
+}
+
+int brie_destroy(brie_handle *h) {
+    if (!h) return BRIE_OK;
+    hipSetDevice(h->p.device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
+                     h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
+                     h->gene_tmp, h->partials};
+    for (float *q : ptrs)
+        if (q) hipFree(q);
+    if (h->loss_parts) hipFree(h->loss_parts);
+    for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
+    if (h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return BRIE_OK;
+}
+
+int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64_t cols, int64_t ld) {
+    if (!h || (!src && rows * cols > 0)) return fail(BRIE_ERR_INVALID, "null argument");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
+    if (which == BRIE_EFFLEN) {
+        if (!h->p.has_efflen) return fail(BRIE_ERR_INVALID, "problem was created without effLen");
+        if (rows != h->p.Ng || cols != 6)
+            return fail(BRIE_ERR_INVALID, "effLen must be (Ng=%lld, 6), got (%lld, %lld)", (long long)h->p.Ng,
+                        (long long)rows, (long long)cols);
+        // effLen[:, [0, 4, 5]] (model_TFProb.py:176) -> rows 0..2 of effL, logs in rows 3..5
+        std::vector<float> tmp(static_cast<size_t>(rows) * 6), packed(static_cast<size_t>(3) * h->ld, 1.0f);
+        HIP_TRY(hipMemcpy2D(tmp.data(), 6 * sizeof(float), src, ld * sizeof(float), 6 * sizeof(float), rows,
+                            hipMemcpyDefault));
+        const int sel[3] = {0, 4, 5};
+        for (int64_t j = 0; j < rows; ++j)
+            for (int s = 0; s < 3; ++s) packed[s * h->ld + j] = tmp[j * 6 + sel[s]];
+        HIP_TRY(hipMemcpyAsync(h->effL, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(brie::log_rows, dim3((h->p.Ng + 255) / 256), dim3(256), 0, h->stream, h->effL, h->ld,
+                           static_cast<int>(h->p.Ng));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->have_eff = true;
+        return BRIE_OK;
+    }
+    float *dev = nullptr;
+    int64_t R = 0, C = 0, ldd = 0;
+    rc = matrix_target(h, which, &dev, &R, &C, &ldd);
+    if (rc != BRIE_OK) return rc;
+    if (rows != R || cols != C)
+        return fail(BRIE_ERR_INVALID, "array %d must be (%lld, %lld), got (%lld, %lld)", which, (long long)R,
+                    (long long)C, (long long)rows, (long long)cols);
+    if (R * C > 0) {
+        HIP_TRY(hipMemcpy2DAsync(dev, ldd * sizeof(float), src, ld * sizeof(float), C * sizeof(float), R,
+                                 hipMemcpyDefault, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3) h->have_c[which - BRIE_COUNT1] = true;
+    if (which == BRIE_XC) h->have_xc = true;
+    if (which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG) h->have_state = true;
+    return BRIE_OK;
+}
+
+int brie_add_pseudo_count(brie_handle *h, float pc) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (!h->have_c[0] || !h->have_c[1]) return fail(BRIE_ERR_STATE, "count layers 1 and 2 not uploaded");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    const int64_t n4 = h->p.Nc * h->ld / 4;
+    hipLaunchKernelGGL(brie::pseudo_count, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[0], h->c[1], n4, pc);
+    HIP_TRY(hipGetLastError());
+    return BRIE_OK;
+}
+
+int brie_reset_optimizer(brie_handle *h) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    const size_t mat = static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), vec = h->ld * sizeof(float);
+    HIP_TRY(hipMemsetAsync(h->m_mu, 0, mat, h->stream));
+    HIP_TRY(hipMemsetAsync(h->v_mu, 0, mat, h->stream));
+    HIP_TRY(hipMemsetAsync(h->m_rho, 0, mat, h->stream));
+    HIP_TRY(hipMemsetAsync(h->v_rho, 0, mat, h->stream));
+    if (h->p.Kc > 0) {
+        HIP_TRY(hipMemsetAsync(h->m_W, 0, vec * h->p.Kc, h->stream));
+        HIP_TRY(hipMemsetAsync(h->v_W, 0, vec * h->p.Kc, h->stream));
+    }
+    HIP_TRY(hipMemsetAsync(h->m_b, 0, vec, h->stream));
+    HIP_TRY(hipMemsetAsync(h->v_b, 0, vec, h->stream));
+    HIP_TRY(hipMemsetAsync(h->m_lam, 0, vec, h->stream));
+    HIP_TRY(hipMemsetAsync(h->v_lam, 0, vec, h->stream));
+    h->t = 0;
+    return BRIE_OK;
+}
+
+int brie_init_state(brie_handle *h, float intercept, float sigma) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    const uint32_t slo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull), shi = static_cast<uint32_t>(h->p.seed >> 32);
+    const uint32_t qoff = static_cast<uint32_t>(h->p.gene_offset / 4);
+    const int Nc = static_cast<int>(h->p.Nc), Ng = static_cast<int>(h->p.Ng);
+    const int64_t quads = (Ng + 3) / 4;
+    hipLaunchKernelGGL(brie::init_z, dim3(grid_1d(Nc * quads)), dim3(256), 0, h->stream, h->mu, h->rho, h->ld, Nc, Ng,
+                       slo, shi, qoff);
+    if (h->p.Kc > 0)
+        hipLaunchKernelGGL(brie::init_gene_rows, dim3(grid_1d(h->p.Kc * quads)), dim3(256), 0, h->stream, h->W, h->ld,
+                           h->p.Kc, Ng, 2u, slo, shi, qoff);
+    if (std::isnan(intercept))
+        hipLaunchKernelGGL(brie::init_gene_rows, dim3(grid_1d(quads)), dim3(256), 0, h->stream, h->b, h->ld, 1, Ng, 3u,
+                           slo, shi, qoff);
+    else
+        hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Ng)), dim3(256), 0, h->stream, h->b, static_cast<int64_t>(Ng),
+                           intercept);
+    const float lam0 = std::isnan(sigma) ? 0.0f : logf(sigma);
+    hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Ng)), dim3(256), 0, h->stream, h->lam, static_cast<int64_t>(Ng), lam0);
+    HIP_TRY(hipGetLastError());
+    h->have_state = true;
+    return brie_reset_optimizer(h);
+}
+
+int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (rows_per_chunk < 0 || (rows_per_chunk > 0 && rows_per_chunk < brie::kWavesPerBlock))
+        return fail(BRIE_ERR_INVALID, "rows_per_chunk=%d", rows_per_chunk);
+    h->user_rows_per_chunk = rows_per_chunk;
+    configure_tiling(h);
+    return BRIE_OK;
+}
+
+int64_t brie_step_algorithmic_bytes(const brie_handle *h) {
+    if (!h) return 0;
+    return h->p.Nc * h->p.Ng * (48 + 4 * static_cast<int64_t>(h->p.n_layers));
+}
+
+int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float *loss_trace) {
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (n_steps < 0 || mc_size < 1) return fail(BRIE_ERR_INVALID, "n_steps=%d mc_size=%d", n_steps, mc_size);
+    if (n_steps == 0) return BRIE_OK;
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
+    const size_t lp_need = static_cast<size_t>(n_steps) * h->fin_blocks * 2;
+    if (lp_need > h->loss_parts_elems) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->loss_parts) HIP_TRY(hipFree(h->loss_parts));
+        h->loss_parts = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->loss_parts), lp_need * sizeof(double)));
+        h->loss_parts_elems = lp_need;
+    }
+    if (h->profiling) {
+        while (h->ev_pool.size() < h->ev_used + 2 * static_cast<size_t>(n_steps)) {
+            hipEvent_t ev;
+            HIP_TRY(hipEventCreate(&ev));
+            h->ev_pool.push_back(ev);
+        }
+    }
+
+    brie::StepArgs a{};
+    a.c1 = h->c[0]; a.c2 = h->c[1]; a.c3 = h->c[2];
+    a.mu = h->mu; a.rho = h->rho; a.m_mu = h->m_mu; a.v_mu = h->v_mu; a.m_rho = h->m_rho; a.v_rho = h->v_rho;
+    a.Xc = h->Xc; a.W = h->W; a.b = h->b; a.lam = h->lam; a.effL = h->effL; a.partials = h->partials;
+    a.ld = h->ld; a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
+    a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
+    a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
+    a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+
+    brie::FinalizeArgs f{};
+    f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
+    f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.loss_gene_step = nullptr; f.ld = h->ld;
+    f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks; f.train_b = h->p.train_intercept; f.train_lam = h->p.train_sigma;
+
+    const dim3 grid(h->gene_blocks, h->n_chunks);
+    for (int i = 0; i < n_steps; ++i) {
+        h->t += 1;
+        const double tt = static_cast<double>(h->t);
+        const float alpha = static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) /
+                                               (1.0 - std::pow(0.9, tt)));
+        a.alpha = alpha; f.alpha = alpha;
+        a.draw = h->draw++;
+        f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
+        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        BRIE_DISPATCH_KC(launch_step_kc, h, a, grid);
+        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, f);
+    }
+    HIP_TRY(hipGetLastError());
+    if (loss_trace) {
+        std::vector<double> parts(lp_need);
+        HIP_TRY(hipMemcpyAsync(parts.data(), h->loss_parts, lp_need * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int i = 0; i < n_steps; ++i) {
+            double kl = 0.0, ll = 0.0;
+            for (int bk = 0; bk < h->fin_blocks; ++bk) {
+                kl += parts[(static_cast<size_t>(i) * h->fin_blocks + bk) * 2 + 0];
+                ll += parts[(static_cast<size_t>(i) * h->fin_blocks + bk) * 2 + 1];
+            }
+            loss_trace[i] = static_cast<float>(kl - ll);      // sum KL - sum ll (model_TFProb.py:208-211)
+        }
+    }
+    return BRIE_OK;
+}
+
+int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (n_repeats < 1 || !out) return fail(BRIE_ERR_INVALID, "n_repeats=%d out=%p", n_repeats, (void *)out);
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
+    brie::LossGeneArgs a{};
+    a.c1 = h->c[0]; a.c2 = h->c[1]; a.c3 = h->c[2]; a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
+    a.lam = h->lam; a.effL = h->effL; a.partials = h->partials; a.ld = h->ld;
+    a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
+    a.rows_per_chunk = h->rows_per_chunk; a.n_rep = n_repeats;
+    a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
+    a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    h->draw += static_cast<uint32_t>(n_repeats);
+    const dim3 grid(h->gene_blocks, h->n_chunks);
+    BRIE_DISPATCH_KC(launch_lg_kc, h, a, grid);
+    hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
+                       h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, h->gene_tmp, h->p.Ng * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BRIE_OK;
+}
+
+int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols, int64_t ld) {
+    if (!h || !dst) return fail(BRIE_ERR_INVALID, "null argument");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    if (which == BRIE_PSI || which == BRIE_Z_STD || which == BRIE_PSI95CI) {
+        if (rows != Nc || cols != Ng)
+            return fail(BRIE_ERR_INVALID, "array %d must be (%lld, %lld)", which, (long long)Nc, (long long)Ng);
+        float *tmp = nullptr;
+        const int64_t n4 = Nc * h->ld / 4;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * h->ld * sizeof(float)));
+        hipLaunchKernelGGL(brie::psi_epilogue, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->mu, h->rho, tmp, n4,
+                           which - BRIE_PSI);
+        hipError_t e = hipMemcpy2DAsync(dst, ld * sizeof(float), tmp, h->ld * sizeof(float), Ng * sizeof(float), Nc,
+                                        hipMemcpyDefault, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        hipFree(tmp);
+        if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read derived array: %s", hipGetErrorString(e));
+        return BRIE_OK;
+    }
+    if (which == BRIE_SIGMA) {
+        if (rows != 1 || cols != Ng) return fail(BRIE_ERR_INVALID, "sigma must be (1, %lld)", (long long)Ng);
+        hipLaunchKernelGGL(brie::exp_vec, dim3((Ng + 255) / 256), dim3(256), 0, h->stream, h->lam, h->gene_tmp,
+                           static_cast<int>(Ng));
+        HIP_TRY(hipMemcpyAsync(dst, h->gene_tmp, Ng * sizeof(float), hipMemcpyDefault, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        return BRIE_OK;
+    }
+    float *dev = nullptr;
+    int64_t R = 0, C = 0, ldd = 0;
+    rc = matrix_target(h, which, &dev, &R, &C, &ldd);
+    if (rc != BRIE_OK) return rc;
+    if (rows != R || cols != C)
+        return fail(BRIE_ERR_INVALID, "array %d is (%lld, %lld), asked for (%lld, %lld)", which, (long long)R,
+                    (long long)C, (long long)rows, (long long)cols);
+    if (R * C > 0) {
+        HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(float), dev, ldd * sizeof(float), C * sizeof(float), R,
+                                 hipMemcpyDefault, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return BRIE_OK;
+}
+
+int brie_get_draw(brie_handle *h, uint32_t *draw) {
+    if (!h || !draw) return fail(BRIE_ERR_INVALID, "null argument");
+    *draw = h->draw;
+    return BRIE_OK;
+}
+int brie_set_draw(brie_handle *h, uint32_t draw) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    h->draw = draw;
+    return BRIE_OK;
+}
+
+int brie_synchronize(brie_handle *h) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BRIE_OK;
+}
+
+int brie_profile_enable(brie_handle *h, int32_t enable) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    h->profiling = enable != 0;
+    h->ev_used = 0;
+    h->prof_ms = 0.0;
+    h->prof_launches = 0;
+    return BRIE_OK;
+}
+
+int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launches) {
+    if (!h || !kernel_ms_total || !n_launches) return fail(BRIE_ERR_INVALID, "null argument");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
+        h->prof_ms += ms;
+        h->prof_launches += 1;
+    }
+    h->ev_used = 0;
+    *kernel_ms_total = h->prof_ms;
+    *n_launches = h->prof_launches;
+    return BRIE_OK;
+}
+
+}  // extern "C"

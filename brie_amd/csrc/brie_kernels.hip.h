@@ -1,0 +1,645 @@
+// brie_kernels.hip.h -- CDNA4 (gfx950) device code of the brie-quant ELBO hot path.
+//
+// Data layout in HBM (one gene shard): every cell x gene array is (Nc, ld)
+// fp32 row-major, ld = Ng rounded up to 64 genes (256-B aligned rows), i.e.
+// exactly the reference's C-order (Nc, Ng) layers with a padded pitch.  A lane
+// owns 4 consecutive genes (one 16-B vector); a 64-lane wavefront owns a
+// 256-gene "gene block" and streams cells (rows) through it, so every global
+// access is a fully coalesced 1-KiB wave transaction and every per-gene
+// statistic is a private per-lane register accumulation over cells -- no
+// cross-lane traffic in the streaming loop.  The four waves of a workgroup
+// interleave the rows of one cell chunk and fold their per-gene partials
+// through LDS once per chunk.
+//
+// Reference semantics restated per kernel (paths relative to /root/reference):
+//   elbo_adam_step   brie/models/model_TFProb.py:118-127 (Z_prior), 130-191
+//                    (logLik_MC), 194-211 (get_loss) + tfp.math.minimize /
+//                    Keras Adam / clip constraints for Z_loc, Z_std_log (:69,81,237-241)
+//   gene_finalize    reduce_sum over cells (:208-211) + Adam for Wc_loc,
+//                    intercept, sigma_log
+//   loss_gene_eval   :261-264   psi_epilogue :88-106   init_state :12-31
+//   pseudo_count     brie/models/model_wrap.py:113-117
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace brie {
+
+constexpr int kWave = 64;
+constexpr int kVec = 4;                 // genes per lane
+constexpr int kBlock = 256;             // threads per workgroup
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kGenesPerBlock = kWave * kVec;   // 256 genes per gene block
+constexpr uint32_t kInitDraw = 0xFFFFFFFFu;
+
+#ifndef BRIE_FAST_MATH
+#define BRIE_FAST_MATH 0
+#endif
+
+// ----------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11) -> 4 standard normals per gene quad.
+// Must match oracle/philox.py bit-for-bit in the integer part.
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0;
+        const uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ float u01(uint32_t x) {
+    return (static_cast<float>(x >> 9) + 0.5f) * 0x1p-23f;      // exact in fp32, in (0,1)
+}
+
+__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &n0, float &n1) {
+    const float ua = u01(xa), ub = u01(xb);
+#if BRIE_FAST_MATH
+    const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(ua));
+    n0 = r * __builtin_amdgcn_cosf(ub);      // v_cos_f32 takes revolutions: cos(2 pi ub)
+    n1 = r * __builtin_amdgcn_sinf(ub);
+#else
+    const float r = sqrtf(-2.0f * logf(ua));
+    float sn, cs;
+    sincospif(2.0f * ub, &sn, &cs);          // angle 2 pi ub without rounding the product
+    n0 = r * cs;
+    n1 = r * sn;
+#endif
+}
+
+// eps for genes 4q..4q+3 of cell `cell` at (draw, k)
+__device__ __forceinline__ void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k,
+                                        uint32_t seed_lo, uint32_t seed_hi, float e[4]) {
+    uint32_t x[4];
+    philox4x32_10(quad, cell, draw, k, seed_lo, seed_hi, x);
+    box_muller(x[0], x[1], e[0], e[1]);
+    box_muller(x[2], x[3], e[2], e[3]);
+}
+
+// ----------------------------------------------------------------------------
+// scalar math helpers
+// ----------------------------------------------------------------------------
+__device__ __forceinline__ float f_exp(float x) {
+#if BRIE_FAST_MATH
+    return __expf(x);
+#else
+    return expf(x);
+#endif
+}
+__device__ __forceinline__ float f_log(float x) {
+#if BRIE_FAST_MATH
+    return __logf(x);
+#else
+    return logf(x);
+#endif
+}
+__device__ __forceinline__ float f_log1p(float x) {
+#if BRIE_FAST_MATH
+    // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2
+    return x < 1e-3f ? x * (1.0f - 0.5f * x) : __logf(1.0f + x);
+#else
+    return log1pf(x);
+#endif
+}
+__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float f_sqrt(float x) {
+#if BRIE_FAST_MATH
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+
+struct alignas(16) F4 { float v[4]; };
+
+__device__ __forceinline__ F4 ld4(const float *p) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    return F4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ void st4(float *p, const F4 &a) {
+    *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+
+// Likelihood modes
+enum : int { kLik2 = 0,      // 2 categories, no effLen   (model_TFProb.py:162-167)
+             kLikEff2 = 1,   // effLen, 2 count layers    (model_TFProb.py:168-183)
+             kLikEff3 = 2 }; // effLen, 3 count layers    (model_TFProb.py:184-185)
+
+// Per-sample log-likelihood l(z) and dl/dz for one element.
+template <int MODE>
+__device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
+                                       float L0, float L4, float L5,
+                                       float lL0, float lL4, float lL5,
+                                       float &ll, float &g) {
+    const float az = fabsf(z);
+    const float e = f_exp(-az);                   // exp(-|z|) in (0,1]
+    const float inv = f_rcp(1.0f + e);
+    const float big = inv, small = e * inv;       // sigmoid(|z|), sigmoid(-|z|)
+    const float sp = z >= 0.0f ? big : small;     // sigmoid(z)
+    const float sn = z >= 0.0f ? small : big;     // sigmoid(-z)
+    const float l1p = f_log1p(e);
+    const float ls1 = fminf(z, 0.0f) - l1p;       // log_sigmoid(z)
+    const float ls2 = fminf(-z, 0.0f) - l1p;      // log_sigmoid(-z)
+    if (MODE == kLik2) {
+        ll = c1 * ls1 + c2 * ls2;
+        g = c1 - (c1 + c2) * sp;
+    } else {
+        const float D = sp * L0 + sn * L4 + L5;
+        const float lD = f_log(D);
+        const float iD = f_rcp(D);
+        const float phi1 = sp * L0 * iD, phi2 = sn * L4 * iD;
+        float N = c1 + c2;
+        ll = c1 * (ls1 + lL0 - lD) + c2 * (ls2 + lL4 - lD);
+        if (MODE == kLikEff3) {
+            ll += c3 * (lL5 - lD);
+            N += c3;
+        }
+        g = c1 * sn - c2 * sp - N * (phi1 * sn - phi2 * sp);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Kernel arguments
+// ----------------------------------------------------------------------------
+struct StepArgs {
+    const float *c1, *c2, *c3;              // counts (Nc, ld)
+    float *mu, *rho;                        // Z_loc, Z_std_log (Nc, ld)
+    float *m_mu, *v_mu, *m_rho, *v_rho;     // Adam moments (Nc, ld)
+    const float *Xc;                        // (Nc, Kc) row-major
+    const float *W;                         // (Kc, ld)
+    const float *b, *lam;                   // (ld)
+    const float *effL;                      // (6, ld): L0, L4, L5, log L0, log L4, log L5
+    float *partials;                        // (n_chunks, S, ld), S = Kc + 4
+    int64_t ld;
+    int32_t Nc, Ng, rows_per_chunk, mc;
+    uint32_t seed_lo, seed_hi, draw, quad_offset;
+    float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
+    float inv_mc;
+};
+
+constexpr float kOneMinusB1 = 1.0f - 0.9f;      // as Keras computes it in fp32
+constexpr float kOneMinusB2 = 1.0f - 0.999f;
+constexpr float kAdamEps = 1e-7f;
+
+// ----------------------------------------------------------------------------
+// elbo_adam_step: one fused pass = ELBO forward + gradient + Adam for Z_loc,
+// Z_std_log + per-gene sufficient statistics.  Algorithmic HBM traffic per
+// element: read L counts + read/write mu, rho + read/write 4 moments
+// = 48 + 4L bytes.
+// ----------------------------------------------------------------------------
+template <int KC, int MODE>
+__global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
+    constexpr int S = KC + 4;
+    __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int quad = blockIdx.x * kWave + lane;          // local gene quad
+    const int j0 = quad * kVec;
+    const bool active = j0 < a.Ng;
+    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+
+    float acc[S][kVec];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
+
+    if (active) {
+        // per-gene parameters, live across the whole chunk
+        float Wk[KC > 0 ? KC : 1][kVec], bj[kVec], lamj[kVec], isig2[kVec];
+        float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const F4 t = ld4(a.W + k * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
+        }
+        {
+            const F4 tb = ld4(a.b + j0), tl = ld4(a.lam + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                bj[v] = tb.v[v];
+                lamj[v] = tl.v[v];
+                isig2[v] = f_exp(-2.0f * tl.v[v]);
+            }
+        }
+        if (MODE != kLik2) {
+            const F4 t0 = ld4(a.effL + 0 * a.ld + j0), t1 = ld4(a.effL + 1 * a.ld + j0),
+                     t2 = ld4(a.effL + 2 * a.ld + j0), t3 = ld4(a.effL + 3 * a.ld + j0),
+                     t4 = ld4(a.effL + 4 * a.ld + j0), t5 = ld4(a.effL + 5 * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
+                lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
+        }
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+
+        for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
+            const int64_t off = static_cast<int64_t>(r) * a.ld + j0;
+            const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
+            F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
+            if (MODE == kLikEff3) c3 = ld4(a.c3 + off);
+            F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
+            F4 mm = ld4(a.m_mu + off), vm = ld4(a.v_mu + off);
+            F4 mr = ld4(a.m_rho + off), vr = ld4(a.v_rho + off);
+
+            float xc[KC > 0 ? KC : 1];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xc[k] = a.Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform -> SMEM
+
+            float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
+                  ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) s[v] = f_exp(rho.v[v]);
+
+            for (int k = 0; k < a.mc; ++k) {
+                float e[kVec];
+                normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k),
+                        a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    const float z = fmaf(s[v], e[v], mu.v[v]);          // reparameterised sample
+                    float l, g;
+                    loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                                 lL0[v], lL4[v], lL5[v], l, g);
+                    ll[v] += l;
+                    gbar[v] += g;
+                    gse[v] = fmaf(g, e[v], gse[v]);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                float m = bj[v];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
+                const float d = mu.v[v] - m;
+                const float rr = d * isig2[v];                                     // (mu - m) / sigma^2
+                const float s2r = s[v] * s[v] * isig2[v];                          // s^2 / sigma^2
+                const float dl = rho.v[v] - lamj[v];
+                const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;         // KL(q || prior)
+                const float g_mu = rr - gbar[v] * a.inv_mc;
+                const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
+                // Keras Adam
+                mm.v[v] += (g_mu - mm.v[v]) * kOneMinusB1;
+                vm.v[v] += (g_mu * g_mu - vm.v[v]) * kOneMinusB2;
+                mr.v[v] += (g_rho - mr.v[v]) * kOneMinusB1;
+                vr.v[v] += (g_rho * g_rho - vr.v[v]) * kOneMinusB2;
+                float nmu = mu.v[v] - (mm.v[v] * a.alpha) * f_rcp(f_sqrt(vm.v[v]) + kAdamEps);
+                nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
+                mu.v[v] = nmu;
+                rho.v[v] -= (mr.v[v] * a.alpha) * f_rcp(f_sqrt(vr.v[v]) + kAdamEps);
+                // per-gene sufficient statistics
+#pragma unroll
+                for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
+                acc[KC + 0][v] += rr;
+                acc[KC + 1][v] += 1.0f - d * rr - s2r;
+                acc[KC + 2][v] += kl;
+                acc[KC + 3][v] += ll[v] * a.inv_mc;
+            }
+            st4(a.mu + off, mu);
+            st4(a.rho + off, rho);
+            st4(a.m_mu + off, mm);
+            st4(a.v_mu + off, vm);
+            st4(a.m_rho + off, mr);
+            st4(a.v_rho + off, vr);
+        }
+    }
+
+    // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row
+    if (w > 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int v = 0; v < kVec; ++v)
+                red[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
+    }
+    __syncthreads();
+    if (w == 0 && active) {
+        float *dst = a.partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            F4 o;
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                float t = acc[s][v];
+#pragma unroll
+                for (int ww = 0; ww < kWavesPerBlock - 1; ++ww)
+                    t += red[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
+                o.v[v] = t;
+            }
+            st4(dst + s * a.ld, o);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// gene_finalize: per gene, sum the chunk partials (fp64), Adam for Wc_loc,
+// intercept (clip +-9) and sigma_log, and emit the loss partial sums.
+// ----------------------------------------------------------------------------
+struct FinalizeArgs {
+    const float *partials;      // (n_chunks, S, ld)
+    float *W, *m_W, *v_W;       // (Kc, ld)
+    float *b, *m_b, *v_b;       // (ld)
+    float *lam, *m_lam, *v_lam; // (ld)
+    double *loss_parts;         // (n_blocks, 2): sum KL, sum ll for this step
+    float *loss_gene_step;      // (ld) per-gene loss of this step (may be null)
+    int64_t ld;
+    int32_t Ng, Kc, n_chunks, train_b, train_lam;
+    float alpha;
+};
+
+__device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float g, float alpha) {
+    m += (g - m) * kOneMinusB1;
+    v += (g * g - v) * kOneMinusB2;
+    x -= (m * alpha) / (sqrtf(v) + kAdamEps);
+}
+
+__global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int S = a.Kc + 4;
+    double kl = 0.0, ll = 0.0;
+    if (j < a.Ng) {
+        for (int s = 0; s < S; ++s) {
+            double t = 0.0;
+            for (int c = 0; c < a.n_chunks; ++c)
+                t += static_cast<double>(a.partials[(static_cast<int64_t>(c) * S + s) * a.ld + j]);
+            if (s < a.Kc) {
+                const int64_t o = static_cast<int64_t>(s) * a.ld + j;
+                float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
+                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/dW = -Xc^T r
+                a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
+            } else if (s == a.Kc) {
+                if (a.train_b) {
+                    float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
+                    adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);    // dL/db = -sum r
+                    x = fminf(fmaxf(x, -9.0f), 9.0f);
+                    a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
+                }
+            } else if (s == a.Kc + 1) {
+                if (a.train_lam) {
+                    float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
+                    adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
+                    a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
+                }
+            } else if (s == a.Kc + 2) {
+                kl = t;
+            } else {
+                ll = t;
+            }
+        }
+        if (a.loss_gene_step) a.loss_gene_step[j] = static_cast<float>(kl - ll);
+    }
+    // block reduction of (kl, ll) in fp64 -> one deterministic partial per block
+    __shared__ double sk[kBlock], sl[kBlock];
+    sk[threadIdx.x] = kl;
+    sl[threadIdx.x] = ll;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) {
+            sk[threadIdx.x] += sk[threadIdx.x + st];
+            sl[threadIdx.x] += sl[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.loss_parts[2 * blockIdx.x + 0] = sk[0];
+        a.loss_parts[2 * blockIdx.x + 1] = sl[0];
+    }
+}
+
+// ----------------------------------------------------------------------------
+// loss_gene_eval: forward-only ELBO per gene averaged over `n_rep` fresh noise
+// draws (MC_size = 1 each), reading every element ONCE: the KL term is
+// deterministic, only the likelihood term is re-sampled.
+// partials: (n_chunks, 2, ld) = sum_i KL, sum_i sum_rep ll
+// ----------------------------------------------------------------------------
+struct LossGeneArgs {
+    const float *c1, *c2, *c3, *mu, *rho, *Xc, *W, *b, *lam, *effL;
+    float *partials;
+    int64_t ld;
+    int32_t Nc, Ng, rows_per_chunk, n_rep;
+    uint32_t seed_lo, seed_hi, draw0, quad_offset;
+};
+
+template <int KC, int MODE>
+__global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
+    __shared__ float red[(kWavesPerBlock - 1) * 2 * kGenesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int quad = blockIdx.x * kWave + lane;
+    const int j0 = quad * kVec;
+    const bool active = j0 < a.Ng;
+    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+    float akl[kVec] = {0.f, 0.f, 0.f, 0.f}, all[kVec] = {0.f, 0.f, 0.f, 0.f};
+
+    if (active) {
+        float Wk[KC > 0 ? KC : 1][kVec], bj[kVec], lamj[kVec], isig2[kVec];
+        float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const F4 t = ld4(a.W + k * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
+        }
+        {
+            const F4 tb = ld4(a.b + j0), tl = ld4(a.lam + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                bj[v] = tb.v[v]; lamj[v] = tl.v[v]; isig2[v] = f_exp(-2.0f * tl.v[v]);
+            }
+        }
+        if (MODE != kLik2) {
+            const F4 t0 = ld4(a.effL + 0 * a.ld + j0), t1 = ld4(a.effL + 1 * a.ld + j0),
+                     t2 = ld4(a.effL + 2 * a.ld + j0), t3 = ld4(a.effL + 3 * a.ld + j0),
+                     t4 = ld4(a.effL + 4 * a.ld + j0), t5 = ld4(a.effL + 5 * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
+                lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
+        }
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
+            const int64_t off = static_cast<int64_t>(r) * a.ld + j0;
+            const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
+            F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
+            if (MODE == kLikEff3) c3 = ld4(a.c3 + off);
+            const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
+            float s[kVec];
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                s[v] = f_exp(rho.v[v]);
+                float m = bj[v];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) m = fmaf(a.Xc[static_cast<int64_t>(r) * KC + k], Wk[k][v], m);
+                const float d = mu.v[v] - m;
+                const float s2r = s[v] * s[v] * isig2[v];
+                akl[v] += 0.5f * d * d * isig2[v] + 0.5f * (s2r - 1.0f) - (rho.v[v] - lamj[v]);
+            }
+            float lsum[kVec] = {0.f, 0.f, 0.f, 0.f};
+            for (int rep = 0; rep < a.n_rep; ++rep) {
+                float e[kVec];
+                normal4(gquad, static_cast<uint32_t>(r), a.draw0 + static_cast<uint32_t>(rep), 0u,
+                        a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    float l, g;
+                    loglik<MODE>(fmaf(s[v], e[v], mu.v[v]), c1.v[v], c2.v[v], c3.v[v],
+                                 L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
+                    lsum[v] += l;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) all[v] += lsum[v];
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            red[((w - 1) * 2 + 0) * kGenesPerBlock + v * kWave + lane] = akl[v];
+            red[((w - 1) * 2 + 1) * kGenesPerBlock + v * kWave + lane] = all[v];
+        }
+    }
+    __syncthreads();
+    if (w == 0 && active) {
+        float *dst = a.partials + (static_cast<int64_t>(blockIdx.y) * 2) * a.ld + j0;
+        F4 o0, o1;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            float t0 = akl[v], t1 = all[v];
+#pragma unroll
+            for (int ww = 0; ww < kWavesPerBlock - 1; ++ww) {
+                t0 += red[(ww * 2 + 0) * kGenesPerBlock + v * kWave + lane];
+                t1 += red[(ww * 2 + 1) * kGenesPerBlock + v * kWave + lane];
+            }
+            o0.v[v] = t0; o1.v[v] = t1;
+        }
+        st4(dst, o0);
+        st4(dst + a.ld, o1);
+    }
+}
+
+// out[j] = sum_c KL - (sum_c LL) / n_rep
+__global__ void loss_gene_reduce(const float *partials, float *out, int64_t ld, int Ng,
+                                 int n_chunks, float inv_rep) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ng) return;
+    double kl = 0.0, ll = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+        kl += static_cast<double>(partials[(static_cast<int64_t>(c) * 2 + 0) * ld + j]);
+        ll += static_cast<double>(partials[(static_cast<int64_t>(c) * 2 + 1) * ld + j]);
+    }
+    out[j] = static_cast<float>(kl - ll * static_cast<double>(inv_rep));
+}
+
+// ----------------------------------------------------------------------------
+// small elementwise kernels (grid-stride over (Nc, ld) in float4 units)
+// ----------------------------------------------------------------------------
+// Model_init (model_TFProb.py:27-28): Z_loc ~ N(0,1), log Z_std ~ N(0,1)
+__global__ void init_z(float *mu, float *rho, int64_t ld, int Nc, int Ng, uint32_t seed_lo,
+                       uint32_t seed_hi, uint32_t quad_offset) {
+    const int quads = (Ng + kVec - 1) / kVec;
+    const int64_t total = static_cast<int64_t>(Nc) * quads;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int r = static_cast<int>(i / quads), q = static_cast<int>(i % quads);
+        F4 e0, e1;
+        normal4(quad_offset + q, r, kInitDraw, 0u, seed_lo, seed_hi, e0.v);
+        normal4(quad_offset + q, r, kInitDraw, 1u, seed_lo, seed_hi, e1.v);
+        for (int v = 0; v < kVec; ++v)
+            if (q * kVec + v >= Ng) { e0.v[v] = 0.0f; e1.v[v] = 0.0f; }
+        st4(mu + static_cast<int64_t>(r) * ld + q * kVec, e0);
+        st4(rho + static_cast<int64_t>(r) * ld + q * kVec, e1);
+    }
+}
+
+// rows of a (rows, ld) per-gene array drawn at (kInitDraw, k): Wc_loc (k=2), intercept (k=3)
+__global__ void init_gene_rows(float *dst, int64_t ld, int rows, int Ng, uint32_t k, uint32_t seed_lo,
+                               uint32_t seed_hi, uint32_t quad_offset) {
+    const int quads = (Ng + kVec - 1) / kVec;
+    const int64_t total = static_cast<int64_t>(rows) * quads;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int r = static_cast<int>(i / quads), q = static_cast<int>(i % quads);
+        F4 e;
+        normal4(quad_offset + q, r, kInitDraw, k, seed_lo, seed_hi, e.v);
+        for (int v = 0; v < kVec; ++v)
+            if (q * kVec + v >= Ng) e.v[v] = 0.0f;
+        st4(dst + static_cast<int64_t>(r) * ld + q * kVec, e);
+    }
+}
+
+__global__ void fill_f32(float *dst, int64_t n, float value) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        dst[i] = value;
+}
+
+// model_wrap.py:113-117
+__global__ void pseudo_count(float *c1, float *c2, int64_t n4, float pc) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        F4 a = ld4(c1 + 4 * i), b = ld4(c2 + 4 * i);
+#pragma unroll
+        for (int v = 0; v < kVec; ++v)
+            if (a.v[v] + b.v[v] > 0.0f) { a.v[v] += pc; b.v[v] += pc; }
+        st4(c1 + 4 * i, a);
+        st4(c2 + 4 * i, b);
+    }
+}
+
+// effL rows 3..5 = log(rows 0..2)   (tf.math.log(effLen[..., [0,4,5]]), model_TFProb.py:175-176)
+__global__ void log_rows(float *effL, int64_t ld, int Ng) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ng) return;
+    for (int s = 0; s < 3; ++s) effL[(3 + s) * ld + j] = logf(effL[s * ld + j]);
+}
+
+// mode 0: Psi = sigmoid(mu); 1: Z_std = exp(rho); 2: CI95 = sig(mu+z s) - sig(mu-z s)
+__device__ __forceinline__ float sigmoid_acc(float x) {
+    const float e = expf(-fabsf(x));
+    return x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+}
+__global__ void psi_epilogue(const float *mu, const float *rho, float *out, int64_t n4, int mode) {
+    constexpr float kZ975 = 1.959963984540054f;     // ndtri(0.975)
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const F4 m = ld4(mu + 4 * i), r = ld4(rho + 4 * i);
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            if (mode == 0) o.v[v] = sigmoid_acc(m.v[v]);
+            else if (mode == 1) o.v[v] = expf(r.v[v]);
+            else {
+                const float s = expf(r.v[v]);
+                o.v[v] = sigmoid_acc(m.v[v] + kZ975 * s) - sigmoid_acc(m.v[v] - kZ975 * s);
+            }
+        }
+        st4(out + 4 * i, o);
+    }
+}
+
+__global__ void exp_vec(const float *src, float *dst, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) dst[j] = expf(src[j]);
+}
+
+}  // namespace brie

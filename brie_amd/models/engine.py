@@ -1,0 +1,226 @@
+"""`BRIE2` -- the reference's model class, backed by HIP kernels on MI355X.
+
+Mirrors the constructor / `fit` / `get_loss` signatures and the attributes of
+`brie.models.BRIE2` (/root/reference/brie/models/model_TFProb.py:35-273) so
+that `BRIE_RV` and callers written against the reference keep working; the
+variational EM loop itself runs in `libbrie_amd.so` through the C ABI of
+`include/brie_amd.h`.  There is no CPU path.
+
+Deviations from the reference (documented in DESIGN.md):
+ * noise and initial state come from a seeded Philox4x32-10 stream (the
+   reference is unseeded); `seed=` is a new optional argument;
+ * all genes of a shard are fitted concurrently (the reference loops over
+   ~`batch_size/Nc`-gene batches); convergence is decided on the shard's summed
+   loss trace;
+ * `Kg > 0`, `intercept_mode='cell'` and `target='marginLik'` couple genes and
+   raise NotImplementedError.
+"""
+import time
+
+import numpy as np
+
+from .. import _capi
+
+#: staged learning rates of BRIE2.fit (model_TFProb.py:234)
+LEARNING_RATES = (0.001, 0.005, 0.01, 0.02, 0.01, 0.005)
+
+
+class HostArray(np.ndarray):
+    """ndarray that also answers `.numpy()` like the tf tensors BRIE_RV reads
+    (model_wrap.py:28-38)."""
+
+    def numpy(self):
+        return np.asarray(self)
+
+
+def _wrap(a):
+    return np.asarray(a).view(HostArray)
+
+
+def _dense_f32(x):
+    """logLik_MC densifies sparse layers (model_TFProb.py:135-137)."""
+    if hasattr(x, "toarray"):
+        x = x.toarray()
+    if hasattr(x, "data_ptr"):
+        return x
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+class BRIE2(object):
+    """
+    Ng : number of genes,  Nc : number of cells,
+    Kg : number of gene features,  Kc : number of cell features
+    (same arguments as model_TFProb.py:42-45, plus seed / device / gene_offset).
+    """
+
+    def __init__(self, Nc, Ng, Kc=0, Kg=0, effLen=None, intercept=None, intercept_mode='gene',
+                 sigma=None, tau_prior=[3, 27], name=None, init_obj=None,
+                 seed=0, device=0, gene_offset=0):
+        self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
+        self.effLen = effLen                       # (Ng, 3 * 2)
+        self.intercept_mode = intercept_mode
+        self._intercept_value, self._sigma_value = intercept, sigma
+        self._init_obj = init_obj
+        self.seed, self.device, self.gene_offset = int(seed), int(device), int(gene_offset)
+        self.Xc = self.Xg = None
+        self._shard = None
+        self._n_layers = None
+        self._pseudo_count = None
+        if self.Kg != 0:
+            raise NotImplementedError("Kg > 0 couples genes (SURVEY.md 8f-4): not built")
+        if str(intercept_mode).upper() == 'CELL':
+            raise NotImplementedError("intercept_mode='cell' couples genes (SURVEY.md 8f-4): not built")
+        if self.Kc > _capi.MAX_KC:
+            raise NotImplementedError("Kc=%d > %d" % (self.Kc, _capi.MAX_KC))
+
+    # ------------------------------------------------------------------ device state
+    def _ensure_shard(self, count_layers, Xc):
+        n_layers = len(count_layers)
+        if self.effLen is None:
+            n_layers = 2                          # third layer unused without effLen (model_TFProb.py:162-167)
+        if self._shard is not None and self._n_layers == n_layers:
+            return self._shard
+        sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
+                         train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
+                         seed=self.seed, device=self.device, gene_offset=self.gene_offset)
+        for l in range(n_layers):
+            sh.upload(_capi.COUNT1 + l, _dense_f32(count_layers[l]))
+        if self._pseudo_count:
+            sh.add_pseudo_count(self._pseudo_count)
+        if self.effLen is not None:
+            sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
+        if self.Kc > 0:
+            if Xc is None:
+                raise ValueError("Kc=%d but Xc is None" % self.Kc)
+            sh.upload(_capi.XC, np.ascontiguousarray(Xc, dtype=np.float32))
+        io = self._init_obj
+        if io is None:
+            sh.init_state(self._intercept_value, self._sigma_value)       # Model_init, model_TFProb.py:12-31
+        else:                                                             # init_obj hook, model_TFProb.py:62-84
+            sh.init_state(self._intercept_value, self._sigma_value)
+            get = (lambda k: io[k]) if isinstance(io, dict) else (lambda k: getattr(io, k))
+            sh.upload(_capi.Z_LOC, np.asarray(get('Z_loc'), np.float32))
+            if isinstance(io, dict) and 'Z_std_log' in io:
+                sh.upload(_capi.Z_STD_LOG, np.asarray(io['Z_std_log'], np.float32))
+            else:
+                sh.upload(_capi.Z_STD_LOG, np.log(np.asarray(get('Z_std'), np.float32)))
+            if self.Kc > 0:
+                sh.upload(_capi.WC_LOC, np.asarray(get('Wc_loc'), np.float32).reshape(self.Kc, self.Ng))
+            sh.upload(_capi.INTERCEPT, np.asarray(get('intercept'), np.float32).reshape(1, self.Ng))
+            if isinstance(io, dict) and 'sigma_log' in io:
+                sh.upload(_capi.SIGMA_LOG, np.asarray(io['sigma_log'], np.float32).reshape(1, self.Ng))
+            else:
+                sh.upload(_capi.SIGMA_LOG, np.log(np.asarray(get('sigma'), np.float32)).reshape(1, self.Ng))
+        self._shard, self._n_layers = sh, n_layers
+        return sh
+
+    def _need(self):
+        if self._shard is None:
+            raise RuntimeError("BRIE2 state lives on the GPU and is created by fit()/get_loss()")
+        return self._shard
+
+    # ------------------------------------------------------------------ properties (model_TFProb.py:87-116)
+    @property
+    def Z_loc(self):
+        return _wrap(self._need().read(_capi.Z_LOC))
+
+    @property
+    def Z_std_log(self):
+        return _wrap(self._need().read(_capi.Z_STD_LOG))
+
+    @property
+    def Z_std(self):
+        return _wrap(self._need().read(_capi.Z_STD))
+
+    @property
+    def Psi(self):
+        """sigmoid(Z_loc) (model_TFProb.py:92-95)"""
+        return _wrap(self._need().read(_capi.PSI))
+
+    @property
+    def Psi95CI(self):
+        """Width of the 95% interval of the logit-normal posterior (model_TFProb.py:102-106); plain ndarray."""
+        return self._need().read(_capi.PSI95CI)
+
+    @property
+    def sigma(self):
+        return _wrap(self._need().read(_capi.SIGMA))
+
+    @property
+    def sigma_log(self):
+        return _wrap(self._need().read(_capi.SIGMA_LOG))
+
+    @property
+    def intercept(self):
+        return _wrap(self._need().read(_capi.INTERCEPT))
+
+    @property
+    def Wc_loc(self):
+        return _wrap(self._need().read(_capi.WC_LOC))
+
+    @property
+    def Wg_loc(self):
+        return _wrap(np.zeros((self.Nc, 0), np.float32))
+
+    # ------------------------------------------------------------------ loss (model_TFProb.py:194-211)
+    def get_loss(self, count_layers, target="ELBO", axis=None, **kwargs):
+        """One stochastic evaluation of the ELBO loss (no parameter update).
+
+        axis=None -> scalar, axis=0 -> per gene.  Advances the noise stream by one draw.
+        """
+        if target != "ELBO":
+            raise NotImplementedError("target='marginLik' (SURVEY.md 8f-4): not built")
+        sh = self._ensure_shard(count_layers, self.Xc)
+        mc = int(kwargs.get("MC_size", 1))
+        if mc != 1:
+            raise NotImplementedError("get_loss outside fit supports MC_size=1")
+        lg = sh.loss_gene(1)
+        if axis is None:
+            return _wrap(np.float32(lg.astype(np.float64).sum()))
+        if axis == 0:
+            return _wrap(lg)
+        raise NotImplementedError("axis=%r" % (axis,))
+
+    # ------------------------------------------------------------------ fit (model_TFProb.py:214-273)
+    def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
+            min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
+            n_loss_gene=500, pseudo_count=None, **kwargs):
+        """Fit the model's parameters; returns the loss trace like the reference.
+
+        `optimizer` / `learn_rate` are accepted and ignored exactly as in the
+        reference (overwritten at model_TFProb.py:228-237).
+        """
+        start_time = time.time()
+        if target != "ELBO":
+            raise NotImplementedError("target='marginLik' (SURVEY.md 8f-4): not built")
+        MC_size = int(kwargs.pop("MC_size", 1))
+        if kwargs:
+            raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
+        self.Xc, self.Xg, self.target = Xc, Xg, target
+        self._pseudo_count = pseudo_count
+        sh = self._ensure_shard(count_layers, Xc)
+
+        losses = np.zeros(0, np.float32)
+        for i in range(6):                                           # model_TFProb.py:235-241
+            sh.reset_optimizer()                                     # fresh Adam per stage
+            losses = sh.step(int(min_iter / 6), LEARNING_RATES[i], MC_size)
+        n_iter = min_iter + 0                                        # model_TFProb.py:247-258
+        d1 = int(min(50, add_iter / 2))
+        d2 = d1 * 2
+        while (len(losses) >= d2 and d1 > 0 and
+               losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv and n_iter < max_iter):
+            n_iter += add_iter
+            losses = np.concatenate([losses, sh.step(add_iter, LEARNING_RATES[5], MC_size)])
+
+        self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
+        self.losses = _wrap(losses)
+        self.n_iter = n_iter
+        if verbose:
+            print("[BRIE2] model fit with %d steps in %.2f min, loss: %.2f" % (
+                n_iter, (time.time() - start_time) / 60, float(np.sum(self.loss_gene))))
+        return self.losses
+
+    def close(self):
+        if self._shard is not None:
+            self._shard.close()
+            self._shard = None

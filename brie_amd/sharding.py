@@ -1,0 +1,74 @@
+"""Gene sharding over the GPUs of one node.
+
+Genes are independent whenever Kg == 0 and intercept_mode != 'cell' -- the
+very condition under which the reference splits genes into sequential batches
+(model_wrap.py:241-260).  Here each rank (one process per GPU) owns one
+contiguous gene block; no collective is needed inside the optimisation loop.
+RCCL (torch.distributed backend "nccl") is used only for
+  * the end-of-fit all-gather of per-gene vectors (weights, intercept, sigma,
+    loss_gene, ELBO_gain) -- BASELINE's "RCCL weight all-gather", and
+  * the all-reduce of the short loss-trace windows that drive the (global)
+    convergence decision.
+Cell x gene matrices (Psi, Z_std, Psi_95CI) stay sharded.
+"""
+import numpy as np
+
+
+def gene_shard(Ng, rank, world):
+    """[g0, g1) of `rank`; boundaries are multiples of 4 (one Philox draw = one gene quad)."""
+    per = -(-int(Ng) // int(world))
+    per = -(-per // 4) * 4
+    g0 = min(rank * per, Ng)
+    g1 = min(g0 + per, Ng)
+    return g0, g1
+
+
+class GeneComm(object):
+    """torch.distributed plumbing for gene-sharded fits (RCCL on GPU, gloo on CPU)."""
+
+    def __init__(self, group=None, device=None):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.device = device
+
+    def _tensor(self, a, dtype=None):
+        import torch
+        t = torch.as_tensor(np.ascontiguousarray(a))
+        if dtype is not None:
+            t = t.to(dtype)
+        if self.backend == "nccl":
+            t = t.to(self.device if self.device is not None else "cuda")
+        return t
+
+    def allreduce_sum(self, a):
+        """Sum a small host vector over ranks (fp64 on the wire)."""
+        import torch
+        t = self._tensor(np.asarray(a, np.float64), torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def allgather_genes(self, local, Ng):
+        """local (k, n_local) per-gene rows -> (k, Ng) on every rank."""
+        import torch
+        local = np.asarray(local, np.float32)
+        if local.ndim == 1:
+            local = local.reshape(1, -1)
+        k = local.shape[0]
+        per = gene_shard(Ng, 0, self.world)[1]
+        buf = np.zeros((k, per), np.float32)
+        buf[:, :local.shape[1]] = local
+        t = self._tensor(buf)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        full = np.concatenate([o.cpu().numpy() for o in out], axis=1)
+        keep = np.concatenate([np.arange(r * per, r * per + (gene_shard(Ng, r, self.world)[1] -
+                                                              gene_shard(Ng, r, self.world)[0]))
+                               for r in range(self.world)]) if self.world > 1 else np.arange(Ng)
+        return full[:, keep.astype(np.int64)]
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)

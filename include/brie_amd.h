@@ -1,0 +1,150 @@
+/*
+ * brie_amd.h -- C ABI of the MI355X-native brie-quant inference core.
+ *
+ * The reference (huangyh09/brie v2.3.0) has NO native/FFI boundary on this
+ * path: the per-gene variational ELBO loop lives behind plain Python
+ * callables (brie/models/__init__.py:1-2) whose arithmetic is executed by
+ * TensorFlow / TensorFlow-Probability.  This header is the boundary a
+ * maintainer would bind instead (ctypes / cffi ABI mode).
+ * Each entry point cites the reference code it replaces
+ * (paths relative to /root/reference/).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - every function returns BRIE_OK (0) or a negative brie_status; the message
+ *    of the last failure on the calling thread is brie_last_error().
+ *  - all matrices are float32, row-major, `ld` = elements between rows.
+ *    Cell x gene matrices are (Nc, Ng) C-order exactly as the reference's
+ *    count layers (brie/models/model_wrap.py:108-111); no host repack needed.
+ *  - `src`/`dst` may be host OR device pointers (hipMemcpyDefault); the
+ *    library copies in at upload and out at read and never retains them.
+ *  - a handle owns one gene shard on one device; a handle is not thread-safe,
+ *    distinct handles are independent.
+ */
+#ifndef BRIE_AMD_H
+#define BRIE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRIE_AMD_ABI_VERSION 1
+
+typedef enum brie_status {
+    BRIE_OK = 0,
+    BRIE_ERR_INVALID = -1,      /* bad argument / shape                     */
+    BRIE_ERR_STATE = -2,        /* call order: something not uploaded yet   */
+    BRIE_ERR_HIP = -3,          /* HIP runtime failure (no GPU, OOM, ...)   */
+    BRIE_ERR_UNSUPPORTED = -4   /* mode outside the hot path built so far   */
+} brie_status;
+
+/* Arrays addressable through brie_upload / brie_read. */
+typedef enum brie_array {
+    /* inputs (upload) */
+    BRIE_COUNT1 = 0,      /* (Nc, Ng) isoform1 / spliced   -- count_layers[0], model_TFProb.py:165 */
+    BRIE_COUNT2 = 1,      /* (Nc, Ng) isoform2 / unspliced -- count_layers[1], model_TFProb.py:166 */
+    BRIE_COUNT3 = 2,      /* (Nc, Ng) ambiguous            -- count_layers[2], model_TFProb.py:184-185 */
+    BRIE_XC = 3,          /* (Nc, Kc) cell features        -- model_TFProb.py:220 */
+    BRIE_EFFLEN = 4,      /* (Ng, 6) effective lengths     -- model_TFProb.py:49,175-176 */
+    /* state (upload = warm start / init_obj hook model_TFProb.py:45,62-65; read) */
+    BRIE_Z_LOC = 8,       /* (Nc, Ng)  model_TFProb.py:80 */
+    BRIE_Z_STD_LOG = 9,   /* (Nc, Ng)  model_TFProb.py:82 */
+    BRIE_WC_LOC = 10,     /* (Kc, Ng)  model_TFProb.py:84 */
+    BRIE_INTERCEPT = 11,  /* (1, Ng)   model_TFProb.py:67-71 */
+    BRIE_SIGMA_LOG = 12,  /* (1, Ng)   model_TFProb.py:73-78 */
+    /* derived (read only) */
+    BRIE_PSI = 16,        /* (Nc, Ng) sigmoid(Z_loc)              model_TFProb.py:92-95 */
+    BRIE_Z_STD = 17,      /* (Nc, Ng) exp(Z_std_log)              model_TFProb.py:88-90 */
+    BRIE_PSI95CI = 18,    /* (Nc, Ng) q(.975)-q(.025) logit-normal model_TFProb.py:102-106 */
+    BRIE_SIGMA = 19       /* (1, Ng)  exp(sigma_log)              model_TFProb.py:108-111 */
+} brie_array;
+
+/* Problem description == the constructor arguments of BRIE2
+ * (brie/models/model_TFProb.py:42-45) for one gene shard. */
+typedef struct brie_problem {
+    int32_t abi_version;      /* BRIE_AMD_ABI_VERSION */
+    int32_t device;           /* HIP device ordinal */
+    int64_t Nc;               /* cells */
+    int64_t Ng;               /* genes in this shard */
+    int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
+                                 keys the noise stream so results do not depend on sharding */
+    int32_t Kc;               /* cell features (0..BRIE_MAX_KC) */
+    int32_t Kg;               /* gene features: must be 0 (coupled mode) */
+    int32_t n_layers;         /* 2 or 3 count layers */
+    int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
+                                 1: effLen likelihood (model_TFProb.py:168-185) */
+    int32_t intercept_mode;   /* 0 = 'gene' (1,Ng); 1 = 'cell' -> BRIE_ERR_UNSUPPORTED */
+    int32_t train_intercept;  /* 1: intercept is a variable clipped to [-9,9] (model_TFProb.py:67-69) */
+    int32_t train_sigma;      /* 1: sigma_log is a variable (model_TFProb.py:73-75) */
+    int32_t reserved;
+    uint64_t seed;            /* key of the Philox4x32-10 noise stream */
+} brie_problem;
+
+#define BRIE_MAX_KC 8
+
+typedef struct brie_handle brie_handle;
+
+/* BRIE2.__init__ (model_TFProb.py:42-85): allocate the shard's state in HBM. */
+int brie_create(const brie_problem *problem, brie_handle **out);
+int brie_destroy(brie_handle *h);
+
+/* Copy a host or device matrix into the shard (densified fp32 layers of
+ * model_wrap.py:108-111; Xc of model_TFProb.py:220; init_obj of :62-65). */
+int brie_upload(brie_handle *h, int which, const float *src,
+                int64_t rows, int64_t cols, int64_t ld);
+
+/* model_wrap.py:113-117: where count1+count2 > 0 add `pseudo_count` to BOTH
+ * unique layers -- applied to the device copy, caller arrays are untouched. */
+int brie_add_pseudo_count(brie_handle *h, float pseudo_count);
+
+/* Model_init (model_TFProb.py:12-31) drawn from the shared Philox stream
+ * (draw id 0xFFFFFFFF; k=0 Z_loc, 1 log Z_std, 2 Wc_loc, 3 intercept).
+ * `intercept` / `sigma`: NaN = reference default (N(0,1) / ones), otherwise the
+ * constant of model_TFProb.py:20,25. */
+int brie_init_state(brie_handle *h, float intercept, float sigma);
+
+/* A fresh tf.optimizers.Adam (model_TFProb.py:237): zero moments, iteration 0. */
+int brie_reset_optimizer(brie_handle *h);
+
+/* tfp.math.minimize(loss_fn, num_steps, optimizer) (model_TFProb.py:239-241,
+ * 255-257) with Keras Adam(lr) + the clip[-9,9] constraints (:69,81).
+ * `loss_trace` (host, n_steps floats, may be NULL) receives the ELBO loss
+ * BEFORE each update.  With loss_trace == NULL the call only enqueues work. */
+int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
+              float *loss_trace);
+
+/* model_TFProb.py:261-264: mean over `n_repeats` stochastic evaluations of
+ * get_loss(axis=0) with MC_size = 1 -> out[Ng] (host). */
+int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out);
+
+/* BRIE_RV.__init__ (model_wrap.py:18-40): copy state / derived arrays out. */
+int brie_read(brie_handle *h, int which, float *dst,
+              int64_t rows, int64_t cols, int64_t ld);
+
+/* Noise-draw counter (one draw id per loss evaluation). */
+int brie_get_draw(brie_handle *h, uint32_t *draw);
+int brie_set_draw(brie_handle *h, uint32_t draw);
+
+/* Block until all enqueued work of this handle is done. */
+int brie_synchronize(brie_handle *h);
+
+/* Per-launch HIP-event timing of the dominant kernel (elbo_adam_step) on the
+ * handle's own stream, for bench.py's roofline.  enable=1 starts/clears. */
+int brie_profile_enable(brie_handle *h, int32_t enable);
+int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launches);
+
+/* Tuning knobs of the tiling (0 = library default). */
+int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk);
+
+/* Algorithmic HBM bytes of one elbo_adam_step launch: Nc*Ng*(48 + 4*n_layers). */
+int64_t brie_step_algorithmic_bytes(const brie_handle *h);
+
+const char *brie_last_error(void);
+int brie_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRIE_AMD_H */

@@ -1,0 +1,277 @@
+"""NumPy restatement of the BRIE2 ELBO hot path.  TEST INFRASTRUCTURE ONLY.
+
+Follows /root/reference/brie/models/model_TFProb.py (cited per function as
+`ref:LINE`) with the third-party TF/TFP semantics restated as described in
+oracle/__init__.py.  Gradients are hand-derived and are
+pinned against torch autograd in tests/test_oracle_grad.py.
+
+Shapes: counts L x (Nc, Ng); Xc (Nc, Kc); Z_loc, Z_std_log (Nc, Ng);
+Wc_loc (Kc, Ng); intercept, sigma_log (1, Ng)  [intercept_mode='gene'].
+`dtype` = np.float32 reproduces the reference's precision; np.float64 gives
+the precision-independent answer used to bound fp32 effects.
+"""
+import numpy as np
+
+from . import philox
+
+LEARNING_RATES = (0.001, 0.005, 0.01, 0.02, 0.01, 0.005)    # ref:234
+Z975 = 1.959963984540054                                     # ndtri(0.975), ref:105-106 via tfd.LogitNormal.quantile
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7                # tf.optimizers.Adam defaults (ref:237)
+
+
+def log_sigmoid(x):
+    """tf.math.log_sigmoid (ref:163-164): -softplus(-x), evaluated stably."""
+    return np.minimum(x, 0) - np.log1p(np.exp(-np.abs(x)))
+
+
+def sigmoid(x):
+    """tf.sigmoid (ref:95), evaluated stably in x's dtype."""
+    e = np.exp(-np.abs(x))
+    return np.where(x >= 0, 1 / (1 + e), e / (1 + e)).astype(x.dtype)
+
+
+def add_pseudo_count(data, pseudo_count=0.01):
+    """model_wrap.py:113-117 -- +pc on BOTH unique layers where c1+c2 > 0 (returns copies)."""
+    data = [np.array(d, dtype=np.float32, copy=True) for d in data]
+    idx = data[0] + data[1] > 0
+    for i in range(2):
+        data[i][idx] = data[i][idx] + np.float32(pseudo_count)
+    return data
+
+
+class AdamSlot(object):
+    """One Keras-style Adam optimiser variable slot."""
+
+    def __init__(self, shape, dtype):
+        self.m = np.zeros(shape, dtype)
+        self.v = np.zeros(shape, dtype)
+
+
+class OracleBRIE2(object):
+    """Restatement of `BRIE2` (ref:35-273), gene intercept mode, Kg = 0."""
+
+    def __init__(self, Nc, Ng, Kc=0, effLen=None, intercept=None, sigma=None,
+                 seed=0, gene_offset=0, dtype=np.float32, init=None):
+        self.Nc, self.Ng, self.Kc = int(Nc), int(Ng), int(Kc)
+        self.dtype = np.dtype(dtype)
+        self.seed, self.gene_offset = int(seed), int(gene_offset)
+        self.effLen = None if effLen is None else np.asarray(effLen, np.float64)
+        self.train_intercept = intercept is None        # ref:67-71
+        self.train_sigma = sigma is None                # ref:73-78
+        self.draw = 0                                   # global noise-draw counter
+        dt = self.dtype
+        if init is None:
+            init = self.model_init(intercept, sigma)
+        self.Z_loc = np.array(init['Z_loc'], dt)                    # ref:80
+        self.Z_std_log = np.array(init['Z_std_log'], dt)            # ref:82 (log of Z_std)
+        self.Wc_loc = np.array(init['Wc_loc'], dt).reshape(self.Kc, self.Ng)    # ref:84
+        self.intercept = np.array(init['intercept'], dt).reshape(1, self.Ng)    # ref:67-71
+        self.sigma_log = np.array(init['sigma_log'], dt).reshape(1, self.Ng)    # ref:73-78
+        self.reset_optimizer()
+
+    # ------------------------------------------------------------------ init
+    def model_init(self, intercept=None, sigma=None):
+        """`Model_init` (ref:12-31) with the unseeded tf.random.normal replaced by
+        the shared Philox stream at draw id INIT_DRAW:
+        k=0 Z_loc, k=1 log Z_std (Z_std = exp(N(0,1)), ref:28), k=2 Wc_loc rows
+        (cell index = feature index), k=3 intercept (cell index 0)."""
+        Nc, Ng, Kc, go = self.Nc, self.Ng, self.Kc, self.gene_offset
+        D = philox.INIT_DRAW
+        out = {
+            'Z_loc': philox.normal(self.seed, D, 0, Nc, Ng, go),
+            'Z_std_log': philox.normal(self.seed, D, 1, Nc, Ng, go),
+            'Wc_loc': philox.normal(self.seed, D, 2, Kc, Ng, go) if Kc > 0
+            else np.zeros((0, Ng), np.float32),
+        }
+        if intercept is None:
+            out['intercept'] = philox.normal(self.seed, D, 3, 1, Ng, go)          # ref:17-18
+        else:
+            out['intercept'] = np.ones((1, Ng), np.float32) * np.float32(intercept)   # ref:20
+        if sigma is None:
+            out['sigma_log'] = np.zeros((1, Ng), np.float32)                      # log(ones), ref:23,74
+        else:
+            out['sigma_log'] = np.log(np.ones((1, Ng), np.float32) * np.float32(sigma))   # ref:25,77
+        return out
+
+    def reset_optimizer(self):
+        """A fresh `tf.optimizers.Adam` (ref:237): zero moments, iteration 0."""
+        dt = self.dtype
+        self.t = 0
+        self.slots = {n: AdamSlot(getattr(self, n).shape, dt)
+                      for n in ('Z_loc', 'Z_std_log', 'Wc_loc', 'intercept', 'sigma_log')}
+
+    # ------------------------------------------------------------ properties
+    @property
+    def Z_std(self):            # ref:88-90
+        return np.exp(self.Z_std_log)
+
+    @property
+    def sigma(self):            # ref:108-111
+        return np.exp(self.sigma_log)
+
+    @property
+    def Psi(self):              # ref:92-95  sigmoid(Z_loc)
+        return sigmoid(self.Z_loc)
+
+    @property
+    def Psi95CI(self):          # ref:102-106
+        s = self.Z_std
+        return sigmoid(self.Z_loc + self.dtype.type(Z975) * s) - \
+            sigmoid(self.Z_loc - self.dtype.type(Z975) * s)
+
+    def prior_mean(self, Xc):   # ref:118-127 (Kg = 0)
+        m = np.zeros((self.Nc, self.Ng), self.dtype)
+        if self.Kc > 0 and Xc is not None:
+            m = np.matmul(np.asarray(Xc, self.dtype), self.Wc_loc)
+        return m + self.intercept
+
+    # ------------------------------------------------------------- noise
+    def noise(self, MC_size):
+        """eps (MC, Nc, Ng) for the current draw id; advances the draw counter."""
+        e = np.stack([philox.normal(self.seed, self.draw, k, self.Nc, self.Ng, self.gene_offset)
+                      for k in range(MC_size)], axis=0)
+        self.draw += 1
+        return e.astype(self.dtype)
+
+    # ------------------------------------------------------------- loss
+    def loglik_terms(self, counts, z):
+        """Per-sample log-likelihood l(z) and dl/dz  (ref:161-185).
+
+        No effLen (ref:162-167): l = c1 logsig(z) + c2 logsig(-z).
+        effLen (ref:168-185): log phi = a - logsumexp(a),
+            a = [logsig(z)+log L0, logsig(-z)+log L4, log L5], effLen[:, [0,4,5]] (ref:176).
+        """
+        dt = self.dtype
+        c1, c2 = counts[0], counts[1]
+        ls1, ls2 = log_sigmoid(z), log_sigmoid(-z)
+        if self.effLen is None:
+            ll = c1 * ls1 + c2 * ls2
+            g = c1 - (c1 + c2) * sigmoid(z)
+            return ll, g
+        logL = np.log(self.effLen[:, [0, 4, 5]]).astype(dt)          # (Ng, 3)
+        a = np.stack([ls1 + logL[:, 0], ls2 + logL[:, 1],
+                      np.zeros_like(z) + logL[:, 2]], axis=-1)
+        amax = a.max(axis=-1, keepdims=True)
+        lse = amax + np.log(np.exp(a - amax).sum(axis=-1, keepdims=True))
+        lphi = a - lse
+        ll = c1 * lphi[..., 0] + c2 * lphi[..., 1]
+        N = c1 + c2
+        if len(counts) > 2:                                           # ref:184-185
+            ll = ll + counts[2] * lphi[..., 2]
+            N = N + counts[2]
+        psi = sigmoid(z)
+        phi = np.exp(lphi)
+        g = c1 * (1 - psi) - c2 * psi - N * (phi[..., 0] * (1 - psi) - phi[..., 1] * psi)
+        return ll.astype(dt), g.astype(dt)
+
+    def loss_and_grads(self, counts, Xc, MC_size=1, eps=None, need_grads=True):
+        """`get_loss(target="ELBO")` (ref:194-211) + its gradient.
+
+        Returns dict with scalar `loss` (= sum KL - sum ll, each reduced
+        separately, ref:208-211), per-gene `loss_gene` (axis=0) and gradients.
+        """
+        dt = self.dtype
+        counts = [np.asarray(c, dt) for c in counts]
+        if eps is None:
+            eps = self.noise(MC_size)
+        mu, rho, lam = self.Z_loc, self.Z_std_log, self.sigma_log
+        s = np.exp(rho)
+        m = self.prior_mean(Xc)
+        d = mu - m
+        inv_sig2 = np.exp(-2 * lam)
+        # tfd.kl_divergence(Normal, Normal) (ref:208; TFP _kl_normal_normal)
+        kl = 0.5 * (d * d) * inv_sig2 + 0.5 * np.expm1(2 * (rho - lam)) - (rho - lam)
+        ll = np.zeros_like(mu)
+        gbar = np.zeros_like(mu)
+        gse = np.zeros_like(mu)
+        for k in range(eps.shape[0]):
+            z = mu + s * eps[k]                     # Normal.sample reparameterisation (ref:159)
+            ll_k, g_k = self.loglik_terms(counts, z)
+            ll += ll_k
+            gbar += g_k
+            gse += g_k * s * eps[k]
+        K = dt.type(eps.shape[0])
+        ll /= K                                      # reduce_mean over MC (ref:191)
+        gbar /= K
+        gse /= K
+        kl_gene = kl.sum(axis=0)
+        ll_gene = ll.sum(axis=0)
+        out = {'loss': kl.sum() - ll.sum(), 'loss_gene': kl_gene - ll_gene,
+               'kl_gene': kl_gene, 'll_gene': ll_gene}
+        if not need_grads:
+            return out
+        r = d * inv_sig2
+        s2 = s * s * inv_sig2
+        out['Z_loc'] = r - gbar
+        out['Z_std_log'] = s2 - 1 - gse
+        if self.Kc > 0:
+            out['Wc_loc'] = -np.matmul(np.asarray(Xc, dt).T, r)
+        out['intercept'] = -r.sum(axis=0, keepdims=True)
+        out['sigma_log'] = (1 - d * d * inv_sig2 - s2).sum(axis=0, keepdims=True)
+        return out
+
+    # ------------------------------------------------------------- Adam
+    def trainable(self):
+        names = ['Z_loc', 'Z_std_log']
+        if self.Kc > 0:
+            names.append('Wc_loc')
+        if self.train_intercept:
+            names.append('intercept')
+        if self.train_sigma:
+            names.append('sigma_log')
+        return names
+
+    def adam_step(self, grads, lr):
+        """Keras Adam `update_step` + variable constraints."""
+        dt = self.dtype.type
+        self.t += 1
+        b1p = np.power(dt(ADAM_B1), dt(self.t))
+        b2p = np.power(dt(ADAM_B2), dt(self.t))
+        alpha = dt(lr) * np.sqrt(dt(1) - b2p) / (dt(1) - b1p)
+        for name in self.trainable():
+            g = grads[name].astype(self.dtype)
+            slot = self.slots[name]
+            slot.m += (g - slot.m) * (dt(1) - dt(ADAM_B1))
+            slot.v += (g * g - slot.v) * (dt(1) - dt(ADAM_B2))
+            var = getattr(self, name)
+            var -= (slot.m * alpha) / (np.sqrt(slot.v) + dt(ADAM_EPS))
+            if name in ('Z_loc', 'intercept'):          # clip_by_value constraint (ref:69,81)
+                np.clip(var, dt(-9), dt(9), out=var)
+
+    def minimize(self, counts, Xc, num_steps, lr, MC_size=1):
+        """`tfp.math.minimize` (ref:239-241): trace = loss BEFORE each update."""
+        trace = np.zeros(num_steps, self.dtype)
+        for i in range(num_steps):
+            out = self.loss_and_grads(counts, Xc, MC_size)
+            trace[i] = out['loss']
+            self.adam_step(out, lr)
+        return trace
+
+    # ------------------------------------------------------------- fit
+    def fit(self, counts, Xc=None, min_iter=1000, max_iter=5000, add_iter=500,
+            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500):
+        """`BRIE2.fit` (ref:214-273)."""
+        self.Xc = Xc
+        for i in range(6):                                   # ref:235-241
+            self.reset_optimizer()
+            losses = self.minimize(counts, Xc, int(min_iter / 6), LEARNING_RATES[i], MC_size)
+        n_iter = min_iter + 0                                # ref:247
+        d1 = int(min(50, add_iter / 2))                      # ref:248
+        d2 = d1 * 2
+        while (losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv
+               and n_iter < max_iter):                       # ref:250-251
+            n_iter += add_iter
+            losses = np.concatenate([losses, self.minimize(
+                counts, Xc, add_iter, LEARNING_RATES[5], MC_size)])
+        self.n_iter = n_iter
+        self.loss_gene = self.eval_loss_gene(counts, Xc, n_loss_gene)
+        self.losses = losses
+        return losses
+
+    def eval_loss_gene(self, counts, Xc, n_repeats=500):
+        """ref:261-264 -- mean of `n_repeats` stochastic get_loss(axis=0), MC_size=1
+        (the call at ref:261 does not forward **kwargs)."""
+        acc = np.zeros(self.Ng, self.dtype)
+        for _ in range(n_repeats):
+            acc += self.loss_and_grads(counts, Xc, 1, need_grads=False)['loss_gene']
+        return acc / self.dtype.type(n_repeats)

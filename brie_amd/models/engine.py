@@ -184,7 +184,7 @@ class BRIE2(object):
     # ------------------------------------------------------------------ fit (model_TFProb.py:214-273)
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
-            n_loss_gene=500, pseudo_count=None, **kwargs):
+            n_loss_gene=500, pseudo_count=None, trace_reduce=None, **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
@@ -200,17 +200,23 @@ class BRIE2(object):
         self._pseudo_count = pseudo_count
         sh = self._ensure_shard(count_layers, Xc)
 
+        def run(n_steps, lr):
+            trace = sh.step(n_steps, lr, MC_size)
+            if trace_reduce is not None:                             # gene-sharded fit: global loss
+                trace = np.asarray(trace_reduce(trace), np.float32)
+            return trace
+
         losses = np.zeros(0, np.float32)
         for i in range(6):                                           # model_TFProb.py:235-241
             sh.reset_optimizer()                                     # fresh Adam per stage
-            losses = sh.step(int(min_iter / 6), LEARNING_RATES[i], MC_size)
+            losses = run(int(min_iter / 6), LEARNING_RATES[i])
         n_iter = min_iter + 0                                        # model_TFProb.py:247-258
         d1 = int(min(50, add_iter / 2))
         d2 = d1 * 2
         while (len(losses) >= d2 and d1 > 0 and
                losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv and n_iter < max_iter):
             n_iter += add_iter
-            losses = np.concatenate([losses, sh.step(add_iter, LEARNING_RATES[5], MC_size)])
+            losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])
 
         self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
         self.losses = _wrap(losses)

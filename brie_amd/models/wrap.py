@@ -194,6 +194,8 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
             raise NotImplementedError("gene sharding needs Kg == 0 and intercept_mode != 'cell'")
         from ..sharding import gene_shard
         g_lo, g_hi = gene_shard(Ng, comm.rank, comm.world)
+        # the loss trace is summed over ranks so every rank takes the same convergence decision
+        keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
 
     if separable and emulate_batches:                                 # model_wrap.py:242-260
         _n_gene = int(np.ceil(batch_size / Nc))
@@ -217,8 +219,6 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
             ResVal.ELBO_gain = comm.allgather_genes(ResVal.ELBO_gain.T, Ng).T
             ResVal.pval = elbo_gain_pval(ResVal.ELBO_gain)
             ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
-        n = min(comm.allreduce_sum([-len(ResVal.losses)])[0] * 0 + len(ResVal.losses), len(ResVal.losses))
-        ResVal.losses = comm.allreduce_sum(ResVal.losses[:n]).astype(np.float32)
 
     # update adata (model_wrap.py:272-311); matrices cover this rank's gene range
     full = (g_lo, g_hi) == (0, Ng)

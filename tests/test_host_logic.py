@@ -1,0 +1,166 @@
+"""CPU: C-ABI surface, host statistics, gene sharding, and the fit_BRIE_matrix / fitBRIE
+orchestration (with the oracle-backed stand-in from tests/fakes.py)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import host_stats
+from oracle.synth import make_problem
+from tests.fakes import FakeAnnData, OracleBackedBRIE2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from brie_amd.build import compile_library
+    from brie_amd import _capi
+    compile_library()                     # hipcc cross-compiles gfx950 without a GPU
+    return _capi.load_library()
+
+
+def test_capi_exports_every_declared_symbol(built_lib):
+    from brie_amd import _capi
+    header = open(os.path.join(ROOT, "include", "brie_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(brie_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no prototypes parsed"
+    for name in declared:
+        assert hasattr(built_lib, name), "libbrie_amd.so does not export %s" % name
+    assert sorted(_capi.EXPORTS) == declared
+    assert built_lib.brie_abi_version() == _capi.ABI_VERSION
+    assert built_lib.brie_last_error() is not None
+
+
+def test_capi_struct_layout_matches_header():
+    import ctypes
+    from brie_amd import _capi
+    assert ctypes.sizeof(_capi.BrieProblem) == 72
+    assert _capi.BrieProblem.seed.offset == 64 and _capi.BrieProblem.Kc.offset == 32
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from brie_amd import _capi
+    with pytest.raises(ImportError):
+        _capi.load_library(str(tmp_path / "nope.so"))
+
+
+def test_fdr_bh_matches_restatement_and_scipy():
+    from scipy.stats import false_discovery_control
+    from brie_amd.stats import fdr_bh, elbo_gain_pval
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 17, 500):
+        p = rng.uniform(size=n) ** 3
+        p[rng.integers(0, n)] = p[0]                              # a tie
+        np.testing.assert_allclose(fdr_bh(p), host_stats.fdr_bh(p), rtol=1e-12)
+        np.testing.assert_allclose(fdr_bh(p), false_discovery_control(p, method="bh"), rtol=1e-12)
+    gain = rng.normal(size=(30, 2)) * 3
+    np.testing.assert_allclose(elbo_gain_pval(gain), host_stats.pval_from_gain(gain))
+    assert elbo_gain_pval(np.array([0.0]))[0] == 1.0
+
+
+def test_gene_shard_partition():
+    from brie_amd.sharding import gene_shard
+    for Ng, world in [(20000, 8), (20000, 1), (30000, 8), (500, 3), (7, 4), (5, 8)]:
+        edges = [gene_shard(Ng, r, world) for r in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == Ng
+        for (a0, a1), (b0, b1) in zip(edges, edges[1:]):
+            assert a1 == b0 and a0 % 4 == 0 and b0 % 4 == 0 or b0 == Ng
+        assert sum(b - a for a, b in edges) == Ng
+    assert gene_shard(20000, 3, 8) == (7500, 10000)
+
+
+@pytest.fixture
+def patched_wrap(monkeypatch):
+    import brie_amd.models.wrap as wrap
+    OracleBackedBRIE2.instances = []
+    monkeypatch.setattr(wrap, "BRIE2", OracleBackedBRIE2)
+    return wrap
+
+
+FIT = dict(min_iter=60, max_iter=60, n_loss_gene=3, verbose=False)
+
+
+def test_fit_brie_matrix_lrt_bookkeeping_full_mode(patched_wrap):
+    Nc, Ng, Kc = 40, 12, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=3)
+    raw = [c.copy() for c in P["counts"]]
+    res = patched_wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0, 1], **FIT)
+    base, t0, t1 = OracleBackedBRIE2.instances
+    assert base.fit_args["Kc"] == 2 and t0.fit_args["Kc"] == 1 and t1.fit_args["Kc"] == 1
+    np.testing.assert_array_equal(t0.fit_args["Xc"], P["Xc"][:, 1:2])      # feature 0 deleted
+    np.testing.assert_array_equal(t1.fit_args["Xc"], P["Xc"][:, 0:1])
+    np.testing.assert_allclose(res.ELBO_gain[:, 0], t0.loss_gene - base.loss_gene, rtol=1e-6)
+    np.testing.assert_allclose(res.pval, host_stats.pval_from_gain(res.ELBO_gain))
+    for i in range(2):
+        np.testing.assert_allclose(res.fdr[:, i], host_stats.fdr_bh(res.pval[:, i]))
+    assert res.cell_coeff.shape == (2, Ng) and res.Psi.shape == (Nc, Ng)
+    for a, b in zip(raw, P["counts"]):
+        np.testing.assert_array_equal(a, b)                                 # caller arrays untouched
+
+
+def test_fit_brie_matrix_null_mode_and_defaults(patched_wrap):
+    Nc, Ng, Kc = 30, 8, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=4)
+    res = patched_wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[1], base_mode='null', **FIT)
+    base, test = OracleBackedBRIE2.instances
+    assert base.fit_args["Kc"] == 1 and test.fit_args["Kc"] == 2
+    np.testing.assert_array_equal(test.fit_args["Xc"][:, -1], P["Xc"][:, 1])
+    np.testing.assert_allclose(res.ELBO_gain[:, 0], base.loss_gene - test.loss_gene, rtol=1e-6)
+    assert res.cell_coeff.shape == (2, Ng)                                  # test weight appended
+    OracleBackedBRIE2.instances = []
+    res = patched_wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=None, **FIT)
+    assert len(OracleBackedBRIE2.instances) == 3 and res.ELBO_gain.shape == (Ng, 2)   # None => all features
+    OracleBackedBRIE2.instances = []
+    res = patched_wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[], **FIT)
+    assert len(OracleBackedBRIE2.instances) == 1 and not hasattr(res, "ELBO_gain")
+
+
+def test_fitBRIE_writes_the_reference_keys(patched_wrap):
+    Nc, Ng, Kc = 36, 20, 1
+    P = make_problem(Nc, Ng, Kc=Kc, L=3, seed=6)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1], 'ambiguous': P["counts"][2]},
+                     effLen=P["effLen"])
+    res = patched_wrap.fitBRIE(ad, Xc=P["Xc"], LRT_index=[0], **FIT)
+    assert set(ad.layers) >= {'Psi', 'Z_std', 'Psi_95CI'}
+    assert ad.layers['Psi'].shape == (Nc, Ng)
+    assert ad.varm['cell_coeff'].shape == (Ng, Kc) and ad.varm['intercept'].shape == (Ng, 1)
+    assert ad.varm['sigma'].shape == (Ng, 1) and ad.var['loss_gene'].shape == (Ng,)
+    assert ad.varm['ELBO_gain'].shape == (Ng, 1) and ad.varm['pval'].shape == (Ng, 1)
+    assert ad.varm['fdr'].shape == (Ng, 1)
+    assert ad.uns['brie_param']['pseudo_count'] == 0.01 and 'brie_losses' in ad.uns
+    assert res.Ng == Ng and str(res) == "BRIE2 results for %d cells and %d genes" % (Nc, Ng)
+    # no LRT => no fdr keys
+    ad2 = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    patched_wrap.fitBRIE(ad2, Xc=P["Xc"], **FIT)
+    assert 'fdr' not in ad2.varm and 'Psi' in ad2.layers
+
+
+def test_fitBRIE_emulated_batches_equal_whole_fit(patched_wrap):
+    """Genes are independent (model_wrap.py:241): reference-style sequential gene batches give
+    the same per-gene results as one concurrent fit, because the noise stream is keyed by the
+    global gene index."""
+    Nc, Ng = 25, 24
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=8)
+    mk = lambda: FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    whole = patched_wrap.fitBRIE(mk(), Xc=P["Xc"], **FIT)
+    batched = patched_wrap.fitBRIE(mk(), Xc=P["Xc"], batch_size=Nc * 8, emulate_batches=True, **FIT)
+    assert len(OracleBackedBRIE2.instances) == 1 + 3
+    np.testing.assert_allclose(batched.Psi, whole.Psi, atol=2e-6)
+    np.testing.assert_allclose(batched.cell_coeff, whole.cell_coeff, atol=2e-6)
+    assert len(batched.losses) == 3 * len(whole.losses)                     # traces concatenated (model_wrap.py:61)
+
+
+def test_unsupported_modes_raise():
+    import brie_amd
+    with pytest.raises(NotImplementedError):
+        brie_amd.BRIE2(10, 10, Kg=1)
+    with pytest.raises(NotImplementedError):
+        brie_amd.BRIE2(10, 10, intercept_mode='cell')
+    m = brie_amd.BRIE2(10, 10)
+    with pytest.raises(NotImplementedError):
+        m.fit([np.zeros((10, 10))] * 2, target="marginLik")
+    with pytest.raises(RuntimeError):
+        m.Psi

@@ -1,0 +1,194 @@
+"""CPU: pin the oracle (oracle/) -- known-answer vectors, reference fragments, autograd, identities."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from scipy.special import gammaln, expit
+
+from oracle import philox
+from oracle.brie_oracle import OracleBRIE2, add_pseudo_count, log_sigmoid, sigmoid, LEARNING_RATES
+from oracle.brie_oracle_torch import TorchBRIE2
+from oracle.synth import make_problem
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_philox_random123_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kat = [((0, 0, 0, 0), (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            "d16cfe09 94fdcceb 5001e420 24126ea1")]
+    for c, k, want in kat:
+        got = " ".join("%08x" % int(x) for x in philox.philox4x32_10(*c, *k))
+        assert got == want
+
+
+def test_noise_is_standard_normal_and_shard_invariant():
+    e = philox.normal(3, 5, 0, 400, 400)
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01
+    assert abs(np.mean(e ** 3)) < 0.03 and abs(np.mean(e ** 4) - 3) < 0.1
+    sub = philox.normal(3, 5, 0, 50, 12, gene_offset=20, cell_offset=7)
+    np.testing.assert_array_equal(sub, e[7:57, 20:32])
+    assert not np.array_equal(philox.normal(3, 6, 0, 4, 8), philox.normal(3, 5, 0, 4, 8))
+    assert not np.array_equal(philox.normal(3, 5, 1, 4, 8), philox.normal(3, 5, 0, 4, 8))
+
+
+def test_ci95_against_reference_fragment():
+    """get_CI95 (base_model.py:29-36, z=1.96) vs the oracle's Psi95CI (z=1.959964): <= ~2e-5."""
+    g = np.load(os.path.join(GOLD, "ref_get_CI95.npz"))
+    Psi, Z_std = g["Psi"], g["Z_std"]
+    o = OracleBRIE2(Psi.shape[0], Psi.shape[1], 0, dtype=np.float64,
+                    init=dict(Z_loc=np.log(Psi / (1 - Psi)), Z_std_log=np.log(Z_std),
+                              Wc_loc=np.zeros((0, Psi.shape[1])), intercept=np.zeros((1, Psi.shape[1])),
+                              sigma_log=np.zeros((1, Psi.shape[1]))))
+    width_ref = g["high"] - g["low"]
+    assert np.max(np.abs(o.Psi95CI - width_ref)) < 5e-5
+    # with the reference's own constant the endpoints agree to rounding
+    z = np.log(Psi / (1 - Psi))
+    np.testing.assert_allclose(expit(z - 1.96 * Z_std), g["low"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(expit(z + 1.96 * Z_std), g["high"], rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(o.Psi, Psi, rtol=1e-12)
+
+
+def test_efflen_likelihood_against_reference_fragment():
+    """BRIE_base_lik (base_model.py:20-27): log pmf - log multinomial coeff == sum_c count_c log phi_c."""
+    g = np.load(os.path.join(GOLD, "ref_BRIE_base_lik.npz"))
+    psi, counts, lengths, pmf = g["psi"], g["counts"], g["lengths"], g["pmf"]
+    n = len(psi)
+    eff = np.zeros((n, 6))
+    eff[:, [0, 4, 5]] = lengths
+    o = OracleBRIE2(1, n, 0, effLen=eff, dtype=np.float64)
+    z = np.log(psi / (1 - psi))[None, :]
+    ll, _ = o.loglik_terms([counts[:, i][None, :].astype(np.float64) for i in range(3)], z)
+    N = counts.sum(1)
+    logcoef = gammaln(N + 1) - gammaln(counts + 1).sum(1)
+    ok = pmf > 0
+    np.testing.assert_allclose(ll[0][ok], np.log(pmf[ok]) - logcoef[ok], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("L,Kc,MC", [(2, 0, 1), (2, 3, 3), (3, 1, 2)])
+def test_hand_gradients_match_autograd(L, Kc, MC):
+    Nc, Ng = 40, 24
+    P = make_problem(Nc, Ng, Kc=Kc, L=L, seed=1)
+    cnt = add_pseudo_count(P["counts"])
+    o = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=5, dtype=np.float64)
+    init = {k: getattr(o, k).copy() for k in ("Z_loc", "Z_std_log", "Wc_loc", "intercept", "sigma_log")}
+    t = TorchBRIE2(Nc, Ng, Kc, effLen=P["effLen"], init=init, seed=5, dtype=torch.float64)
+    t.Xc = torch.as_tensor(P["Xc"], dtype=torch.float64)
+    out = o.loss_and_grads(cnt, P["Xc"], MC_size=MC)
+    loss = t.get_loss([torch.as_tensor(c, dtype=torch.float64) for c in cnt], None, MC)
+    grads = torch.autograd.grad(loss, t.variables())
+    assert abs(float(loss.detach()) - out["loss"]) < 1e-9 * max(1, abs(out["loss"]))
+    for name, g in zip(o.trainable(), grads):
+        np.testing.assert_allclose(out[name], g.numpy(), rtol=1e-10, atol=1e-10, err_msg=name)
+    lg = t.get_loss([torch.as_tensor(c, dtype=torch.float64) for c in cnt], 0, MC,
+                    eps=torch.as_tensor(np.stack([philox.normal(5, 0, k, Nc, Ng) for k in range(MC)])).double())
+    np.testing.assert_allclose(out["loss_gene"], lg.detach().numpy(), rtol=1e-10)
+
+
+def test_numpy_and_torch_trajectories_agree():
+    Nc, Ng, Kc = 30, 20, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=2)
+    cnt = add_pseudo_count(P["counts"])
+    o = OracleBRIE2(Nc, Ng, Kc, seed=9, dtype=np.float64)
+    init = {k: getattr(o, k).copy() for k in ("Z_loc", "Z_std_log", "Wc_loc", "intercept", "sigma_log")}
+    t = TorchBRIE2(Nc, Ng, Kc, init=init, seed=9, dtype=torch.float64)
+    t.Xc = torch.as_tensor(P["Xc"], dtype=torch.float64)
+    tr_o = o.minimize(cnt, P["Xc"], 25, 0.01, 1)
+    tr_t = t.minimize([torch.as_tensor(c, dtype=torch.float64) for c in cnt], 25, t.new_adam(0.01), 1)
+    np.testing.assert_allclose(tr_o, tr_t, rtol=1e-6)
+    np.testing.assert_allclose(o.Z_loc, t.Z_loc.detach().numpy(), atol=1e-9)
+    np.testing.assert_allclose(o.sigma_log, t.sigma_log.detach().numpy(), atol=1e-9)
+
+
+def test_kl_zero_and_stationary_at_prior():
+    """KL = 0 and its gradient vanishes at q = prior; with zero counts the loss is exactly the KL."""
+    Nc, Ng, Kc = 12, 8, 1
+    rng = np.random.default_rng(0)
+    Xc = rng.standard_normal((Nc, Kc))
+    W = rng.standard_normal((Kc, Ng))
+    b = rng.standard_normal((1, Ng))
+    lam = rng.standard_normal((1, Ng)) * 0.3
+    init = dict(Z_loc=Xc @ W + b, Z_std_log=np.zeros((Nc, Ng)) + lam, Wc_loc=W, intercept=b, sigma_log=lam)
+    o = OracleBRIE2(Nc, Ng, Kc, dtype=np.float64, init=init)
+    zero = [np.zeros((Nc, Ng)), np.zeros((Nc, Ng))]
+    out = o.loss_and_grads(zero, Xc, 1)
+    assert abs(out["loss"]) < 1e-12
+    for k in o.trainable():
+        assert np.max(np.abs(out[k])) < 1e-12, k
+
+
+def test_zero_counts_posterior_relaxes_to_prior():
+    """doc/brie_quant.rst:143-146: no reads => Psi ~ prior mean, wide interval."""
+    Nc, Ng = 30, 8
+    zero = [np.zeros((Nc, Ng), np.float32)] * 2
+    o = OracleBRIE2(Nc, Ng, 0, seed=4, dtype=np.float64, intercept=0.0, sigma=2.0)
+    for lr in LEARNING_RATES:
+        o.reset_optimizer()
+        o.minimize(zero, None, 150, lr, 1)
+    assert np.max(np.abs(o.Psi - 0.5)) < 0.02
+    np.testing.assert_allclose(o.Z_std, 2.0, rtol=0.02)
+    assert np.min(o.Psi95CI) > 0.9
+
+
+def test_adam_step_matches_keras_formula():
+    o = OracleBRIE2(2, 4, 0, seed=1, dtype=np.float64)
+    z0 = o.Z_loc.copy()
+    g = {"Z_loc": np.full((2, 4), 0.3), "Z_std_log": np.zeros((2, 4)),
+         "intercept": np.zeros((1, 4)), "sigma_log": np.zeros((1, 4))}
+    o.adam_step(g, 0.01)
+    m, v = 0.3 * 0.1, 0.09 * 0.001
+    alpha = 0.01 * np.sqrt(1 - 0.999) / (1 - 0.9)
+    np.testing.assert_allclose(o.Z_loc, np.clip(z0 - m * alpha / (np.sqrt(v) + 1e-7), -9, 9), rtol=1e-6)
+    big = OracleBRIE2(1, 4, 0, dtype=np.float64, init=dict(
+        Z_loc=np.full((1, 4), 8.9999), Z_std_log=np.zeros((1, 4)), Wc_loc=np.zeros((0, 4)),
+        intercept=np.zeros((1, 4)), sigma_log=np.zeros((1, 4))))
+    big.adam_step({"Z_loc": np.full((1, 4), -5.0), "Z_std_log": np.zeros((1, 4)),
+                   "intercept": np.zeros((1, 4)), "sigma_log": np.zeros((1, 4))}, 0.02)
+    assert np.all(big.Z_loc == 9.0)                      # clip constraint (model_TFProb.py:81)
+
+
+def test_pseudo_count_rule():
+    c1 = np.array([[0, 1, 0, 2]], np.float32)
+    c2 = np.array([[0, 0, 3, 2]], np.float32)
+    c3 = np.array([[5, 0, 0, 1]], np.float32)
+    out = add_pseudo_count([c1, c2, c3], 0.01)
+    np.testing.assert_allclose(out[0], [[0, 1.01, 0.01, 2.01]])
+    np.testing.assert_allclose(out[1], [[0, 0.01, 3.01, 2.01]])
+    np.testing.assert_array_equal(out[2], c3)
+    assert c1[0, 1] == 1                                  # returns copies
+
+
+@pytest.mark.parametrize("name", ["lik2_kc2", "eff3_kc1_mc3"])
+def test_oracle_reproduces_golden_trajectory(name):
+    g = np.load(os.path.join(GOLD, "oracle_traj_%s.npz" % name))
+    counts = [g[k] for k in ("count1", "count2", "count3") if k in g.files]
+    eff = g["effLen"] if "effLen" in g.files else None
+    Nc, Ng = counts[0].shape
+    Kc = g["Xc"].shape[1]
+    o = OracleBRIE2(Nc, Ng, Kc, effLen=eff, seed=int(g["seed"]), dtype=np.float64)
+    np.testing.assert_array_equal(o.Z_loc, g["init_Z_loc"])
+    cnt = add_pseudo_count(counts)
+    tr = []
+    for lr in LEARNING_RATES:
+        o.reset_optimizer()
+        tr.append(o.minimize(cnt, g["Xc"], int(g["steps_per_stage"]), lr, int(g["MC"])))
+    np.testing.assert_allclose(np.concatenate(tr), g["losses"], rtol=1e-9)
+    np.testing.assert_allclose(o.Psi, g["Psi"], atol=1e-9)
+    np.testing.assert_allclose(o.eval_loss_gene(cnt, g["Xc"], 10), g["loss_gene"], rtol=1e-9)
+
+
+def test_fit_recovers_simulated_truth():
+    """Recovery on data from the generative recipe of brie/models/simulator.py:22-69."""
+    Nc, Ng, Kc = 300, 40, 1
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=5, theta=1.0, depth=20.0, effect_frac=0.5)
+    cnt = add_pseudo_count(P["counts"])
+    o = OracleBRIE2(Nc, Ng, Kc, seed=2, dtype=np.float32)
+    losses = o.fit(cnt, P["Xc"], min_iter=600, max_iter=600, n_loss_gene=5)
+    assert losses[-1] < losses[0]
+    assert np.corrcoef(o.Psi.ravel(), P["Psi_true"].ravel())[0, 1] > 0.9
+    strong = np.abs(P["W_true"][0]) > 0.8
+    assert np.corrcoef(o.Wc_loc[0][strong], P["W_true"][0][strong])[0, 1] > 0.9
+    assert o.loss_gene.shape == (Ng,) and len(losses) == 100

@@ -200,6 +200,11 @@ def main():
         elapsed = float(t.item())
 
     kern_ms, n_launch = sh.profile_read()
+    stream_gbs = None
+    if rank == 0:
+        # measured ceiling of THIS box: a kernel with the same 16-B read/write stream mix and no arithmetic
+        n_read = L + 6
+        stream_gbs = max(_capi.calibrate_stream(n_read, 6, 1 << 30, iters=5, device=local_rank) for _ in range(2))
     sh.profile_enable(False)
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last
@@ -226,7 +231,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch},
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
+                         "measured_stream_ceiling_GBs": stream_gbs,
+                         "frac_of_measured_stream_ceiling": achieved / stream_gbs},
         }
     sh.close()
 

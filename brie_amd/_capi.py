@@ -22,7 +22,8 @@ EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
-    "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_last_error", "brie_abi_version",
+    "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_calibrate_stream", "brie_last_error",
+    "brie_abi_version",
 ]
 
 
@@ -71,6 +72,7 @@ def load_library(path=None):
     lib.brie_profile_enable.argtypes = [vp, i32]
     lib.brie_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.brie_set_tiling.argtypes = [vp, i32]
+    lib.brie_calibrate_stream.argtypes = [i32, i32, i32, i64, i32, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_step_algorithmic_bytes.argtypes = [vp]
     lib.brie_step_algorithmic_bytes.restype = i64
     lib.brie_last_error.restype = ctypes.c_char_p
@@ -117,6 +119,15 @@ def _matrix_pointer(x):
     if not a.flags.c_contiguous:
         a = np.ascontiguousarray(a)
     return a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.shape[1], a
+
+
+def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=0, lds_bytes=0):
+    """HBM GB/s of a pure streaming kernel with the given read/write stream mix."""
+    lib = load_library()
+    out = ctypes.c_double()
+    _check(lib, lib.brie_calibrate_stream(int(device), int(n_read), int(n_write), int(bytes_per_stream),
+                                          int(iters), int(lds_bytes), ctypes.byref(out)))
+    return out.value
 
 
 class Shard(object):

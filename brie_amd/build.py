@@ -18,9 +18,12 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in SOURCES + HEADERS)
 
 
-def compile_library(force=False, fast_math=None, verbose=False):
-    """hipcc --offload-arch=gfx950 -> brie_amd/lib/libbrie_amd.so (cross-compiles without a GPU)."""
-    if not force and not needs_build():
+def compile_library(force=False, fast_math=None, verbose=False, out=None, defines=()):
+    """hipcc --offload-arch=gfx950 -> brie_amd/lib/libbrie_amd.so (cross-compiles without a GPU).
+
+    `out` / `defines` build tuning variants (e.g. -DBRIE_MIN_WAVES=4) next to the default library;
+    select one at run time with the BRIE_AMD_LIB environment variable."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
@@ -32,11 +35,14 @@ def compile_library(force=False, fast_math=None, verbose=False):
         fast_math = os.environ.get("BRIE_FAST_MATH")
     if fast_math is not None:
         cmd.append("-DBRIE_FAST_MATH=%d" % int(fast_math))
-    cmd += SOURCES + ["-o", LIB_PATH]
+    cmd += ["-D" + d for d in defines]
+    out = out or LIB_PATH
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    cmd += SOURCES + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 if __name__ == "__main__":

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -39,7 +40,9 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 struct brie_handle {
     brie_problem p{};
-    int64_t ld = 0;
+    int64_t ld = 0;                 // gene_blocks * 256: pitch of per-gene vectors and of row-major matrices
+    int64_t row_stride = 0, gb_stride = 0;   // matrix addressing (see StepScalars)
+    bool tiled = true;              // gene-block-major tiles [gene block][cell][256 genes]
     int S = 0;                      // statistics per gene per chunk = Kc + 4
     int mode = 0;                   // likelihood mode (brie::kLik2 ...)
     hipStream_t stream = nullptr;
@@ -89,9 +92,11 @@ void configure_tiling(brie_handle *h) {
     h->gene_blocks = static_cast<int>((h->p.Ng + brie::kGenesPerBlock - 1) / brie::kGenesPerBlock);
     int rpc = h->user_rows_per_chunk;
     if (rpc <= 0) {
+        // A function of Nc ONLY (never of the shard's gene count): the per-gene fp32 partial sums are
+        // then formed in the same order however the genes are sharded, so a gene's trajectory is
+        // bit-identical in a 1-GPU fit and in any gene shard.  Aim for >= 256 cell chunks.
         rpc = 256;
-        // keep >= ~8 workgroups per CU in flight when the problem allows it
-        while (rpc > 16 && static_cast<int64_t>(h->gene_blocks) * ((Nc + rpc - 1) / rpc) < 2048) rpc /= 2;
+        while (rpc > 16 && (Nc + rpc - 1) / rpc < 256) rpc /= 2;
     }
     h->rows_per_chunk = rpc;
     h->n_chunks = static_cast<int>((Nc + rpc - 1) / rpc);
@@ -120,18 +125,32 @@ int check_ready(const brie_handle *h) {
     return BRIE_OK;
 }
 
+struct StepPointers {
+    const float *c1, *c2, *c3;
+    float *mu, *rho, *m_mu, *v_mu, *m_rho, *v_rho;
+    const float *Xc, *W, *b, *lam, *effL;
+    float *partials;
+};
+
+template <int KC, int MODE>
+void launch_step_mode(const brie_handle *h, const StepPointers &q, const brie::StepScalars &a, dim3 grid) {
+#define BRIE_LAUNCH_STEP(MC)                                                                                     \
+    hipLaunchKernelGGL((brie::elbo_adam_step<KC, MODE, MC>), grid, dim3(brie::kBlock), 0, h->stream, q.c1, q.c2,    \
+                       q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,        \
+                       q.partials, a)
+    // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
+    if (a.mc == 1) BRIE_LAUNCH_STEP(1);
+    else if (a.mc == 3) BRIE_LAUNCH_STEP(3);
+    else BRIE_LAUNCH_STEP(0);
+#undef BRIE_LAUNCH_STEP
+}
+
 template <int KC>
-void launch_step_kc(const brie_handle *h, const brie::StepArgs &a, dim3 grid) {
+void launch_step_kc(const brie_handle *h, const StepPointers &q, const brie::StepScalars &a, dim3 grid) {
     switch (h->mode) {
-        case brie::kLik2:
-            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLik2>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
-        case brie::kLikEff2:
-            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLikEff2>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
-        default:
-            hipLaunchKernelGGL((brie::elbo_adam_step<KC, brie::kLikEff3>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
+        case brie::kLik2: launch_step_mode<KC, brie::kLik2>(h, q, a, grid); break;
+        case brie::kLikEff2: launch_step_mode<KC, brie::kLikEff2>(h, q, a, grid); break;
+        default: launch_step_mode<KC, brie::kLikEff3>(h, q, a, grid); break;
     }
 }
 
@@ -150,17 +169,17 @@ void launch_lg_kc(const brie_handle *h, const brie::LossGeneArgs &a, dim3 grid) 
     }
 }
 
-#define BRIE_DISPATCH_KC(fn, h, a, grid)                 \
+#define BRIE_DISPATCH_KC(fn, h, ...)                     \
     switch ((h)->p.Kc) {                                 \
-        case 0: fn<0>(h, a, grid); break;                \
-        case 1: fn<1>(h, a, grid); break;                \
-        case 2: fn<2>(h, a, grid); break;                \
-        case 3: fn<3>(h, a, grid); break;                \
-        case 4: fn<4>(h, a, grid); break;                \
-        case 5: fn<5>(h, a, grid); break;                \
-        case 6: fn<6>(h, a, grid); break;                \
-        case 7: fn<7>(h, a, grid); break;                \
-        default: fn<8>(h, a, grid); break;               \
+        case 0: fn<0>(h, __VA_ARGS__); break;            \
+        case 1: fn<1>(h, __VA_ARGS__); break;            \
+        case 2: fn<2>(h, __VA_ARGS__); break;            \
+        case 3: fn<3>(h, __VA_ARGS__); break;            \
+        case 4: fn<4>(h, __VA_ARGS__); break;            \
+        case 5: fn<5>(h, __VA_ARGS__); break;            \
+        case 6: fn<6>(h, __VA_ARGS__); break;            \
+        case 7: fn<7>(h, __VA_ARGS__); break;            \
+        default: fn<8>(h, __VA_ARGS__); break;           \
     }
 
 int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t *cols, int64_t *ldd) {
@@ -178,6 +197,33 @@ int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t
         case BRIE_SIGMA_LOG: *dev = h->lam; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
         default: return fail(BRIE_ERR_INVALID, "array id %d is not a stored matrix", which);
     }
+}
+
+// Copy a (Nc, Ng) matrix between the caller's row-major buffer and the device layout.
+// Tiled layout: one strided 2-D copy per 256-gene block (1-KiB device rows).
+int copy_cellgene(brie_handle *h, float *dev, const float *ext, float *ext_out, int64_t ld_ext) {
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    if (!h->tiled) {
+        if (ext_out)
+            HIP_TRY(hipMemcpy2DAsync(ext_out, ld_ext * sizeof(float), dev, h->ld * sizeof(float), Ng * sizeof(float), Nc,
+                                     hipMemcpyDefault, h->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(dev, h->ld * sizeof(float), ext, ld_ext * sizeof(float), Ng * sizeof(float), Nc,
+                                     hipMemcpyDefault, h->stream));
+        return BRIE_OK;
+    }
+    const int64_t G = brie::kGenesPerBlock;
+    for (int64_t g = 0; g * G < Ng; ++g) {
+        const int64_t cols = (Ng - g * G) < G ? (Ng - g * G) : G;
+        float *d = dev + g * h->gb_stride;
+        if (ext_out)
+            HIP_TRY(hipMemcpy2DAsync(ext_out + g * G, ld_ext * sizeof(float), d, G * sizeof(float), cols * sizeof(float),
+                                     Nc, hipMemcpyDefault, h->stream));
+        else
+            HIP_TRY(hipMemcpy2DAsync(d, G * sizeof(float), ext + g * G, ld_ext * sizeof(float), cols * sizeof(float), Nc,
+                                     hipMemcpyDefault, h->stream));
+    }
+    return BRIE_OK;
 }
 
 int grid_1d(int64_t n) {
@@ -218,7 +264,13 @@ int brie_create(const brie_problem *p, brie_handle **out) {
 
     brie_handle *h = new brie_handle();
     h->p = *p;
-    h->ld = round_up(p->Ng, 64);
+    h->ld = round_up(p->Ng, brie::kGenesPerBlock);
+    {   // device layout of cell x gene matrices: "tiled" (default) or "rowmajor" (BRIE_LAYOUT, for A/B runs)
+        const char *lay = getenv("BRIE_LAYOUT");
+        h->tiled = !(lay && strcmp(lay, "rowmajor") == 0);
+        if (h->tiled) { h->row_stride = brie::kGenesPerBlock; h->gb_stride = p->Nc * brie::kGenesPerBlock; }
+        else { h->row_stride = h->ld; h->gb_stride = brie::kGenesPerBlock; }
+    }
     h->S = p->Kc + 4;
     h->mode = !p->has_efflen ? brie::kLik2 : (p->n_layers == 3 ? brie::kLikEff3 : brie::kLikEff2);
     int rc = set_device(h);
@@ -294,8 +346,13 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
         return fail(BRIE_ERR_INVALID, "array %d must be (%lld, %lld), got (%lld, %lld)", which, (long long)R,
                     (long long)C, (long long)rows, (long long)cols);
     if (R * C > 0) {
-        HIP_TRY(hipMemcpy2DAsync(dev, ldd * sizeof(float), src, ld * sizeof(float), C * sizeof(float), R,
-                                 hipMemcpyDefault, h->stream));
+        const bool cellgene = (which <= BRIE_COUNT3) || which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG;
+        if (cellgene) {
+            if ((rc = copy_cellgene(h, dev, src, nullptr, ld)) != BRIE_OK) return rc;
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(dev, ldd * sizeof(float), src, ld * sizeof(float), C * sizeof(float), R,
+                                     hipMemcpyDefault, h->stream));
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3) h->have_c[which - BRIE_COUNT1] = true;
@@ -344,8 +401,8 @@ int brie_init_state(brie_handle *h, float intercept, float sigma) {
     const uint32_t qoff = static_cast<uint32_t>(h->p.gene_offset / 4);
     const int Nc = static_cast<int>(h->p.Nc), Ng = static_cast<int>(h->p.Ng);
     const int64_t quads = (Ng + 3) / 4;
-    hipLaunchKernelGGL(brie::init_z, dim3(grid_1d(Nc * quads)), dim3(256), 0, h->stream, h->mu, h->rho, h->ld, Nc, Ng,
-                       slo, shi, qoff);
+    hipLaunchKernelGGL(brie::init_z, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * Nc * brie::kWave)), dim3(256), 0,
+                       h->stream, h->mu, h->rho, h->row_stride, h->gb_stride, h->gene_blocks, Nc, Ng, slo, shi, qoff);
     if (h->p.Kc > 0)
         hipLaunchKernelGGL(brie::init_gene_rows, dim3(grid_1d(h->p.Kc * quads)), dim3(256), 0, h->stream, h->W, h->ld,
                            h->p.Kc, Ng, 2u, slo, shi, qoff);
@@ -399,18 +456,20 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         }
     }
 
-    brie::StepArgs a{};
-    a.c1 = h->c[0]; a.c2 = h->c[1]; a.c3 = h->c[2];
-    a.mu = h->mu; a.rho = h->rho; a.m_mu = h->m_mu; a.v_mu = h->v_mu; a.m_rho = h->m_rho; a.v_rho = h->v_rho;
-    a.Xc = h->Xc; a.W = h->W; a.b = h->b; a.lam = h->lam; a.effL = h->effL; a.partials = h->partials;
-    a.ld = h->ld; a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
+    StepPointers q{};
+    q.c1 = h->c[0]; q.c2 = h->c[1]; q.c3 = h->c[2];
+    q.mu = h->mu; q.rho = h->rho; q.m_mu = h->m_mu; q.v_mu = h->v_mu; q.m_rho = h->m_rho; q.v_rho = h->v_rho;
+    q.Xc = h->Xc; q.W = h->W; q.b = h->b; q.lam = h->lam; q.effL = h->effL; q.partials = h->partials;
+    brie::StepScalars a{};
+    a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+    a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
     a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
-    f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.loss_gene_step = nullptr; f.ld = h->ld;
+    f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
     f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks; f.train_b = h->p.train_intercept; f.train_lam = h->p.train_sigma;
 
     const dim3 grid(h->gene_blocks, h->n_chunks);
@@ -423,9 +482,9 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        BRIE_DISPATCH_KC(launch_step_kc, h, a, grid);
+        BRIE_DISPATCH_KC(launch_step_kc, h, q, a, grid);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, f);
+        hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
     }
     HIP_TRY(hipGetLastError());
     if (loss_trace) {
@@ -453,6 +512,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     brie::LossGeneArgs a{};
     a.c1 = h->c[0]; a.c2 = h->c[1]; a.c3 = h->c[2]; a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
     a.lam = h->lam; a.effL = h->effL; a.partials = h->partials; a.ld = h->ld;
+    a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
     a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
     a.rows_per_chunk = h->rows_per_chunk; a.n_rep = n_repeats;
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
@@ -482,10 +542,10 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * h->ld * sizeof(float)));
         hipLaunchKernelGGL(brie::psi_epilogue, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->mu, h->rho, tmp, n4,
                            which - BRIE_PSI);
-        hipError_t e = hipMemcpy2DAsync(dst, ld * sizeof(float), tmp, h->ld * sizeof(float), Ng * sizeof(float), Nc,
-                                        hipMemcpyDefault, h->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        rc = copy_cellgene(h, tmp, nullptr, dst, ld);
+        hipError_t e = hipStreamSynchronize(h->stream);
         hipFree(tmp);
+        if (rc != BRIE_OK) return rc;
         if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read derived array: %s", hipGetErrorString(e));
         return BRIE_OK;
     }
@@ -505,8 +565,12 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         return fail(BRIE_ERR_INVALID, "array %d is (%lld, %lld), asked for (%lld, %lld)", which, (long long)R,
                     (long long)C, (long long)rows, (long long)cols);
     if (R * C > 0) {
-        HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(float), dev, ldd * sizeof(float), C * sizeof(float), R,
-                                 hipMemcpyDefault, h->stream));
+        if (which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG || which <= BRIE_COUNT3) {
+            if ((rc = copy_cellgene(h, dev, nullptr, dst, ld)) != BRIE_OK) return rc;
+        } else {
+            HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(float), dev, ldd * sizeof(float), C * sizeof(float), R,
+                                     hipMemcpyDefault, h->stream));
+        }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return BRIE_OK;
@@ -554,6 +618,47 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
     h->ev_used = 0;
     *kernel_ms_total = h->prof_ms;
     *n_launches = h->prof_launches;
+    return BRIE_OK;
+}
+
+// Measure the HBM rate of `n_read` read streams + `n_write` write streams of `bytes_per_stream`
+// each (no arithmetic) -> GB/s.  Supported mixes: (1,1) copy, (8,6) and (9,6) = elbo_adam_step with
+// 2 / 3 count layers.  `lds_bytes_per_block` > 0 reserves dynamic LDS per 256-thread block to cap the
+// occupancy (160 KiB per CU: 80 KiB -> 2 blocks = 8 waves per CU), i.e. the bytes in flight per CU.
+int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream, int32_t iters,
+                          int32_t lds_bytes_per_block, double *gbps) {
+    if (!gbps || iters < 1 || bytes_per_stream < 4096) return fail(BRIE_ERR_INVALID, "bad argument");
+    if (!((n_read == 1 && n_write == 1) || (n_read == 8 && n_write == 6) || (n_read == 9 && n_write == 6)))
+        return fail(BRIE_ERR_INVALID, "unsupported mix %d/%d", n_read, n_write);
+    HIP_TRY(hipSetDevice(device));
+    brie::StreamArgs a{};
+    a.n4 = bytes_per_stream / 16;
+    std::vector<void *> bufs;
+    auto cleanup = [&]() { for (void *q : bufs) hipFree(q); };
+    for (int i = 0; i < n_read + n_write; ++i) {
+        void *q = nullptr;
+        if (hipMalloc(&q, a.n4 * 16) != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer"); }
+        hipMemset(q, 0, a.n4 * 16);
+        bufs.push_back(q);
+        if (i < n_read) a.in[i] = static_cast<const float *>(q); else a.out[i - n_read] = static_cast<float *>(q);
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const dim3 grid(8192), block(brie::kBlock);
+    for (int it = -2; it < iters; ++it) {
+        if (it == 0) hipEventRecord(e0, nullptr);
+        if (n_read == 1) hipLaunchKernelGGL((brie::stream_mix<1, 1>), grid, block, lds_bytes_per_block, nullptr, a);
+        else if (n_read == 8) hipLaunchKernelGGL((brie::stream_mix<8, 6>), grid, block, lds_bytes_per_block, nullptr, a);
+        else hipLaunchKernelGGL((brie::stream_mix<9, 6>), grid, block, lds_bytes_per_block, nullptr, a);
+    }
+    hipEventRecord(e1, nullptr);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    cleanup();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "calibration: %s", hipGetErrorString(e));
+    *gbps = static_cast<double>(n_read + n_write) * a.n4 * 16.0 * iters / (ms * 1e-3) / 1e9;
     return BRIE_OK;
 }
 

@@ -35,6 +35,14 @@ constexpr uint32_t kInitDraw = 0xFFFFFFFFu;
 #ifndef BRIE_FAST_MATH
 #define BRIE_FAST_MATH 0
 #endif
+// minimum waves per SIMD requested from the register allocator for the streaming kernels
+#ifndef BRIE_MIN_WAVES
+#define BRIE_MIN_WAVES 1
+#endif
+// 1: issue the next row's loads before computing the current row (register double buffer)
+#ifndef BRIE_PREFETCH
+#define BRIE_PREFETCH 1
+#endif
 
 // ----------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. SC'11) -> 4 standard normals per gene quad.
@@ -128,6 +136,28 @@ __device__ __forceinline__ void st4(float *p, const F4 &a) {
     *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
 }
 
+// streaming (touched once per step) accesses; BRIE_NT=1 marks them non-temporal
+#ifndef BRIE_NT
+#define BRIE_NT 1
+#endif
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ F4 ld4s(const float *p) {
+#if BRIE_NT
+    const floatx4 t = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p));
+    return F4{{t.x, t.y, t.z, t.w}};
+#else
+    return ld4(p);
+#endif
+}
+__device__ __forceinline__ void st4s(float *p, const F4 &a) {
+#if BRIE_NT
+    floatx4 t = {a.v[0], a.v[1], a.v[2], a.v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<floatx4 *>(p));
+#else
+    st4(p, a);
+#endif
+}
+
 // Likelihood modes
 enum : int { kLik2 = 0,      // 2 categories, no effLen   (model_TFProb.py:162-167)
              kLikEff2 = 1,   // effLen, 2 count layers    (model_TFProb.py:168-183)
@@ -169,21 +199,21 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
 // ----------------------------------------------------------------------------
 // Kernel arguments
 // ----------------------------------------------------------------------------
-struct StepArgs {
-    const float *c1, *c2, *c3;              // counts (Nc, ld)
-    float *mu, *rho;                        // Z_loc, Z_std_log (Nc, ld)
-    float *m_mu, *v_mu, *m_rho, *v_rho;     // Adam moments (Nc, ld)
-    const float *Xc;                        // (Nc, Kc) row-major
-    const float *W;                         // (Kc, ld)
-    const float *b, *lam;                   // (ld)
-    const float *effL;                      // (6, ld): L0, L4, L5, log L0, log L4, log L5
-    float *partials;                        // (n_chunks, S, ld), S = Kc + 4
-    int64_t ld;
+// Scalars of one step.  Array pointers are passed as individual __restrict__
+// kernel parameters so that the compiler can prove the read-only inputs are not
+// clobbered by the state stores (wave-uniform Xc rows then go through SMEM).
+struct StepScalars {
+    int64_t ld;                             // pitch of per-gene vectors = gene_blocks * 256
+    int64_t row_stride, gb_stride;          // matrix element (r, gene block g, lane l, v) lives at
+                                            //   g*gb_stride + r*row_stride + 4*l + v
     int32_t Nc, Ng, rows_per_chunk, mc;
     uint32_t seed_lo, seed_hi, draw, quad_offset;
     float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
     float inv_mc;
 };
+
+// the 16-B vectors one lane holds for one cell row
+struct RowRegs { F4 c1, c2, c3, mu, rho, mm, vm, mr, vr; };
 
 constexpr float kOneMinusB1 = 1.0f - 0.9f;      // as Keras computes it in fp32
 constexpr float kOneMinusB2 = 1.0f - 0.999f;
@@ -194,10 +224,20 @@ constexpr float kAdamEps = 1e-7f;
 // Z_std_log + per-gene sufficient statistics.  Algorithmic HBM traffic per
 // element: read L counts + read/write mu, rho + read/write 4 moments
 // = 48 + 4L bytes.
+// MC > 0: Monte-Carlo sample count fixed at compile time (the row body is then
+// one straight-line basic block, which is what lets the next row's loads stay
+// in flight across it); MC == 0: run-time count a.mc.
 // ----------------------------------------------------------------------------
-template <int KC, int MODE>
-__global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
+template <int KC, int MODE, int MC>
+__global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
+    const float *__restrict__ c1p, const float *__restrict__ c2p, const float *__restrict__ c3p,
+    float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
+    float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
+    const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
+    const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
+    const StepScalars a) {
     constexpr int S = KC + 4;
+    constexpr int KCX = KC > 0 ? KC : 1;
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
 
     const int lane = threadIdx.x & (kWave - 1);
@@ -214,18 +254,18 @@ __global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
 #pragma unroll
         for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
 
-    if (active) {
+    if (active && row0 + w < row_end) {
         // per-gene parameters, live across the whole chunk
-        float Wk[KC > 0 ? KC : 1][kVec], bj[kVec], lamj[kVec], isig2[kVec];
+        float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
-            const F4 t = ld4(a.W + k * a.ld + j0);
+            const F4 t = ld4(Wp + k * a.ld + j0);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
         }
         {
-            const F4 tb = ld4(a.b + j0), tl = ld4(a.lam + j0);
+            const F4 tb = ld4(bp + j0), tl = ld4(lamp + j0);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 bj[v] = tb.v[v];
@@ -234,9 +274,9 @@ __global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
             }
         }
         if (MODE != kLik2) {
-            const F4 t0 = ld4(a.effL + 0 * a.ld + j0), t1 = ld4(a.effL + 1 * a.ld + j0),
-                     t2 = ld4(a.effL + 2 * a.ld + j0), t3 = ld4(a.effL + 3 * a.ld + j0),
-                     t4 = ld4(a.effL + 4 * a.ld + j0), t5 = ld4(a.effL + 5 * a.ld + j0);
+            const F4 t0 = ld4(effL + 0 * a.ld + j0), t1 = ld4(effL + 1 * a.ld + j0),
+                     t2 = ld4(effL + 2 * a.ld + j0), t3 = ld4(effL + 3 * a.ld + j0),
+                     t4 = ld4(effL + 4 * a.ld + j0), t5 = ld4(effL + 5 * a.ld + j0);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
@@ -247,61 +287,72 @@ __global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
 
-        for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
-            const int64_t off = static_cast<int64_t>(r) * a.ld + j0;
-            const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
-            F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
-            if (MODE == kLikEff3) c3 = ld4(a.c3 + off);
-            F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
-            F4 mm = ld4(a.m_mu + off), vm = ld4(a.v_mu + off);
-            F4 mr = ld4(a.m_rho + off), vr = ld4(a.v_rho + off);
-
-            float xc[KC > 0 ? KC : 1];
+        auto load_row = [&](int r, RowRegs &R, float (&xr)[KCX]) {
+            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            R.c1 = ld4s(c1p + off);
+            R.c2 = ld4s(c2p + off);
+            if (MODE == kLikEff3) R.c3 = ld4s(c3p + off);
+            else R.c3 = F4{{0.f, 0.f, 0.f, 0.f}};
+            R.mu = ld4s(mu_p + off);
+            R.rho = ld4s(rho_p + off);
+            R.mm = ld4s(mmu_p + off);
+            R.vm = ld4s(vmu_p + off);
+            R.mr = ld4s(mrho_p + off);
+            R.vr = ld4s(vrho_p + off);
 #pragma unroll
-            for (int k = 0; k < KC; ++k) xc[k] = a.Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform -> SMEM
+            for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
+        };
 
+        auto process_row = [&](int r, RowRegs &R, const float (&xc)[KCX]) {
+            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
                   ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
 #pragma unroll
-            for (int v = 0; v < kVec; ++v) s[v] = f_exp(rho.v[v]);
+            for (int v = 0; v < kVec; ++v) s[v] = f_exp(R.rho.v[v]);
 
-            for (int k = 0; k < a.mc; ++k) {
+            auto sample = [&](uint32_t k) {
                 float e[kVec];
-                normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k),
-                        a.seed_lo, a.seed_hi, e);
+                normal4(gquad, static_cast<uint32_t>(r), a.draw, k, a.seed_lo, a.seed_hi, e);
 #pragma unroll
                 for (int v = 0; v < kVec; ++v) {
-                    const float z = fmaf(s[v], e[v], mu.v[v]);          // reparameterised sample
+                    const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
                     float l, g;
-                    loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                    loglik<MODE>(z, R.c1.v[v], R.c2.v[v], R.c3.v[v], L0[v], L4[v], L5[v],
                                  lL0[v], lL4[v], lL5[v], l, g);
                     ll[v] += l;
                     gbar[v] += g;
                     gse[v] = fmaf(g, e[v], gse[v]);
                 }
+            };
+            if (MC > 0) {
+#pragma unroll
+                for (int k = 0; k < MC; ++k) sample(static_cast<uint32_t>(k));
+            } else {
+                for (int k = 0; k < a.mc; ++k) sample(static_cast<uint32_t>(k));
             }
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 float m = bj[v];
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
-                const float d = mu.v[v] - m;
+                const float d = R.mu.v[v] - m;
                 const float rr = d * isig2[v];                                     // (mu - m) / sigma^2
                 const float s2r = s[v] * s[v] * isig2[v];                          // s^2 / sigma^2
-                const float dl = rho.v[v] - lamj[v];
+                const float dl = R.rho.v[v] - lamj[v];
                 const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;         // KL(q || prior)
                 const float g_mu = rr - gbar[v] * a.inv_mc;
                 const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
                 // Keras Adam
-                mm.v[v] += (g_mu - mm.v[v]) * kOneMinusB1;
-                vm.v[v] += (g_mu * g_mu - vm.v[v]) * kOneMinusB2;
-                mr.v[v] += (g_rho - mr.v[v]) * kOneMinusB1;
-                vr.v[v] += (g_rho * g_rho - vr.v[v]) * kOneMinusB2;
-                float nmu = mu.v[v] - (mm.v[v] * a.alpha) * f_rcp(f_sqrt(vm.v[v]) + kAdamEps);
+                R.mm.v[v] += (g_mu - R.mm.v[v]) * kOneMinusB1;
+                R.vm.v[v] += (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
+                R.mr.v[v] += (g_rho - R.mr.v[v]) * kOneMinusB1;
+                R.vr.v[v] += (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
+                float nmu = R.mu.v[v] - (R.mm.v[v] * a.alpha) * f_rcp(f_sqrt(R.vm.v[v]) + kAdamEps);
                 nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
-                mu.v[v] = nmu;
-                rho.v[v] -= (mr.v[v] * a.alpha) * f_rcp(f_sqrt(vr.v[v]) + kAdamEps);
+                R.mu.v[v] = nmu;
+                R.rho.v[v] -= (R.mr.v[v] * a.alpha) * f_rcp(f_sqrt(R.vr.v[v]) + kAdamEps);
                 // per-gene sufficient statistics
 #pragma unroll
                 for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
@@ -310,13 +361,43 @@ __global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
                 acc[KC + 2][v] += kl;
                 acc[KC + 3][v] += ll[v] * a.inv_mc;
             }
-            st4(a.mu + off, mu);
-            st4(a.rho + off, rho);
-            st4(a.m_mu + off, mm);
-            st4(a.v_mu + off, vm);
-            st4(a.m_rho + off, mr);
-            st4(a.v_rho + off, vr);
+            st4s(mu_p + off, R.mu);
+            st4s(rho_p + off, R.rho);
+            st4s(mmu_p + off, R.mm);
+            st4s(vmu_p + off, R.vm);
+            st4s(mrho_p + off, R.mr);
+            st4s(vrho_p + off, R.vr);
+        };
+
+        int r = row0 + w;
+        const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
+        RowRegs cur;
+        float xc[KCX];
+        load_row(r, cur, xc);
+#if BRIE_PREFETCH
+        // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
+        // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
+        // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body
+        // is branch-free; the last row is peeled so no load is ever issued for a row that is not used.
+        while (r < r_last) {
+            RowRegs nxt;
+            float xn[KCX];
+            load_row(r + kWavesPerBlock, nxt, xn);
+            process_row(r, cur, xc);
+            cur = nxt;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xc[k] = xn[k];
+            r += kWavesPerBlock;
         }
+        process_row(r, cur, xc);
+#else
+        for (;;) {
+            process_row(r, cur, xc);
+            if (r >= r_last) break;
+            r += kWavesPerBlock;
+            load_row(r, cur, xc);
+        }
+#endif
     }
 
     // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row
@@ -329,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void elbo_adam_step(const StepArgs a) {
     }
     __syncthreads();
     if (w == 0 && active) {
-        float *dst = a.partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+        float *dst = partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             F4 o;
@@ -356,7 +437,6 @@ struct FinalizeArgs {
     float *b, *m_b, *v_b;       // (ld)
     float *lam, *m_lam, *v_lam; // (ld)
     double *loss_parts;         // (n_blocks, 2): sum KL, sum ll for this step
-    float *loss_gene_step;      // (ld) per-gene loss of this step (may be null)
     int64_t ld;
     int32_t Ng, Kc, n_chunks, train_b, train_lam;
     float alpha;
@@ -368,57 +448,55 @@ __device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float 
     x -= (m * alpha) / (sqrtf(v) + kAdamEps);
 }
 
+// grid = (gene blocks of 256, S): thread (j, s) owns statistic s of gene j, so every (gene, stat)
+// chunk column is summed by its own thread with 8 independent loads in flight.
 __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
+    const int s = blockIdx.y;
     const int S = a.Kc + 4;
-    double kl = 0.0, ll = 0.0;
+    double t = 0.0;
     if (j < a.Ng) {
-        for (int s = 0; s < S; ++s) {
-            double t = 0.0;
-            for (int c = 0; c < a.n_chunks; ++c)
-                t += static_cast<double>(a.partials[(static_cast<int64_t>(c) * S + s) * a.ld + j]);
-            if (s < a.Kc) {
-                const int64_t o = static_cast<int64_t>(s) * a.ld + j;
-                float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
-                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/dW = -Xc^T r
-                a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
-            } else if (s == a.Kc) {
-                if (a.train_b) {
-                    float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
-                    adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);    // dL/db = -sum r
-                    x = fminf(fmaxf(x, -9.0f), 9.0f);
-                    a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
-                }
-            } else if (s == a.Kc + 1) {
-                if (a.train_lam) {
-                    float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
-                    adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
-                    a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
-                }
-            } else if (s == a.Kc + 2) {
-                kl = t;
-            } else {
-                ll = t;
+        const float *p = a.partials + static_cast<int64_t>(s) * a.ld + j;
+        const int64_t stride = static_cast<int64_t>(S) * a.ld;
+        int c = 0;
+        for (; c + 8 <= a.n_chunks; c += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += static_cast<double>(x[u]);
+        }
+        for (; c < a.n_chunks; ++c) t += static_cast<double>(p[c * stride]);
+        if (s < a.Kc) {
+            const int64_t o = static_cast<int64_t>(s) * a.ld + j;
+            float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
+            adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);            // dL/dW = -Xc^T r
+            a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
+        } else if (s == a.Kc) {
+            if (a.train_b) {
+                float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
+                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/db = -sum r
+                x = fminf(fmaxf(x, -9.0f), 9.0f);
+                a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
+            }
+        } else if (s == a.Kc + 1) {
+            if (a.train_lam) {
+                float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
+                adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
+                a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
             }
         }
-        if (a.loss_gene_step) a.loss_gene_step[j] = static_cast<float>(kl - ll);
     }
-    // block reduction of (kl, ll) in fp64 -> one deterministic partial per block
-    __shared__ double sk[kBlock], sl[kBlock];
-    sk[threadIdx.x] = kl;
-    sl[threadIdx.x] = ll;
+    if (s < a.Kc + 2) return;                      // uniform per block: only the KL / ll rows reduce further
+    // block reduction in fp64 -> one deterministic partial per (block, term)
+    __shared__ double sh[kBlock];
+    sh[threadIdx.x] = t;
     __syncthreads();
     for (int st = kBlock / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st) {
-            sk[threadIdx.x] += sk[threadIdx.x + st];
-            sl[threadIdx.x] += sl[threadIdx.x + st];
-        }
+        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        a.loss_parts[2 * blockIdx.x + 0] = sk[0];
-        a.loss_parts[2 * blockIdx.x + 1] = sl[0];
-    }
+    if (threadIdx.x == 0) a.loss_parts[2 * blockIdx.x + (s - a.Kc - 2)] = sh[0];
 }
 
 // ----------------------------------------------------------------------------
@@ -430,7 +508,7 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
 struct LossGeneArgs {
     const float *c1, *c2, *c3, *mu, *rho, *Xc, *W, *b, *lam, *effL;
     float *partials;
-    int64_t ld;
+    int64_t ld, row_stride, gb_stride;
     int32_t Nc, Ng, rows_per_chunk, n_rep;
     uint32_t seed_lo, seed_hi, draw0, quad_offset;
 };
@@ -477,8 +555,9 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
-            const int64_t off = static_cast<int64_t>(r) * a.ld + j0;
+            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
             F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
             if (MODE == kLikEff3) c3 = ld4(a.c3 + off);
@@ -554,20 +633,23 @@ __global__ void loss_gene_reduce(const float *partials, float *out, int64_t ld, 
 // small elementwise kernels (grid-stride over (Nc, ld) in float4 units)
 // ----------------------------------------------------------------------------
 // Model_init (model_TFProb.py:27-28): Z_loc ~ N(0,1), log Z_std ~ N(0,1)
-__global__ void init_z(float *mu, float *rho, int64_t ld, int Nc, int Ng, uint32_t seed_lo,
-                       uint32_t seed_hi, uint32_t quad_offset) {
-    const int quads = (Ng + kVec - 1) / kVec;
-    const int64_t total = static_cast<int64_t>(Nc) * quads;
+__global__ void init_z(float *mu, float *rho, int64_t row_stride, int64_t gb_stride, int gene_blocks, int Nc,
+                       int Ng, uint32_t seed_lo, uint32_t seed_hi, uint32_t quad_offset) {
+    const int64_t total = static_cast<int64_t>(gene_blocks) * Nc * kWave;
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int r = static_cast<int>(i / quads), q = static_cast<int>(i % quads);
+        const int lane = static_cast<int>(i % kWave);
+        const int r = static_cast<int>((i / kWave) % Nc);
+        const int g = static_cast<int>(i / (static_cast<int64_t>(kWave) * Nc));
+        const int q = g * kWave + lane;
         F4 e0, e1;
         normal4(quad_offset + q, r, kInitDraw, 0u, seed_lo, seed_hi, e0.v);
         normal4(quad_offset + q, r, kInitDraw, 1u, seed_lo, seed_hi, e1.v);
         for (int v = 0; v < kVec; ++v)
             if (q * kVec + v >= Ng) { e0.v[v] = 0.0f; e1.v[v] = 0.0f; }
-        st4(mu + static_cast<int64_t>(r) * ld + q * kVec, e0);
-        st4(rho + static_cast<int64_t>(r) * ld + q * kVec, e1);
+        const int64_t off = g * gb_stride + r * row_stride + lane * kVec;
+        st4(mu + off, e0);
+        st4(rho + off, e1);
     }
 }
 
@@ -640,6 +722,32 @@ __global__ void psi_epilogue(const float *mu, const float *rho, float *out, int6
 __global__ void exp_vec(const float *src, float *dst, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) dst[j] = expf(src[j]);
+}
+
+// ----------------------------------------------------------------------------
+// stream_mix: calibration kernel with the step kernel's HBM access mix and no
+// arithmetic: reads NR streams, writes NW streams of 16-B vectors.  Its rate is
+// the memory-system ceiling the fused kernel can be compared against.
+// ----------------------------------------------------------------------------
+struct StreamArgs {
+    const float *in[12];
+    float *out[12];
+    int64_t n4;          // float4 elements per stream
+};
+template <int NR, int NW>
+__global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < a.n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        F4 acc = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const F4 t = ld4(a.in[r] + 4 * i);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) acc.v[v] += t.v[v];
+        }
+#pragma unroll
+        for (int w = 0; w < NW; ++w) st4(a.out[w] + 4 * i, acc);
+    }
 }
 
 }  // namespace brie

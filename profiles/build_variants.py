@@ -1,0 +1,16 @@
+"""Build tuning variants of libbrie_amd.so into brie_amd/lib/variants/ (they travel to the GPU box)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from brie_amd.build import compile_library, LIB_DIR
+
+VARIANTS = {
+    "base": [],
+    "nt": ["BRIE_NT=1"],
+    "nopf": ["BRIE_PREFETCH=0"],
+    "nopf_nt": ["BRIE_PREFETCH=0", "BRIE_NT=1"],
+}
+names = sys.argv[1:] or sorted(VARIANTS)
+for n in names:
+    out = os.path.join(LIB_DIR, "variants", "libbrie_amd_%s.so" % n)
+    compile_library(out=out, defines=VARIANTS[n], verbose=True)

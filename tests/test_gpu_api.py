@@ -1,0 +1,95 @@
+"""-m gpu: the reference-shaped Python API (BRIE2 / fit_BRIE_matrix / fitBRIE) on the HIP path,
+checked against the oracle run through the same host logic."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
+from oracle.synth import make_problem
+from tests.fakes import FakeAnnData, OracleBackedBRIE2
+
+pytestmark = pytest.mark.gpu
+
+
+def test_BRIE2_fit_matches_oracle_fit(lib):
+    import brie_amd
+    Nc, Ng, Kc = 120, 100, 1
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=31, theta=2.0)
+    m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, seed=17)
+    losses = m.fit(P["counts"], Xc=P["Xc"], min_iter=240, max_iter=240, n_loss_gene=20, pseudo_count=0.01,
+                   verbose=False)
+    o = OracleBRIE2(Nc, Ng, Kc, seed=17, dtype=np.float64)
+    lo = o.fit(add_pseudo_count(P["counts"]), P["Xc"], min_iter=240, max_iter=240, n_loss_gene=20)
+    assert losses.shape == lo.shape == (40,)                 # trace of the LAST stage only (model_TFProb.py:239)
+    np.testing.assert_allclose(losses.numpy(), lo, rtol=2e-4)
+    d = np.abs(m.Psi.numpy() - o.Psi)
+    assert np.percentile(d, 99) < 1e-4 and d.max() < 2e-3
+    np.testing.assert_allclose(m.loss_gene.numpy(), o.loss_gene, rtol=2e-3, atol=2e-2)
+    np.testing.assert_allclose(m.Wc_loc.numpy(), o.Wc_loc, atol=2e-3)
+    np.testing.assert_allclose(m.intercept.numpy(), o.intercept, atol=2e-3)
+    assert m.Z_std.shape == (Nc, Ng) and m.Psi95CI.shape == (Nc, Ng) and m.sigma.shape == (1, Ng)
+    assert isinstance(m.Psi95CI, np.ndarray) and m.n_iter == 240
+    m.close()
+
+
+def test_BRIE2_init_obj_and_convergence_extension(lib):
+    import brie_amd
+    Nc, Ng = 60, 40
+    P = make_problem(Nc, Ng, Kc=0, L=2, seed=5)
+    rng = np.random.default_rng(1)
+    init = dict(Z_loc=rng.standard_normal((Nc, Ng)).astype(np.float32),
+                Z_std=np.exp(rng.standard_normal((Nc, Ng))).astype(np.float32),
+                Wc_loc=np.zeros((0, Ng), np.float32), intercept=rng.standard_normal((1, Ng)).astype(np.float32),
+                sigma=np.ones((1, Ng), np.float32))
+    m = brie_amd.BRIE2(Nc, Ng, init_obj=init, seed=3)
+    # epsilon below any loss drop => the while loop (model_TFProb.py:250-258) extends by add_iter until max_iter
+    losses = m.fit(P["counts"], min_iter=120, max_iter=200, add_iter=20, epsilon_conv=-1e9, n_loss_gene=2,
+                   verbose=False)
+    assert m.n_iter == 200 and len(losses) == 20 + 80
+    o = OracleBRIE2(Nc, Ng, 0, seed=3, dtype=np.float64,
+                    init=dict(Z_loc=init["Z_loc"], Z_std_log=np.log(init["Z_std"]), Wc_loc=init["Wc_loc"],
+                              intercept=init["intercept"], sigma_log=np.zeros((1, Ng))))
+    lo = o.fit(P["counts"], None, min_iter=120, max_iter=200, add_iter=20, epsilon_conv=-1e9, n_loss_gene=2)
+    assert o.n_iter == 200
+    np.testing.assert_allclose(losses.numpy(), lo, rtol=2e-4)
+    m.close()
+
+
+def test_fit_BRIE_matrix_LRT_matches_oracle_backed_run(lib, monkeypatch):
+    import brie_amd
+    import brie_amd.models.wrap as wrap
+    Nc, Ng, Kc = 150, 60, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=3, seed=9, effect_frac=0.5, depth=6.0)
+    kw = dict(Xc=P["Xc"], effLen=P["effLen"], LRT_index=[0], min_iter=180, max_iter=180, n_loss_gene=30,
+              verbose=False, seed=4)
+    res = brie_amd.fit_BRIE_matrix([sp.csc_matrix(c) for c in P["counts"]], **kw)     # sparse layers are densified
+    monkeypatch.setattr(wrap, "BRIE2", OracleBackedBRIE2)
+    ref = wrap.fit_BRIE_matrix([c.copy() for c in P["counts"]], **kw)
+    np.testing.assert_allclose(res.ELBO_gain, ref.ELBO_gain, atol=0.05, rtol=5e-3)
+    np.testing.assert_allclose(res.cell_coeff, ref.cell_coeff, atol=5e-3)
+    d = np.abs(res.Psi - ref.Psi)
+    assert np.percentile(d, 99) < 2e-4
+    assert res.pval.shape == (Ng, 1) and res.fdr.shape == (Ng, 1)
+    assert np.all((res.fdr >= res.pval - 1e-12) & (res.fdr <= 1))
+
+
+def test_fitBRIE_end_to_end_recovers_effects(lib):
+    """Data from the generative recipe (simulator.py:22-69): Psi recovered, LRT finds the effect genes."""
+    import brie_amd
+    Nc, Ng, Kc = 1500, 200, 1
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=21, theta=1.0, depth=8.0, effect_frac=0.3)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    res = brie_amd.fitBRIE(ad, Xc=P["Xc"], LRT_index=[0], min_iter=600, max_iter=600, n_loss_gene=100,
+                           verbose=False, seed=2)
+    assert np.corrcoef(ad.layers['Psi'].ravel(), P["Psi_true"].ravel())[0, 1] > 0.85
+    strong = np.abs(P["W_true"][0]) > 0.7
+    null = P["W_true"][0] == 0
+    assert np.corrcoef(ad.varm['cell_coeff'][strong, 0], P["W_true"][0][strong])[0, 1] > 0.95
+    gain = ad.varm['ELBO_gain'][:, 0]
+    print("ELBO_gain median: strong %.2f null %.2f; fdr<0.05: strong %.2f null %.2f" % (
+        np.median(gain[strong]), np.median(gain[null]), np.mean(ad.varm['fdr'][strong, 0] < 0.05),
+        np.mean(ad.varm['fdr'][null, 0] < 0.05)))
+    assert np.mean(ad.varm['fdr'][strong, 0] < 0.05) > 0.9          # power
+    assert np.median(gain[strong]) > 10 * max(1.0, abs(np.median(gain[null])))
+    assert ad.var['loss_gene'].shape == (Ng,) and res.losses.shape == (100,)
+    assert set(ad.uns['brie_param']) >= {'LRT_index', 'base_mode', 'pseudo_count', 'layer_keys'}

@@ -1,0 +1,88 @@
+"""-m gpu: parity at BASELINE.json's full single-GPU size (configs[2]: 50k cells x 20k genes,
+Kc=3) through properties that do not need the oracle to process 10^9 elements:
+
+ * genes are independent (model_wrap.py:241) and the noise stream is keyed by the global gene
+   index, so the oracle run on a handful of gene quads (all 50k cells) is an EXACT parity check
+   of those genes inside the full-size fit;
+ * the loss trace is finite and decreasing; every Psi is in (0,1); Z_loc respects the clip;
+ * gene-shard invariance: a 2500-gene shard fitted alone reproduces the same genes bit for bit.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 12
+
+
+def _generate(torch, dev, cfg, seed):
+    import bench
+    Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
+    gx = torch.Generator(device=dev)
+    gx.manual_seed(seed)
+    Xc = torch.zeros(Nc, Kc, device=dev)
+    Xc[:, 0] = (torch.rand(Nc, generator=gx, device=dev) < 0.5).float()
+    Xc[:, 1:] = torch.randn(Nc, Kc - 1, generator=gx, device=dev)
+    size = torch.exp(0.5 * torch.randn(Nc, generator=gx, device=dev))
+    layers = [torch.empty(Nc, Ng, device=dev) for _ in range(L)]
+    for c0 in range(0, Ng, bench.GEN_CHUNK):
+        c1 = min(c0 + bench.GEN_CHUNK, Ng)
+        cnt, _ = bench.gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
+        for l in range(L):
+            layers[l][:, c0:c1] = cnt[l]
+    return Xc, layers
+
+
+def test_full_size_config3(lib):
+    import torch
+    import bench
+    from brie_amd import _capi
+    from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS["c3"]
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 424242
+    Xc, layers = _generate(torch, dev, cfg, seed)
+    sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=seed)
+    for l in range(2):
+        sh.upload(_capi.COUNT1 + l, layers[l])
+    sh.add_pseudo_count(0.01)
+    sh.upload(_capi.XC, Xc)
+    sh.init_state()
+    trace = sh.step(STEPS, 0.01, 1)
+    assert np.all(np.isfinite(trace)) and trace[-1] < trace[0]
+    psi = sh.read(_capi.PSI)
+    zloc = sh.read(_capi.Z_LOC)
+    zsl = sh.read(_capi.Z_STD_LOG)
+    assert psi.min() > 0 and psi.max() < 1 and np.abs(zloc).max() <= 9.0
+    W, b, lam = sh.read(_capi.WC_LOC), sh.read(_capi.INTERCEPT), sh.read(_capi.SIGMA_LOG)
+
+    # --- exact parity of scattered gene quads against the oracle (all 50k cells)
+    Xc_h = Xc.cpu().numpy()
+    for g0 in (0, 7316, 19996):
+        cols = slice(g0, g0 + 4)
+        cnt = add_pseudo_count([layers[l][:, cols].cpu().numpy() for l in range(2)])
+        o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
+        tr = o.minimize(cnt, Xc_h, STEPS, 0.01, 1)
+        for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
+                                   ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
+                                   ("sigma_log", lam[:, cols], o.sigma_log)):
+            d = np.abs(dev_arr - ref)
+            assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (g0, name, float(d.max()))
+        d = np.abs(psi[:, cols] - o.Psi)
+        assert d.max() < 5e-4 and np.percentile(d, 99) < 1e-5, (g0, float(d.max()))
+
+    # --- gene-shard invariance at the 8-GPU shard size (BASELINE configs[3]: 2500 genes per GPU)
+    s0, s1 = 7500, 10000
+    part = _capi.Shard(Nc, s1 - s0, Kc, n_layers=2, seed=seed, gene_offset=s0)
+    for l in range(2):
+        part.upload(_capi.COUNT1 + l, layers[l][:, s0:s1])
+    part.add_pseudo_count(0.01)
+    part.upload(_capi.XC, Xc)
+    part.init_state()
+    part.step(STEPS, 0.01, 1)
+    np.testing.assert_array_equal(part.read(_capi.Z_LOC), zloc[:, s0:s1])
+    np.testing.assert_array_equal(part.read(_capi.WC_LOC), W[:, s0:s1])
+    np.testing.assert_array_equal(part.read(_capi.SIGMA_LOG), lam[:, s0:s1])
+    sh.close()
+    part.close()

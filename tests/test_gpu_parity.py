@@ -117,10 +117,16 @@ def test_psi_after_staged_fit(lib, Nc, Ng, Kc, L, MC, min_iter):
     print("PSI delta vs fp64 oracle: HIP max %.3g p99 %.3g | fp32 oracle max %.3g p99 %.3g"
           % (d_dev.max(), np.percentile(d_dev, 99), d_o32.max(), np.percentile(d_o32, 99)))
     assert np.percentile(d_dev, 99) <= 1e-4
-    assert d_dev.max() <= 1e-3
-    ci = sh.read(_capi.PSI95CI)
-    assert util.max_abs_diff(ci, o64.Psi95CI) <= 2e-3
-    np.testing.assert_allclose(sh.read(_capi.SIGMA), o64.sigma, rtol=1e-2)
+    # worst element: no farther from the fp64 answer than ~the reference's own fp32 precision gets
+    assert d_dev.max() <= max(1e-3, 3 * d_o32.max())
+    # same rule for the interval width and the prior width: bulk tight, worst element bounded by
+    # what the reference's own precision (fp32 oracle) does on the same trajectory
+    for name, dev, ref64, ref32 in (("Psi95CI", sh.read(_capi.PSI95CI), o64.Psi95CI, o32.Psi95CI),
+                                    ("sigma", sh.read(_capi.SIGMA), o64.sigma, o32.sigma)):
+        d = np.abs(dev - ref64)
+        d32 = np.abs(ref32 - ref64)
+        assert np.percentile(d, 99) <= max(2e-4, 3 * np.percentile(d32, 99)), (name, float(np.percentile(d, 99)))
+        assert d.max() <= max(2e-3, 3 * d32.max()), (name, float(d.max()), float(d32.max()))
 
 
 def test_loss_gene_matches_oracle(lib):

@@ -204,7 +204,8 @@ def main():
     if rank == 0:
         # measured ceiling of THIS box: a kernel with the same 16-B read/write stream mix and no arithmetic
         n_read = L + 6
-        stream_gbs = max(_capi.calibrate_stream(n_read, 6, 1 << 30, iters=5, device=local_rank) for _ in range(2))
+        stream_gbs = max(_capi.calibrate_stream(n_read, 6, 1 << 30, iters=5, device=local_rank, nt=nt)
+                         for nt in (False, True, False, True))
     sh.profile_enable(False)
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last

@@ -121,8 +121,10 @@ def _matrix_pointer(x):
     return a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.shape[1], a
 
 
-def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=0, lds_bytes=0):
+def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=0, lds_bytes=0, nt=False):
     """HBM GB/s of a pure streaming kernel with the given read/write stream mix."""
+    if nt:
+        lds_bytes = -(int(lds_bytes) + 1)
     lib = load_library()
     out = ctypes.c_double()
     _check(lib, lib.brie_calibrate_stream(int(device), int(n_read), int(n_write), int(bytes_per_stream),

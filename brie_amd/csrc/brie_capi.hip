@@ -624,7 +624,8 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
 // Measure the HBM rate of `n_read` read streams + `n_write` write streams of `bytes_per_stream`
 // each (no arithmetic) -> GB/s.  Supported mixes: (1,1) copy, (8,6) and (9,6) = elbo_adam_step with
 // 2 / 3 count layers.  `lds_bytes_per_block` > 0 reserves dynamic LDS per 256-thread block to cap the
-// occupancy (160 KiB per CU: 80 KiB -> 2 blocks = 8 waves per CU), i.e. the bytes in flight per CU.
+// occupancy (160 KiB per CU: 80 KiB -> 2 blocks = 8 waves per CU), i.e. the bytes in flight per CU;
+// a negative value -(lds+1) selects non-temporal loads/stores (what elbo_adam_step uses).
 int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream, int32_t iters,
                           int32_t lds_bytes_per_block, double *gbps) {
     if (!gbps || iters < 1 || bytes_per_stream < 4096) return fail(BRIE_ERR_INVALID, "bad argument");
@@ -645,11 +646,19 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const dim3 grid(8192), block(brie::kBlock);
+    const bool nt = lds_bytes_per_block < 0;          // negative: non-temporal variant, |value| = LDS bytes
+    const int lds = lds_bytes_per_block < 0 ? -lds_bytes_per_block - 1 : lds_bytes_per_block;
     for (int it = -2; it < iters; ++it) {
         if (it == 0) hipEventRecord(e0, nullptr);
-        if (n_read == 1) hipLaunchKernelGGL((brie::stream_mix<1, 1>), grid, block, lds_bytes_per_block, nullptr, a);
-        else if (n_read == 8) hipLaunchKernelGGL((brie::stream_mix<8, 6>), grid, block, lds_bytes_per_block, nullptr, a);
-        else hipLaunchKernelGGL((brie::stream_mix<9, 6>), grid, block, lds_bytes_per_block, nullptr, a);
+#define BRIE_SM(NR, NW)                                                                                  \
+    do {                                                                                                 \
+        if (nt) hipLaunchKernelGGL((brie::stream_mix<NR, NW, true>), grid, block, lds, nullptr, a);      \
+        else hipLaunchKernelGGL((brie::stream_mix<NR, NW, false>), grid, block, lds, nullptr, a);        \
+    } while (0)
+        if (n_read == 1) BRIE_SM(1, 1);
+        else if (n_read == 8) BRIE_SM(8, 6);
+        else BRIE_SM(9, 6);
+#undef BRIE_SM
     }
     hipEventRecord(e1, nullptr);
     hipError_t e = hipEventSynchronize(e1);

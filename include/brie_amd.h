@@ -143,7 +143,8 @@ int64_t brie_step_algorithmic_bytes(const brie_handle *h);
 
 /* Measurement utility (no reference counterpart): HBM rate in GB/s of a kernel that only reads
  * `n_read` and writes `n_write` 16-B-vector streams -- (1,1) = copy, (8,6)/(9,6) = the access mix of
- * elbo_adam_step with 2/3 count layers; lds_bytes_per_block > 0 caps the occupancy (waves per CU).
+ * elbo_adam_step with 2/3 count layers; lds_bytes_per_block > 0 caps the occupancy (waves per CU),
+ * a negative value -(lds+1) selects non-temporal loads/stores.
  * bench.py reports the fused kernel against this ceiling. */
 int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream,
                           int32_t iters, int32_t lds_bytes_per_block, double *gbps);

@@ -6,9 +6,7 @@ from brie_amd.build import compile_library, LIB_DIR
 
 VARIANTS = {
     "base": [],
-    "nt": ["BRIE_NT=1"],
-    "nopf": ["BRIE_PREFETCH=0"],
-    "nopf_nt": ["BRIE_PREFETCH=0", "BRIE_NT=1"],
+    "fast": ["BRIE_FAST_MATH=1"],
 }
 names = sys.argv[1:] or sorted(VARIANTS)
 for n in names:

@@ -215,6 +215,13 @@ def main():
     out = None
     if rank == 0:
         alg_bytes = sh.step_algorithmic_bytes()
+        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.config)
+            if pmc and world == 1 and args.mc == 1:
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         avg_ms = kern_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         out = {
@@ -230,7 +237,7 @@ def main():
                        "MC_size": args.mc, "genes_per_rank": ng, "parallelism": "gene-shard x%d" % world,
                        "inputs": "generated on device, resident in HBM (%.1f s, untimed)" % t_gen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
                          "measured_stream_ceiling_GBs": stream_gbs,

@@ -86,3 +86,39 @@ def test_full_size_config3(lib):
     np.testing.assert_array_equal(part.read(_capi.SIGMA_LOG), lam[:, s0:s1])
     sh.close()
     part.close()
+
+
+def test_max_size_config5_single_gpu(lib):
+    """BASELINE configs[4] whole on ONE GPU (100k cells x 30k genes, Kc=5: 3e9 elements, 97 GB of
+    state) -- the largest shape: exercises 64-bit offsets; the last gene quad is checked against the
+    oracle over all 100k cells."""
+    import torch
+    import bench
+    from brie_amd import _capi
+    from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS["c5"]
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 55
+    Xc, layers = _generate(torch, dev, cfg, seed)
+    sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=seed)
+    for l in range(2):
+        sh.upload(_capi.COUNT1 + l, layers[l])
+    sh.add_pseudo_count(0.01)
+    sh.upload(_capi.XC, Xc)
+    sh.init_state()
+    steps = 6
+    trace = sh.step(steps, 0.01, 1)
+    assert np.all(np.isfinite(trace)) and trace[-1] < trace[0]
+    g0 = Ng - 4
+    cnt = add_pseudo_count([layers[l][:, g0:].cpu().numpy() for l in range(2)])
+    del layers
+    torch.cuda.empty_cache()
+    o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
+    o.minimize(cnt, Xc.cpu().numpy(), steps, 0.01, 1)
+    zloc = sh.read(_capi.Z_LOC)
+    d = np.abs(zloc[:, g0:] - o.Z_loc)
+    assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3
+    np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:], o.Wc_loc, atol=2e-4)
+    assert np.abs(zloc).max() <= 9.0 and np.all(np.isfinite(zloc))
+    sh.close()

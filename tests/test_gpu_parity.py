@@ -170,3 +170,53 @@ def test_errors_are_loud(lib):
         sh.step(1, 0.01)                 # nothing uploaded yet
     with pytest.raises(ValueError):
         sh.upload(_capi.COUNT1, np.zeros((3, 3), np.float32))
+
+
+@pytest.mark.parametrize("Nc,Ng,Kc", [(1, 1, 0), (3, 5, 1), (2, 257, 0), (700, 4, 2), (5, 1030, 3)])
+def test_ragged_and_tiny_shapes(lib, Nc, Ng, Kc):
+    """Fewer rows than waves, gene counts that are not multiples of 4 / 256, one cell, one gene."""
+    P = util.problem(Nc, Ng, Kc, 2, seed=3)
+    o = util.oracle_model(P, Nc, Ng, Kc, 13, np.float32)
+    sh = util.device_shard(P, Nc, Ng, Kc, 13)
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 4, 0.02, 2)          # MC_size=2 -> generic (run-time MC) kernel
+    tr_d = sh.step(4, 0.02, 2)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=5e-5, atol=1e-4)
+    assert_states_close(util.oracle_state(o), util.device_state(sh))
+    np.testing.assert_allclose(sh.loss_gene(3), o.eval_loss_gene(P["counts_pc"], P["Xc"], 3), rtol=1e-4, atol=1e-3)
+
+
+def test_all_zero_counts_relax_to_prior(lib):
+    """doc/brie_quant.rst:143-146: events without reads end at the prior (Psi 0.5 under a zero-mean prior)."""
+    from brie_amd import _capi
+    Nc, Ng = 40, 12
+    P = {"counts": [np.zeros((Nc, Ng), np.float32)] * 2, "effLen": None, "Xc": np.zeros((Nc, 0), np.float32)}
+    sh = util.device_shard(P, Nc, Ng, 0, 4, intercept=0.0, sigma=2.0)
+    for n, lr in util.staged_schedule(900):
+        sh.reset_optimizer()
+        tr = sh.step(n, lr, 1)
+    assert np.all(np.isfinite(tr))
+    assert np.max(np.abs(sh.read(_capi.PSI) - 0.5)) < 0.02
+    np.testing.assert_allclose(sh.read(_capi.Z_STD), 2.0, rtol=0.03)
+    assert sh.read(_capi.PSI95CI).min() > 0.9
+
+
+def test_large_counts_and_clip(lib):
+    """Deep coverage drives Z_loc to the clip; everything stays finite and Psi -> c1/(c1+c2)."""
+    from brie_amd import _capi
+    Nc, Ng = 16, 8
+    c1 = np.full((Nc, Ng), 5000, np.float32)
+    c1[:, ::2] = 0
+    c2 = 5000 - c1
+    P = {"counts": [c1, c2], "effLen": None, "Xc": np.zeros((Nc, 0), np.float32)}
+    sh = util.device_shard(P, Nc, Ng, 0, 6)
+    o = util.oracle_model(P, Nc, Ng, 0, 6, np.float32)
+    cnt = [c1 + np.float32(0.01), c2 + np.float32(0.01)]
+    for n, lr in util.staged_schedule(1200):
+        sh.reset_optimizer(); o.reset_optimizer()
+        tr = sh.step(n, lr, 1)
+        o.minimize(cnt, None, n, lr, 1)
+    z = sh.read(_capi.Z_LOC)
+    assert np.all(np.isfinite(tr)) and np.abs(z).max() <= 9.0
+    psi = sh.read(_capi.PSI)
+    assert psi[:, 1::2].min() > 0.99 and psi[:, ::2].max() < 0.01
+    np.testing.assert_allclose(z, o.Z_loc, atol=5e-3)

@@ -318,6 +318,9 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
     if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
+    // `src` may live in HBM and may still be being produced on another stream (e.g. a torch tensor on
+    // torch's stream); the handle's stream is non-blocking, so order the copy after ALL prior device work.
+    HIP_TRY(hipDeviceSynchronize());
     if (which == BRIE_EFFLEN) {
         if (!h->p.has_efflen) return fail(BRIE_ERR_INVALID, "problem was created without effLen");
         if (rows != h->p.Ng || cols != 6)

@@ -104,6 +104,8 @@ def main():
                     help="strong: the config's genes are sharded over ranks (BASELINE configs[3]); "
                          "weak: every rank fits the whole config")
     ap.add_argument("--rows-per-chunk", type=int, default=0)
+    ap.add_argument("--count-storage", default="auto", choices=["auto", "f32"],
+                    help="auto: integer counts <= 255 are kept as u8 in HBM (bit-identical results); f32: as uploaded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psi-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -163,6 +165,8 @@ def main():
     torch.cuda.synchronize()
 
     sh = _capi.Shard(Nc, ng, Kc, n_layers=L, has_efflen=L == 3, seed=seed, device=local_rank, gene_offset=g0)
+    if args.count_storage == "f32":
+        sh.set_count_storage(1)
     for l in range(L):
         sh.upload(_capi.COUNT1 + l, layers[l])           # device -> device
     sh.add_pseudo_count(0.01)
@@ -220,7 +224,7 @@ def main():
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.config)
-            if pmc and world == 1 and args.mc == 1:
+            if pmc and world == 1 and args.mc == 1 and pmc.get("count_storage", "f32") == sh.count_storage:
                 traffic = pmc["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass
@@ -242,6 +246,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
+                         "count_storage": sh.count_storage, "storage_bytes_per_launch": sh.step_storage_bytes(),
                          "measured_stream_ceiling_GBs": stream_gbs,
                          "frac_of_measured_stream_ceiling": achieved / stream_gbs},
         }

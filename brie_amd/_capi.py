@@ -22,8 +22,8 @@ EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
-    "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_calibrate_stream", "brie_last_error",
-    "brie_abi_version",
+    "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
+    "brie_get_count_storage", "brie_calibrate_stream", "brie_last_error", "brie_abi_version",
 ]
 
 
@@ -75,10 +75,15 @@ def load_library(path=None):
     lib.brie_calibrate_stream.argtypes = [i32, i32, i32, i64, i32, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_step_algorithmic_bytes.argtypes = [vp]
     lib.brie_step_algorithmic_bytes.restype = i64
+    lib.brie_step_storage_bytes.argtypes = [vp]
+    lib.brie_step_storage_bytes.restype = i64
+    lib.brie_set_count_storage.argtypes = [vp, i32]
+    lib.brie_get_count_storage.argtypes = [vp]
     lib.brie_last_error.restype = ctypes.c_char_p
     lib.brie_abi_version.restype = ctypes.c_int
     for name in EXPORTS:
-        if name not in ("brie_step_algorithmic_bytes", "brie_last_error", "brie_abi_version"):
+        if name not in ("brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_last_error",
+                        "brie_abi_version"):
             getattr(lib, name).restype = ctypes.c_int
     if lib.brie_abi_version() != ABI_VERSION:
         raise ImportError("libbrie_amd.so ABI %d != binding %d" % (lib.brie_abi_version(), ABI_VERSION))
@@ -221,3 +226,14 @@ class Shard(object):
 
     def step_algorithmic_bytes(self):
         return int(self.lib.brie_step_algorithmic_bytes(self._h))
+
+    def step_storage_bytes(self):
+        return int(self.lib.brie_step_storage_bytes(self._h))
+
+    def set_count_storage(self, mode):
+        """0 = auto (u8 when every count is an integer <= 255), 1 = always fp32."""
+        _check(self.lib, self.lib.brie_set_count_storage(self._h, int(mode)))
+
+    @property
+    def count_storage(self):
+        return {0: "f32", 1: "u8", 2: "u16"}.get(int(self.lib.brie_get_count_storage(self._h)), "?")

@@ -1,14 +1,25 @@
-"""Build the HIP shared library in-tree (gfx950 only)."""
+"""Build the HIP shared library in-tree (gfx950 only).
+
+    python -m brie_amd.build
+
+Translation units: brie_capi.hip (C ABI + small kernels) and brie_inst.hip once per cell-feature
+count KC = 0..8 (the template instantiations of the two streaming kernels), compiled in parallel
+and linked into brie_amd/lib/libbrie_amd.so.
+"""
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbrie_amd.so")
-SOURCES = [os.path.join(HERE, "csrc", "brie_capi.hip")]
-HEADERS = [os.path.join(HERE, "csrc", "brie_kernels.hip.h"), os.path.join(ROOT, "include", "brie_amd.h")]
+SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip")]
+HEADERS = [os.path.join(CSRC, "brie_kernels.hip.h"), os.path.join(CSRC, "brie_launch.h"),
+           os.path.join(ROOT, "include", "brie_amd.h")]
+MAX_KC = 8
 
 
 def needs_build():
@@ -18,7 +29,7 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in SOURCES + HEADERS)
 
 
-def compile_library(force=False, fast_math=None, verbose=False, out=None, defines=()):
+def compile_library(force=False, fast_math=None, verbose=False, out=None, defines=(), jobs=None):
     """hipcc --offload-arch=gfx950 -> brie_amd/lib/libbrie_amd.so (cross-compiles without a GPU).
 
     `out` / `defines` build tuning variants (e.g. -DBRIE_MIN_WAVES=4) next to the default library;
@@ -28,22 +39,38 @@ def compile_library(force=False, fast_math=None, verbose=False, out=None, define
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libbrie_amd.so")
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(HERE, "csrc")]
+    out = out or LIB_PATH
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    obj_dir = os.path.join(HERE, "build", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(obj_dir, exist_ok=True)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     if fast_math is None:
         fast_math = os.environ.get("BRIE_FAST_MATH")
     if fast_math is not None:
-        cmd.append("-DBRIE_FAST_MATH=%d" % int(fast_math))
-    cmd += ["-D" + d for d in defines]
-    out = out or LIB_PATH
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    cmd += SOURCES + ["-o", out]
+        base.append("-DBRIE_FAST_MATH=%d" % int(fast_math))
+    base += ["-D" + d for d in defines]
+    units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), [])]
+    for kc in range(MAX_KC + 1):
+        units.append((os.path.join(CSRC, "brie_inst.hip"), os.path.join(obj_dir, "brie_inst_kc%d.o" % kc),
+                      ["-DBRIE_KC=%d" % kc]))
+
+    def cc(unit):
+        src, obj, extra = unit
+        cmd = base + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(cc, units))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+        print(" ".join(link))
+    subprocess.run(link, check=True)
     return out
 
 
 if __name__ == "__main__":
-    print(compile_library(force=True, verbose=True))
+    print(compile_library(force=True, verbose="-v" in os.sys.argv))

@@ -2,7 +2,8 @@
 // One handle = one gene shard resident in the HBM of one MI355X, driven on its
 // own HIP stream.  No torch, no C++ types across the boundary.
 #include "brie_amd.h"
-#include "brie_kernels.hip.h"
+#define BRIE_HOST_TU 1
+#include "brie_launch.h"
 
 #include <cmath>
 #include <cstdarg>
@@ -48,6 +49,11 @@ struct brie_handle {
     hipStream_t stream = nullptr;
     // (Nc, ld)
     float *c[3] = {nullptr, nullptr, nullptr};
+    void *cu[3] = {nullptr, nullptr, nullptr};      // compact (u8 / u16) count layers, same tiled indexing
+    int cs = brie::kCountF32;       // current count storage
+    bool allow_compact = true;      // BRIE_COUNT_STORAGE=f32 / brie_set_count_storage(h, 1) disable it
+    bool compact_tried = false;
+    float pc = 0.0f;                // pseudo-count applied in registers when cs == kCountU8
     float *mu = nullptr, *rho = nullptr, *m_mu = nullptr, *v_mu = nullptr, *m_rho = nullptr,
           *v_rho = nullptr;
     float *Xc = nullptr;            // (Nc, Kc)
@@ -125,62 +131,73 @@ int check_ready(const brie_handle *h) {
     return BRIE_OK;
 }
 
-struct StepPointers {
-    const float *c1, *c2, *c3;
-    float *mu, *rho, *m_mu, *v_mu, *m_rho, *v_rho;
-    const float *Xc, *W, *b, *lam, *effL;
-    float *partials;
-};
-
-template <int KC, int MODE>
-void launch_step_mode(const brie_handle *h, const StepPointers &q, const brie::StepScalars &a, dim3 grid) {
-#define BRIE_LAUNCH_STEP(MC)                                                                                     \
-    hipLaunchKernelGGL((brie::elbo_adam_step<KC, MODE, MC>), grid, dim3(brie::kBlock), 0, h->stream, q.c1, q.c2,    \
-                       q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,        \
-                       q.partials, a)
-    // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
-    if (a.mc == 1) BRIE_LAUNCH_STEP(1);
-    else if (a.mc == 3) BRIE_LAUNCH_STEP(3);
-    else BRIE_LAUNCH_STEP(0);
-#undef BRIE_LAUNCH_STEP
+void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
+                 const brie::StepScalars &a) {
+    switch (h->p.Kc) {
+#define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a); break;
+        BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
+        default: brie::launch_step_kc8(c, q, a); break;
+#undef BRIE_CASE
+    }
 }
-
-template <int KC>
-void launch_step_kc(const brie_handle *h, const StepPointers &q, const brie::StepScalars &a, dim3 grid) {
-    switch (h->mode) {
-        case brie::kLik2: launch_step_mode<KC, brie::kLik2>(h, q, a, grid); break;
-        case brie::kLikEff2: launch_step_mode<KC, brie::kLikEff2>(h, q, a, grid); break;
-        default: launch_step_mode<KC, brie::kLikEff3>(h, q, a, grid); break;
+void launch_loss_gene(const brie_handle *h, const brie::LaunchCfg &c, const brie::LossGeneArgs &a) {
+    switch (h->p.Kc) {
+#define BRIE_CASE(N) case N: brie::launch_loss_gene_kc##N(c, a); break;
+        BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
+        default: brie::launch_loss_gene_kc8(c, a); break;
+#undef BRIE_CASE
     }
 }
 
-template <int KC>
-void launch_lg_kc(const brie_handle *h, const brie::LossGeneArgs &a, dim3 grid) {
-    switch (h->mode) {
-        case brie::kLik2:
-            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLik2>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
-        case brie::kLikEff2:
-            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLikEff2>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
-        default:
-            hipLaunchKernelGGL((brie::loss_gene_eval<KC, brie::kLikEff3>), grid, dim3(brie::kBlock), 0, h->stream, a);
-            break;
+int grid_1d(int64_t n);
+
+// Try to switch the count layers to a compact storage: u8 if every value is an integer in [0,255],
+// u16 if in [0,65535], else stay fp32.  Called once, when the counts are final (at the pseudo-count,
+// or at the first step if none is added).
+int try_compact_counts(brie_handle *h) {
+    if (h->compact_tried) return BRIE_OK;
+    h->compact_tried = true;
+    if (!h->allow_compact || !h->tiled) return BRIE_OK;
+    const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
+    int *flag = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int)));
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+    for (int l = 0; l < h->p.n_layers; ++l)
+        hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4, flag);
+    int bits = 1;
+    hipError_t e = hipMemcpyAsync(&bits, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(flag);
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "count range check: %s", hipGetErrorString(e));
+    if (bits & 1) return BRIE_OK;                 // fractional / negative / huge: stay fp32
+    const int cs = (bits & 2) ? brie::kCountU16 : brie::kCountU8;
+    const size_t bytes = static_cast<size_t>(n) * (cs == brie::kCountU16 ? 2 : 1);
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        HIP_TRY(hipMalloc(&h->cu[l], bytes));
+        hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->c[l])); h->c[l] = nullptr; }
+    h->cs = cs;
+    return BRIE_OK;
 }
 
-#define BRIE_DISPATCH_KC(fn, h, ...)                     \
-    switch ((h)->p.Kc) {                                 \
-        case 0: fn<0>(h, __VA_ARGS__); break;            \
-        case 1: fn<1>(h, __VA_ARGS__); break;            \
-        case 2: fn<2>(h, __VA_ARGS__); break;            \
-        case 3: fn<3>(h, __VA_ARGS__); break;            \
-        case 4: fn<4>(h, __VA_ARGS__); break;            \
-        case 5: fn<5>(h, __VA_ARGS__); break;            \
-        case 6: fn<6>(h, __VA_ARGS__); break;            \
-        case 7: fn<7>(h, __VA_ARGS__); break;            \
-        default: fn<8>(h, __VA_ARGS__); break;           \
+// Back to fp32 layers (pseudo-count materialised) -- used when counts are modified again.
+int expand_counts(brie_handle *h) {
+    if (h->cs == brie::kCountF32) return BRIE_OK;
+    const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->c[l]), static_cast<size_t>(n) * sizeof(float)));
+        hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
+                           h->c[l], n4, h->pc, l < 2 ? 1 : 0, h->cs);
     }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->cu[l])); h->cu[l] = nullptr; }
+    h->cs = brie::kCountF32;
+    h->pc = 0.0f;
+    h->allow_compact = false;                     // values are no longer integers
+    return BRIE_OK;
+}
 
 int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t *cols, int64_t *ldd) {
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
@@ -268,6 +285,8 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     {   // device layout of cell x gene matrices: "tiled" (default) or "rowmajor" (BRIE_LAYOUT, for A/B runs)
         const char *lay = getenv("BRIE_LAYOUT");
         h->tiled = !(lay && strcmp(lay, "rowmajor") == 0);
+        const char *cst = getenv("BRIE_COUNT_STORAGE");
+        h->allow_compact = !(cst && strcmp(cst, "f32") == 0);
         if (h->tiled) { h->row_stride = brie::kGenesPerBlock; h->gb_stride = p->Nc * brie::kGenesPerBlock; }
         else { h->row_stride = h->ld; h->gb_stride = brie::kGenesPerBlock; }
     }
@@ -307,6 +326,8 @@ int brie_destroy(brie_handle *h) {
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
+    for (void *q : h->cu)
+        if (q) hipFree(q);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -341,6 +362,13 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
         h->have_eff = true;
         return BRIE_OK;
     }
+    if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3 && (h->cs != brie::kCountF32 || h->compact_tried)) {
+        // a fresh layer restarts the storage decision: back to plain fp32 layers first
+        if ((rc = expand_counts(h)) != BRIE_OK) return rc;
+        h->compact_tried = false;
+        const char *cst = getenv("BRIE_COUNT_STORAGE");
+        h->allow_compact = !(cst && strcmp(cst, "f32") == 0);
+    }
     float *dev = nullptr;
     int64_t R = 0, C = 0, ldd = 0;
     rc = matrix_target(h, which, &dev, &R, &C, &ldd);
@@ -367,11 +395,20 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
 int brie_add_pseudo_count(brie_handle *h, float pc) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (!h->have_c[0] || !h->have_c[1]) return fail(BRIE_ERR_STATE, "count layers 1 and 2 not uploaded");
+    for (int l = 0; l < h->p.n_layers; ++l)
+        if (!h->have_c[l]) return fail(BRIE_ERR_STATE, "count layer %d not uploaded", l + 1);
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if (h->cs != brie::kCountF32 && (rc = expand_counts(h)) != BRIE_OK) return rc;   // second pseudo-count: fp32
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    if (h->cs != brie::kCountF32) {           // integer counts: keep them compact, add `pc` in registers
+        h->pc = pc;
+        return BRIE_OK;
+    }
     const int64_t n4 = h->p.Nc * h->ld / 4;
     hipLaunchKernelGGL(brie::pseudo_count, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[0], h->c[1], n4, pc);
     HIP_TRY(hipGetLastError());
+    h->compact_tried = true;                  // fractional values from now on
     return BRIE_OK;
 }
 
@@ -431,6 +468,26 @@ int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk) {
     return BRIE_OK;
 }
 
+int brie_set_count_storage(brie_handle *h, int32_t mode) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (mode != 0 && mode != 1) return fail(BRIE_ERR_INVALID, "count storage mode %d (0 = auto, 1 = fp32)", mode);
+    if (mode == 1) {
+        int rc = set_device(h);
+        if (rc != BRIE_OK) return rc;
+        if ((rc = expand_counts(h)) != BRIE_OK) return rc;
+    }
+    h->allow_compact = mode == 0;
+    return BRIE_OK;
+}
+
+int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
+
+int64_t brie_step_storage_bytes(const brie_handle *h) {
+    if (!h) return 0;
+    const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
+    return h->p.Nc * h->p.Ng * (48 + per_count * static_cast<int64_t>(h->p.n_layers));
+}
+
 int64_t brie_step_algorithmic_bytes(const brie_handle *h) {
     if (!h) return 0;
     return h->p.Nc * h->p.Ng * (48 + 4 * static_cast<int64_t>(h->p.n_layers));
@@ -443,6 +500,7 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const size_t lp_need = static_cast<size_t>(n_steps) * h->fin_blocks * 2;
     if (lp_need > h->loss_parts_elems) {
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -459,8 +517,11 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         }
     }
 
-    StepPointers q{};
-    q.c1 = h->c[0]; q.c2 = h->c[1]; q.c3 = h->c[2];
+    const bool u8 = h->cs != brie::kCountF32;
+    brie::StepPointers q{};
+    q.c1 = u8 ? static_cast<const void *>(h->cu[0]) : h->c[0];
+    q.c2 = u8 ? static_cast<const void *>(h->cu[1]) : h->c[1];
+    q.c3 = u8 ? static_cast<const void *>(h->cu[2]) : h->c[2];
     q.mu = h->mu; q.rho = h->rho; q.m_mu = h->m_mu; q.v_mu = h->v_mu; q.m_rho = h->m_rho; q.v_rho = h->v_rho;
     q.Xc = h->Xc; q.W = h->W; q.b = h->b; q.lam = h->lam; q.effL = h->effL; q.partials = h->partials;
     brie::StepScalars a{};
@@ -469,13 +530,14 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    a.pc = h->pc;
+    brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream};
 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
     f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
     f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks; f.train_b = h->p.train_intercept; f.train_lam = h->p.train_sigma;
 
-    const dim3 grid(h->gene_blocks, h->n_chunks);
     for (int i = 0; i < n_steps; ++i) {
         h->t += 1;
         const double tt = static_cast<double>(h->t);
@@ -485,7 +547,7 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        BRIE_DISPATCH_KC(launch_step_kc, h, q, a, grid);
+        launch_step(h, cfg, q, a);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
     }
@@ -512,8 +574,14 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     if (n_repeats < 1 || !out) return fail(BRIE_ERR_INVALID, "n_repeats=%d out=%p", n_repeats, (void *)out);
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    const bool u8 = h->cs != brie::kCountF32;
     brie::LossGeneArgs a{};
-    a.c1 = h->c[0]; a.c2 = h->c[1]; a.c3 = h->c[2]; a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
+    a.c1 = u8 ? static_cast<const void *>(h->cu[0]) : h->c[0];
+    a.c2 = u8 ? static_cast<const void *>(h->cu[1]) : h->c[1];
+    a.c3 = u8 ? static_cast<const void *>(h->cu[2]) : h->c[2];
+    a.pc = h->pc;
+    a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
     a.lam = h->lam; a.effL = h->effL; a.partials = h->partials; a.ld = h->ld;
     a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
     a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
@@ -521,8 +589,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     h->draw += static_cast<uint32_t>(n_repeats);
-    const dim3 grid(h->gene_blocks, h->n_chunks);
-    BRIE_DISPATCH_KC(launch_lg_kc, h, a, grid);
+    launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream}, a);
     hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
                        h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));
     HIP_TRY(hipGetLastError());
@@ -558,6 +625,23 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
                            static_cast<int>(Ng));
         HIP_TRY(hipMemcpyAsync(dst, h->gene_tmp, Ng * sizeof(float), hipMemcpyDefault, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        return BRIE_OK;
+    }
+    if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3 && h->cs != brie::kCountF32) {
+        const int l = which - BRIE_COUNT1;
+        if (l >= h->p.n_layers) return fail(BRIE_ERR_INVALID, "count layer %d outside n_layers=%d", l + 1, h->p.n_layers);
+        if (rows != Nc || cols != Ng)
+            return fail(BRIE_ERR_INVALID, "array %d is (%lld, %lld)", which, (long long)Nc, (long long)Ng);
+        float *tmp = nullptr;
+        const int64_t n4 = Nc * h->ld / 4;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * h->ld * sizeof(float)));
+        hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
+                           tmp, n4, h->pc, l < 2 ? 1 : 0, h->cs);
+        rc = copy_cellgene(h, tmp, nullptr, dst, ld);
+        hipError_t e = hipStreamSynchronize(h->stream);
+        hipFree(tmp);
+        if (rc != BRIE_OK) return rc;
+        if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read compact counts: %s", hipGetErrorString(e));
         return BRIE_OK;
     }
     float *dev = nullptr;

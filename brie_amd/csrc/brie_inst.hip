@@ -1,0 +1,66 @@
+// brie_inst.hip -- instantiates elbo_adam_step / loss_gene_eval for ONE cell-feature count
+// (-DBRIE_KC=N) over likelihood mode x MC_size {1, 3, run-time} x count storage {fp32, u8, u16}.
+#include "brie_launch.h"
+
+#ifndef BRIE_KC
+#error "compile with -DBRIE_KC=<0..8>"
+#endif
+#define BRIE_CAT2(a, b) a##b
+#define BRIE_CAT(a, b) BRIE_CAT2(a, b)
+
+namespace brie {
+
+namespace {
+
+template <int MODE, int MC, int CS>
+void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, MC, CS>), c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3,
+                       q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a);
+}
+
+template <int MODE, int CS>
+void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
+    if (a.mc == 1) step_launch<MODE, 1, CS>(c, q, a);
+    else if (a.mc == 3) step_launch<MODE, 3, CS>(c, q, a);
+    else step_launch<MODE, 0, CS>(c, q, a);
+}
+
+template <int MODE>
+void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    if (c.cs == kCountU8) step_mc<MODE, kCountU8>(c, q, a);
+    else if (c.cs == kCountU16) step_mc<MODE, kCountU16>(c, q, a);
+    else step_mc<MODE, kCountF32>(c, q, a);
+}
+
+template <int MODE, int CS>
+void lg_launch(const LaunchCfg &c, const LossGeneArgs &a) {
+    hipLaunchKernelGGL((loss_gene_eval<BRIE_KC, MODE, CS>), c.grid, dim3(kBlock), 0, c.stream, a);
+}
+
+template <int MODE>
+void lg_cs(const LaunchCfg &c, const LossGeneArgs &a) {
+    if (c.cs == kCountU8) lg_launch<MODE, kCountU8>(c, a);
+    else if (c.cs == kCountU16) lg_launch<MODE, kCountU16>(c, a);
+    else lg_launch<MODE, kCountF32>(c, a);
+}
+
+}  // namespace
+
+void BRIE_CAT(launch_step_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    switch (c.mode) {
+        case kLik2: step_cs<kLik2>(c, q, a); break;
+        case kLikEff2: step_cs<kLikEff2>(c, q, a); break;
+        default: step_cs<kLikEff3>(c, q, a); break;
+    }
+}
+
+void BRIE_CAT(launch_loss_gene_kc, BRIE_KC)(const LaunchCfg &c, const LossGeneArgs &a) {
+    switch (c.mode) {
+        case kLik2: lg_cs<kLik2>(c, a); break;
+        case kLikEff2: lg_cs<kLikEff2>(c, a); break;
+        default: lg_cs<kLikEff3>(c, a); break;
+    }
+}
+
+}  // namespace brie

@@ -213,10 +213,81 @@ struct StepScalars {
     uint32_t seed_lo, seed_hi, draw, quad_offset;
     float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
     float inv_mc;
+    float pc;                               // pseudo-count applied on the fly to compact (u8) counts
 };
 
-// the 16-B vectors one lane holds for one cell row
-struct RowRegs { F4 c1, c2, c3, mu, rho, mm, vm, mr, vr; };
+// Count storage.  kCountF32: the uploaded fp32 layers (pseudo-count already applied in place).
+// kCountU8: when every count is an integer in [0, 255] the layers are kept as one byte per element
+// (4 genes = one dword per lane) and model_wrap.py:113-117's pseudo-count is applied in registers;
+// the fp32 values entering the arithmetic are bit-identical, the count traffic drops from 4L to L bytes.
+// kCountU16: same with two bytes per element for integers up to 65535 (4 genes = 8 B per lane).
+enum : int { kCountF32 = 0, kCountU8 = 1, kCountU16 = 2 };
+
+template <int CS> struct CountRegs;
+template <> struct CountRegs<kCountF32> { F4 c1, c2, c3; };
+template <> struct CountRegs<kCountU8> { uint32_t u1, u2, u3; };
+template <> struct CountRegs<kCountU16> { uint2 u1, u2, u3; };
+
+typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 ld_u16x4(const void *p, int64_t off) {
+    const uintx2 t = __builtin_nontemporal_load(
+        reinterpret_cast<const uintx2 *>(static_cast<const uint16_t *>(p) + off));
+    return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ float u16_lane(const uint2 &u, int v) {
+    const uint32_t w = v < 2 ? u.x : u.y;
+    return static_cast<float>((w >> (16 * (v & 1))) & 0xFFFFu);
+}
+
+template <int CS, int MODE>
+__device__ __forceinline__ void load_counts(const void *__restrict__ p1, const void *__restrict__ p2,
+                                            const void *__restrict__ p3, int64_t off, CountRegs<CS> &C) {
+    if constexpr (CS == kCountF32) {
+        C.c1 = ld4s(static_cast<const float *>(p1) + off);
+        C.c2 = ld4s(static_cast<const float *>(p2) + off);
+        if (MODE == kLikEff3) C.c3 = ld4s(static_cast<const float *>(p3) + off);
+        else C.c3 = F4{{0.f, 0.f, 0.f, 0.f}};
+    } else if constexpr (CS == kCountU8) {
+        C.u1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p1) + off));
+        C.u2 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p2) + off));
+        if (MODE == kLikEff3)
+            C.u3 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p3) + off));
+        else C.u3 = 0u;
+    } else {
+        C.u1 = ld_u16x4(p1, off);
+        C.u2 = ld_u16x4(p2, off);
+        if (MODE == kLikEff3) C.u3 = ld_u16x4(p3, off);
+        else C.u3 = make_uint2(0u, 0u);
+    }
+}
+
+// counts of the lane's 4 genes as fp32, pseudo-count rule included for the compact storage
+template <int CS>
+__device__ __forceinline__ void decode_counts(const CountRegs<CS> &C, float pc, F4 &c1, F4 &c2, F4 &c3) {
+    if constexpr (CS == kCountF32) {
+        c1 = C.c1; c2 = C.c2; c3 = C.c3;
+    } else if constexpr (CS == kCountU8) {
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            float a = static_cast<float>((C.u1 >> (8 * v)) & 0xFFu);
+            float b = static_cast<float>((C.u2 >> (8 * v)) & 0xFFu);
+            if (a + b > 0.0f) { a += pc; b += pc; }
+            c1.v[v] = a; c2.v[v] = b;
+            c3.v[v] = static_cast<float>((C.u3 >> (8 * v)) & 0xFFu);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            float a = u16_lane(C.u1, v), b = u16_lane(C.u2, v);
+            if (a + b > 0.0f) { a += pc; b += pc; }
+            c1.v[v] = a; c2.v[v] = b;
+            c3.v[v] = u16_lane(C.u3, v);
+        }
+    }
+}
+
+// the vectors one lane holds for one cell row
+template <int CS> struct RowRegs { CountRegs<CS> cnt; F4 mu, rho, mm, vm, mr, vr; };
 
 constexpr float kOneMinusB1 = 1.0f - 0.9f;      // as Keras computes it in fp32
 constexpr float kOneMinusB2 = 1.0f - 0.999f;
@@ -231,9 +302,9 @@ constexpr float kAdamEps = 1e-7f;
 // one straight-line basic block, which is what lets the next row's loads stay
 // in flight across it); MC == 0: run-time count a.mc.
 // ----------------------------------------------------------------------------
-template <int KC, int MODE, int MC>
+template <int KC, int MODE, int MC, int CS>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
-    const float *__restrict__ c1p, const float *__restrict__ c2p, const float *__restrict__ c3p,
+    const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
@@ -292,12 +363,9 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
 
-        auto load_row = [&](int r, RowRegs &R, float (&xr)[KCX]) {
+        auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX]) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-            R.c1 = ld4s(c1p + off);
-            R.c2 = ld4s(c2p + off);
-            if (MODE == kLikEff3) R.c3 = ld4s(c3p + off);
-            else R.c3 = F4{{0.f, 0.f, 0.f, 0.f}};
+            load_counts<CS, MODE>(c1p, c2p, c3p, off, R.cnt);
             R.mu = ld4s(mu_p + off);
             R.rho = ld4s(rho_p + off);
             R.mm = ld4s(mmu_p + off);
@@ -308,8 +376,10 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
         };
 
-        auto process_row = [&](int r, RowRegs &R, const float (&xc)[KCX]) {
+        auto process_row = [&](int r, RowRegs<CS> &R, const float (&xc)[KCX]) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            F4 c1, c2, c3;
+            decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
             float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
                   ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
 #pragma unroll
@@ -322,7 +392,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 for (int v = 0; v < kVec; ++v) {
                     const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
                     float l, g;
-                    loglik<MODE>(z, R.c1.v[v], R.c2.v[v], R.c3.v[v], L0[v], L4[v], L5[v],
+                    loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
                                  lL0[v], lL4[v], lL5[v], l, g);
                     ll[v] += l;
                     gbar[v] += g;
@@ -374,7 +444,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 
         int r = row0 + w;
         const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
-        RowRegs cur;
+        RowRegs<CS> cur;
         float xc[KCX];
         load_row(r, cur, xc);
 #if BRIE_PREFETCH
@@ -383,7 +453,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body
         // is branch-free; the last row is peeled so no load is ever issued for a row that is not used.
         while (r < r_last) {
-            RowRegs nxt;
+            RowRegs<CS> nxt;
             float xn[KCX];
             load_row(r + kWavesPerBlock, nxt, xn);
             process_row(r, cur, xc);
@@ -430,6 +500,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     }
 }
 
+#ifdef BRIE_HOST_TU   // non-template kernels: defined once, in brie_capi.hip's translation unit
 // ----------------------------------------------------------------------------
 // gene_finalize: per gene, sum the chunk partials (fp64), Adam for Wc_loc,
 // intercept (clip +-9) and sigma_log, and emit the loss partial sums.
@@ -502,6 +573,8 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
     if (threadIdx.x == 0) a.loss_parts[2 * blockIdx.x + (s - a.Kc - 2)] = sh[0];
 }
 
+#endif  // BRIE_HOST_TU
+
 // ----------------------------------------------------------------------------
 // loss_gene_eval: forward-only ELBO per gene averaged over `n_rep` fresh noise
 // draws (MC_size = 1 each), reading every element ONCE: the KL term is
@@ -509,14 +582,16 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
 // partials: (n_chunks, 2, ld) = sum_i KL, sum_i sum_rep ll
 // ----------------------------------------------------------------------------
 struct LossGeneArgs {
-    const float *c1, *c2, *c3, *mu, *rho, *Xc, *W, *b, *lam, *effL;
+    const void *c1, *c2, *c3;
+    const float *mu, *rho, *Xc, *W, *b, *lam, *effL;
     float *partials;
     int64_t ld, row_stride, gb_stride;
     int32_t Nc, Ng, rows_per_chunk, n_rep;
     uint32_t seed_lo, seed_hi, draw0, quad_offset;
+    float pc;
 };
 
-template <int KC, int MODE>
+template <int KC, int MODE, int CS>
 __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
     __shared__ float red[(kWavesPerBlock - 1) * 2 * kGenesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
@@ -561,9 +636,10 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-            const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
-            F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
-            if (MODE == kLikEff3) c3 = ld4(a.c3 + off);
+            CountRegs<CS> cr;
+            load_counts<CS, MODE>(a.c1, a.c2, a.c3, off, cr);
+            F4 c1, c2, c3;
+            decode_counts<CS>(cr, a.pc, c1, c2, c3);
             const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
             float s[kVec];
 #pragma unroll
@@ -619,6 +695,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
     }
 }
 
+#ifdef BRIE_HOST_TU
 // out[j] = sum_c KL - (sum_c LL) / n_rep
 __global__ void loss_gene_reduce(const float *partials, float *out, int64_t ld, int Ng,
                                  int n_chunks, float inv_rep) {
@@ -691,6 +768,53 @@ __global__ void pseudo_count(float *c1, float *c2, int64_t n4, float pc) {
     }
 }
 
+// flag bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255
+__global__ void count_range_check(const float *c, int64_t n4, int *flag) {
+    int bad = 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const F4 a = ld4(c + 4 * i);
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            bad |= !(a.v[v] >= 0.0f && a.v[v] <= 65535.0f && a.v[v] == truncf(a.v[v]));
+            bad |= (a.v[v] > 255.0f) ? 2 : 0;
+        }
+    }
+    if (bad) atomicOr(flag, bad);
+}
+// fp32 layer -> compact layer (same element index; 4 genes per thread)
+__global__ void count_compact(const float *c, void *dst, int64_t n4, int cs) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const F4 a = ld4(c + 4 * i);
+        const uint32_t x0 = static_cast<uint32_t>(a.v[0]), x1 = static_cast<uint32_t>(a.v[1]),
+                       x2 = static_cast<uint32_t>(a.v[2]), x3 = static_cast<uint32_t>(a.v[3]);
+        if (cs == kCountU8) static_cast<uint32_t *>(dst)[i] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+        else static_cast<uint2 *>(dst)[i] = make_uint2(x0 | (x1 << 16), x2 | (x3 << 16));
+    }
+}
+__device__ __forceinline__ float compact_get(const void *p, int64_t i, int v, int cs) {
+    if (cs == kCountU8) return static_cast<float>((static_cast<const uint32_t *>(p)[i] >> (8 * v)) & 0xFFu);
+    const uint2 u = static_cast<const uint2 *>(p)[i];
+    return u16_lane(u, v);
+}
+// inverse, with the pseudo-count rule of the compact storage (apply_pc for the two unique layers)
+__global__ void count_expand(const void *u1, const void *u2, const void *self, float *dst, int64_t n4, float pc,
+                             int apply_pc, int cs) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            const float tot = compact_get(u1, i, v, cs) + compact_get(u2, i, v, cs);
+            float val = compact_get(self, i, v, cs);
+            if (apply_pc && tot > 0.0f) val += pc;
+            o.v[v] = val;
+        }
+        st4(dst + 4 * i, o);
+    }
+}
+
 // effL rows 3..5 = log(rows 0..2)   (tf.math.log(effLen[..., [0,4,5]]), model_TFProb.py:175-176)
 __global__ void log_rows(float *effL, int64_t ld, int Ng) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -726,6 +850,8 @@ __global__ void exp_vec(const float *src, float *dst, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) dst[j] = expf(src[j]);
 }
+
+#endif  // BRIE_HOST_TU
 
 // ----------------------------------------------------------------------------
 // stream_mix: calibration kernel with the step kernel's HBM access mix and no

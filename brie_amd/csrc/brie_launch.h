@@ -1,0 +1,31 @@
+// brie_launch.h -- launch entry points of the two template-heavy kernels.  The (KC, MODE, MC,
+// count-storage) instantiations are split over one translation unit per KC (brie_inst.hip built
+// with -DBRIE_KC=0..8) so that hipcc compiles them in parallel; brie_capi.hip only dispatches.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "brie_kernels.hip.h"
+
+namespace brie {
+
+struct StepPointers {
+    const void *c1, *c2, *c3;                          // fp32 or u8 count layers
+    float *mu, *rho, *m_mu, *v_mu, *m_rho, *v_rho;
+    const float *Xc, *W, *b, *lam, *effL;
+    float *partials;
+};
+
+struct LaunchCfg {
+    int mode;      // kLik2 / kLikEff2 / kLikEff3
+    int cs;        // kCountF32 / kCountU8
+    dim3 grid;
+    hipStream_t stream;
+};
+
+#define BRIE_DECLARE_KC(N)                                                                          \
+    void launch_step_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &);           \
+    void launch_loss_gene_kc##N(const LaunchCfg &, const LossGeneArgs &);
+BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE_DECLARE_KC(4)
+BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)
+#undef BRIE_DECLARE_KC
+
+}  // namespace brie

@@ -141,8 +141,18 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
 /* Tuning knobs of the tiling (0 = library default). */
 int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk);
 
-/* Algorithmic HBM bytes of one elbo_adam_step launch: Nc*Ng*(48 + 4*n_layers). */
+/* Algorithmic HBM bytes of one elbo_adam_step launch: Nc*Ng*(48 + 4*n_layers) (fp32 model of
+ * SURVEY 8d), and the bytes the CURRENT storage moves: Nc*Ng*(48 + {1,2}*n_layers) once integer
+ * counts have been compacted to one / two bytes per element (results are bit-identical either way). */
 int64_t brie_step_algorithmic_bytes(const brie_handle *h);
+int64_t brie_step_storage_bytes(const brie_handle *h);
+
+/* Count-layer storage (the reference densifies to fp32, model_wrap.py:108-111).
+ * mode 0 = auto (default): integer counts in [0,255] are kept as u8, in [0,65535] as u16; the
+ * pseudo-count of model_wrap.py:113-117 is then applied in registers; mode 1 = always fp32.
+ * brie_get_count_storage: 0 = fp32, 1 = u8, 2 = u16 (decided at brie_add_pseudo_count / first step). */
+int brie_set_count_storage(brie_handle *h, int32_t mode);
+int brie_get_count_storage(const brie_handle *h);
 
 /* Measurement utility (no reference counterpart): HBM rate in GB/s of a kernel that only reads
  * `n_read` and writes `n_write` 16-B-vector streams -- (1,1) = copy, (8,6)/(9,6) = the access mix of

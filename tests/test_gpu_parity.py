@@ -220,3 +220,58 @@ def test_large_counts_and_clip(lib):
     psi = sh.read(_capi.PSI)
     assert psi[:, 1::2].min() > 0.99 and psi[:, ::2].max() < 0.01
     np.testing.assert_allclose(z, o.Z_loc, atol=5e-3)
+
+
+@pytest.mark.parametrize("L,Kc,MC", [(2, 1, 1), (3, 2, 3), (2, 0, 2)])
+def test_compact_u8_counts_bit_identical_to_fp32(lib, L, Kc, MC):
+    """Integer counts <= 255 are stored as one byte per element and the pseudo-count of
+    model_wrap.py:113-117 is applied in registers: every result must be bit-identical to the fp32 layers."""
+    from brie_amd import _capi
+    Nc, Ng = 90, 300
+    P = util.problem(Nc, Ng, Kc, L, seed=19)
+    assert max(c.max() for c in P["counts"]) <= 255
+    a = util.device_shard(P, Nc, Ng, Kc, 23)
+    b = util.device_shard(P, Nc, Ng, Kc, 23, storage="f32")
+    tr_a, tr_b = a.step(7, 0.01, MC), b.step(7, 0.01, MC)
+    assert a.count_storage == "u8" and b.count_storage == "f32"
+    assert a.step_storage_bytes() == Nc * Ng * (48 + L) and b.step_storage_bytes() == Nc * Ng * (48 + 4 * L)
+    assert a.step_algorithmic_bytes() == b.step_algorithmic_bytes() == Nc * Ng * (48 + 4 * L)
+    np.testing.assert_array_equal(tr_a, tr_b)
+    sa, sb = util.device_state(a), util.device_state(b)
+    for k in util.STATE_KEYS:
+        np.testing.assert_array_equal(sa[k], sb[k])
+    np.testing.assert_array_equal(a.loss_gene(9), b.loss_gene(9))
+    for l in range(L):                                       # read-back materialises the pseudo-count
+        np.testing.assert_array_equal(a.read(_capi.COUNT1 + l), P["counts_pc"][l])
+        np.testing.assert_array_equal(b.read(_capi.COUNT1 + l), P["counts_pc"][l])
+
+
+def test_count_storage_tiers(lib):
+    """Counts above 255 use u16 (bit-identical to fp32), above 65535 or fractional keep fp32."""
+    from brie_amd import _capi
+    Nc, Ng, Kc = 40, 64, 1
+    P = util.problem(Nc, Ng, Kc, 2, seed=29)
+    big = dict(P, counts=[c.copy() for c in P["counts"]])
+    big["counts"][0][3, 5] = 300.0
+    big["counts"][1][11, 63] = 65535.0
+    huge = dict(P, counts=[c.copy() for c in P["counts"]])
+    huge["counts"][0][3, 5] = 70000.0
+    frac = dict(P, counts=[c.copy() for c in P["counts"]])
+    frac["counts"][1][7, 9] += 0.5
+    for Q, want in ((big, "u16"), (huge, "f32"), (frac, "f32")):
+        Q["counts_pc"] = util.add_pseudo_count(Q["counts"], 0.01)
+        sh = util.device_shard(Q, Nc, Ng, Kc, 31)
+        ref = util.device_shard(Q, Nc, Ng, Kc, 31, storage="f32")
+        o = util.oracle_model(Q, Nc, Ng, Kc, 31, np.float32)
+        tr = sh.step(3, 0.01, 1)
+        assert sh.count_storage == want
+        np.testing.assert_array_equal(tr, ref.step(3, 0.01, 1))
+        np.testing.assert_array_equal(sh.read(_capi.Z_LOC), ref.read(_capi.Z_LOC))
+        np.testing.assert_array_equal(sh.read(_capi.COUNT1), Q["counts_pc"][0])
+        np.testing.assert_allclose(tr, o.minimize(Q["counts_pc"], Q["Xc"], 3, 0.01, 1), rtol=2e-5)
+    # no pseudo-count at all: the decision is taken at the first step
+    sh = util.device_shard(P, Nc, Ng, Kc, 31, pseudo=0)
+    o = util.oracle_model(P, Nc, Ng, Kc, 31, np.float32)
+    tr = sh.step(3, 0.01, 1)
+    assert sh.count_storage == "u8"
+    np.testing.assert_allclose(tr, o.minimize(P["counts"], P["Xc"], 3, 0.01, 1), rtol=2e-5)

@@ -19,12 +19,14 @@ def oracle_model(P, Nc, Ng, Kc, seed, dtype=np.float32, gene_offset=0, intercept
                        gene_offset=gene_offset, intercept=intercept, sigma=sigma)
 
 
-def device_shard(P, Nc, Ng, Kc, seed, gene_offset=0, intercept=None, sigma=None, pseudo=0.01):
+def device_shard(P, Nc, Ng, Kc, seed, gene_offset=0, intercept=None, sigma=None, pseudo=0.01, storage=None):
     from brie_amd import _capi
     L = len(P["counts"])
     sh = _capi.Shard(Nc, Ng, Kc, n_layers=L, has_efflen=P["effLen"] is not None,
                      train_intercept=intercept is None, train_sigma=sigma is None,
                      seed=seed, gene_offset=gene_offset)
+    if storage == "f32":
+        sh.set_count_storage(1)
     for l in range(L):
         sh.upload(_capi.COUNT1 + l, P["counts"][l])
     if pseudo:

@@ -160,7 +160,7 @@ def _gene_slice(x, g0, g1):
 def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_index=[],
             layer_keys=['isoform1', 'isoform2', 'ambiguous'], batch_size=500000,
             pseudo_count=0.01, sigma=None, base_mode='full', tau_prior=[3, 27],
-            seed=0, device=0, emulate_batches=False, comm=None, **keyargs):
+            seed=0, device=0, emulate_batches=False, comm=None, gather_layers=True, **keyargs):
     """Fit a BRIE model from an AnnData-like object (model_wrap.py:202-314).
 
     `adata` needs `.shape`, `.layers`, `.varm`, `.obsm`, `.var`, `.uns`
@@ -220,14 +220,19 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
             ResVal.pval = elbo_gain_pval(ResVal.ELBO_gain)
             ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
 
-    # update adata (model_wrap.py:272-311); matrices cover this rank's gene range
+    # update adata (model_wrap.py:272-311).  Sharded fits: rank 0 receives the full cell x gene layers
+    # (gather_layers=True, one gather per layer at the very end); other ranks keep `<key>_shard`.
     full = (g_lo, g_hi) == (0, Ng)
 
     def put_layer(key, local):
         if full:
             adata.layers[key] = local
-        else:
-            adata.layers[key + '_shard'] = local
+            return
+        adata.layers[key + '_shard'] = local
+        if gather_layers:
+            whole = comm.gather_columns(local, Ng)
+            if whole is not None:
+                adata.layers[key] = whole
     if Xc.shape[0] > 0:
         adata.obsm['Xc'] = Xc
         adata.varm['cell_coeff'] = ResVal.cell_coeff.T

@@ -70,5 +70,24 @@ class GeneComm(object):
                                for r in range(self.world)]) if self.world > 1 else np.arange(Ng)
         return full[:, keep.astype(np.int64)]
 
+    def gather_columns(self, local, Ng, root=0):
+        """Column shards (Nc, n_local) of a cell x gene matrix -> the full (Nc, Ng) matrix on `root`
+        (None elsewhere).  Used once per output layer at the end of a fit; inside the loop nothing moves."""
+        import torch
+        local = np.ascontiguousarray(local, np.float32)
+        per = gene_shard(Ng, 0, self.world)[1]
+        buf = np.zeros((local.shape[0], per), np.float32)
+        buf[:, :local.shape[1]] = local
+        t = self._tensor(buf)
+        out = [torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
+        self.dist.gather(t, out, dst=root, group=self.group)
+        if self.rank != root:
+            return None
+        parts = []
+        for r, o in enumerate(out):
+            g0, g1 = gene_shard(Ng, r, self.world)
+            parts.append(o.cpu().numpy()[:, :g1 - g0])
+        return np.concatenate(parts, axis=1)
+
     def barrier(self):
         self.dist.barrier(group=self.group)

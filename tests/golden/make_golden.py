@@ -71,7 +71,60 @@ def part_b():
         np.savez_compressed(os.path.join(HERE, "oracle_traj_%s.npz" % name), **out)
 
 
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def part_c():
+    """Reference host helpers that import without TF/pysam by file path:
+    brie/utils/preprocessing.py:filter_genes (5-83) and brie/utils/base_utils.py:match (5-59)."""
+    pp = _load("/root/reference/brie/utils/preprocessing.py", "ref_pp")
+    bu = _load("/root/reference/brie/utils/base_utils.py", "ref_bu")
+    rng = np.random.default_rng(7)
+
+    class Stub(object):          # the slice of AnnData filter_genes touches
+        def __init__(self, layers):
+            self.layers = layers
+            self.shape = layers['isoform1'].shape
+            self.n_vars = self.shape[1]
+            self.var = {}
+            self.kept = None
+
+        def copy(self):
+            return Stub({k: v.copy() for k, v in self.layers.items()})
+
+        def _inplace_subset_var(self, mask):
+            self.kept = mask.copy()
+            self.layers = {k: v[:, mask] for k, v in self.layers.items()}
+
+    Nc, Ng = 60, 80
+    depth = rng.lognormal(0, 1.2, Ng)
+    psi = rng.beta(0.4, 0.4, Ng)
+    N = rng.poisson(depth[None, :] * np.ones((Nc, 1)))
+    c1 = rng.binomial(N, psi[None, :])
+    layers = {'isoform1': c1.astype(float), 'isoform2': (N - c1).astype(float),
+              'ambiguous': rng.poisson(0.5 * depth[None, :] * np.ones((Nc, 1))).astype(float)}
+    cases = []
+    for kw in (dict(min_counts=50, min_counts_uniq=10, min_cells_uniq=30, min_MIF_uniq=0.001),
+               dict(min_counts=0, min_cells=5, min_counts_uniq=0, min_cells_uniq=0, min_MIF_uniq=0.05),
+               dict(min_counts=200, min_counts_uniq=100, min_cells_uniq=50, min_MIF_uniq=0.2)):
+        st = Stub({k: v.copy() for k, v in layers.items()})
+        out = pp.filter_genes(st, copy=True, **kw)
+        cases.append(dict(kw=kw, kept=out.kept, n_counts=out.var['n_counts'], n_counts_uniq=out.var['n_counts_uniq']))
+    ref_ids = np.array(["c%03d" % i for i in rng.permutation(50)])
+    new_ids = np.array(["c%03d" % i for i in rng.permutation(70)[:40]])
+    m = bu.match(ref_ids, new_ids)
+    np.savez_compressed(os.path.join(HERE, "ref_filter_match.npz"), isoform1=layers['isoform1'],
+                        isoform2=layers['isoform2'], ambiguous=layers['ambiguous'],
+                        cases=np.array(cases, dtype=object), ref_ids=ref_ids, new_ids=new_ids,
+                        match_idx=np.array([-1 if x is None else x for x in m], dtype=int))
+
+
 if __name__ == "__main__":
     part_a()
     part_b()
+    part_c()
     print("golden fixtures written to", HERE)

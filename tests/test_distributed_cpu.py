@@ -40,6 +40,7 @@ def _worker(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sigma=res.sigma, intercept=res.intercept,
              cell_coeff=res.cell_coeff, loss_gene=res.loss_gene, ELBO_gain=res.ELBO_gain, fdr=res.fdr,
              losses=res.losses, Psi=res.Psi, gene_range=np.array(res.gene_range),
+             Psi_full=ad.layers.get('Psi', np.zeros(0)), has_shard='Psi_shard' in ad.layers,
              red=comm.allreduce_sum(np.array([rank + 1.0, 2.0])))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,3 +72,6 @@ def test_gene_sharded_fit_world2_gloo(tmp_path):
     np.testing.assert_allclose(r0["loss_gene"], ref.loss_gene, rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(r0["losses"], ref.losses, rtol=1e-5)
     np.testing.assert_allclose(np.concatenate([r0["Psi"], r1["Psi"]], axis=1), ref.Psi, atol=2e-6)
+    # rank 0 holds the gathered layer, rank 1 only its shard
+    np.testing.assert_allclose(r0["Psi_full"], ref.Psi, atol=2e-6)
+    assert r1["Psi_full"].size == 0 and bool(r0["has_shard"]) and bool(r1["has_shard"])

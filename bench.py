@@ -223,8 +223,9 @@ def main():
         alg_bytes = sh.step_algorithmic_bytes()
         traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.config)
-            if pmc and world == 1 and args.mc == 1 and pmc.get("count_storage", "f32") == sh.count_storage:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
+                "%s_%s" % (args.config, sh.count_storage))
+            if pmc and world == 1 and args.mc == 1:
                 traffic = pmc["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass

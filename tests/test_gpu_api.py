@@ -93,3 +93,33 @@ def test_fitBRIE_end_to_end_recovers_effects(lib):
     assert np.median(gain[strong]) > 10 * max(1.0, abs(np.median(gain[null])))
     assert ad.var['loss_gene'].shape == (Ng,) and res.losses.shape == (100,)
     assert set(ad.uns['brie_param']) >= {'LRT_index', 'base_mode', 'pseudo_count', 'layer_keys'}
+
+
+def test_cli_quant_end_to_end_on_gpu(lib, tmp_path):
+    """brie-quant front end -> fitBRIE -> HIP kernels -> result files (reference CLI: brie/bin/quant.py)."""
+    import pandas as pd
+    from brie_amd.cli.quant import main
+    from tests.test_cli import _write_brie_npz
+    Nc, Ng = 300, 64
+    P = make_problem(Nc, Ng, Kc=1, L=3, seed=77, depth=10.0, effect_frac=0.4)
+    in_file = str(tmp_path / "counts.npz")
+    cells, genes = _write_brie_npz(in_file, P)
+    cell_file = str(tmp_path / "cells.csv")
+    with open(cell_file, "w") as f:
+        f.write("cellID,group\n" + "".join("%s,%g\n" % (c, x) for c, x in zip(cells, P["Xc"][:, 0])))
+    out = str(tmp_path / "out" / "brie_quant.h5ad")
+    main(["-i", in_file, "-c", cell_file, "-o", out, "--LRTindex=All", "--interceptMode=gene", "--minCount=20",
+          "--minUniqCount=5", "--minCell=10", "--minIter=300", "--maxIter=300", "--MCsize=3", "--seed=5"])
+    df = pd.read_csv(str(tmp_path / "out" / "brie_quant.brie_ident.tsv"), sep="\t", index_col=0)
+    assert {'n_counts', 'cdr', 'intercept', 'sigma', 'group_ceoff', 'group_ELBO_gain', 'group_pval', 'group_FDR'} <= set(df.columns)
+    assert len(df) > 10 and np.all(np.isfinite(df['group_ELBO_gain'])) and df['intercept'].notna().all()
+    bundle = np.load(str(tmp_path / "out" / "brie_quant.npz"), allow_pickle=True)
+    psi = bundle["layers/Psi"]
+    keep = [int(g[4:]) for g in df.index]
+    assert psi.shape == (Nc, len(df)) and psi.min() > 0 and psi.max() < 1
+    covered = (P["counts"][0] + P["counts"][1])[:, keep] > 8
+    assert np.corrcoef(psi[covered], P["Psi_true"][:, keep][covered])[0, 1] > 0.7
+    truth = P["W_true"][0][keep]
+    strong = np.abs(truth) > 0.7
+    if strong.sum() >= 3:
+        assert np.corrcoef(df['group_ceoff'].values[strong], truth[strong])[0, 1] > 0.8

@@ -12,11 +12,12 @@ import numpy as np
 from .build import LIB_PATH
 
 # brie_array ids (include/brie_amd.h)
-COUNT1, COUNT2, COUNT3, XC, EFFLEN = 0, 1, 2, 3, 4
-Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG = 8, 9, 10, 11, 12
+COUNT1, COUNT2, COUNT3, XC, EFFLEN, XG = 0, 1, 2, 3, 4, 5
+Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
 ABI_VERSION = 1
 MAX_KC = 8
+MAX_KG = 4
 
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
@@ -143,7 +144,8 @@ class Shard(object):
     def __init__(self, Nc, Ng, Kc=0, n_layers=2, has_efflen=False, train_intercept=True,
                  train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0):
         self.lib = load_library()
-        self.Nc, self.Ng, self.Kc = int(Nc), int(Ng), int(Kc)
+        self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
+        self.cell_mode = int(intercept_mode) == 1
         p = BrieProblem(ABI_VERSION, int(device), int(Nc), int(Ng), int(gene_offset), int(Kc), int(Kg),
                         int(n_layers), int(bool(has_efflen)), int(intercept_mode),
                         int(bool(train_intercept)), int(bool(train_sigma)), 0, int(seed) & (2 ** 64 - 1))
@@ -192,8 +194,9 @@ class Shard(object):
         return out
 
     def read(self, which):
-        shape = {XC: (self.Nc, self.Kc), WC_LOC: (self.Kc, self.Ng), INTERCEPT: (1, self.Ng),
-                 SIGMA_LOG: (1, self.Ng), SIGMA: (1, self.Ng)}.get(which, (self.Nc, self.Ng))
+        par = (self.Nc, 1) if self.cell_mode else (1, self.Ng)
+        shape = {XC: (self.Nc, self.Kc), WC_LOC: (self.Kc, self.Ng), WG_LOC: (self.Nc, self.Kg), INTERCEPT: par,
+                 SIGMA_LOG: par, SIGMA: par}.get(which, (self.Nc, self.Ng))
         out = np.empty(shape, np.float32)
         if out.size:
             _check(self.lib, self.lib.brie_read(self._h, which, out.ctypes.data_as(ctypes.c_void_p),

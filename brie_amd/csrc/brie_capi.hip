@@ -61,6 +61,15 @@ struct brie_handle {
     float *b = nullptr, *m_b = nullptr, *v_b = nullptr;              // (ld)
     float *lam = nullptr, *m_lam = nullptr, *v_lam = nullptr;        // (ld)
     float *effL = nullptr;          // (6, ld)
+    // coupled modes: gene features (Kg > 0) and/or per-cell intercept / sigma (intercept_mode 'cell')
+    bool coupled = false, cell_mode = false;
+    float *Xg = nullptr;            // (kKgMax, ld) transposed gene features
+    float *Wg = nullptr, *m_Wg = nullptr, *v_Wg = nullptr;           // (Nc, kKgMax)
+    float *cb = nullptr, *m_cb = nullptr, *v_cb = nullptr;           // (Nc)
+    float *clam = nullptr, *m_clam = nullptr, *v_clam = nullptr;     // (Nc)
+    float *row_partials = nullptr;  // (gene_blocks, kRowStats, Nc)
+    float *rowstat = nullptr;       // (kRowStats, Nc)
+    bool have_xg = false;
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
     float *partials = nullptr;
     size_t partials_elems = 0;
@@ -126,17 +135,18 @@ int check_ready(const brie_handle *h) {
         if (!h->have_c[l]) return fail(BRIE_ERR_STATE, "count layer %d not uploaded", l + 1);
     if (h->p.Kc > 0 && !h->have_xc) return fail(BRIE_ERR_STATE, "Xc not uploaded (Kc=%d)", h->p.Kc);
     if (h->p.has_efflen && !h->have_eff) return fail(BRIE_ERR_STATE, "effLen not uploaded");
+    if (h->p.Kg > 0 && !h->have_xg) return fail(BRIE_ERR_STATE, "Xg not uploaded (Kg=%d)", h->p.Kg);
     if (!h->have_state)
         return fail(BRIE_ERR_STATE, "state not initialised: call brie_init_state or upload Z_loc..sigma_log");
     return BRIE_OK;
 }
 
 void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
-                 const brie::StepScalars &a) {
+                 const brie::StepScalars &a, const brie::CoupledArgs &cp) {
     switch (h->p.Kc) {
-#define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a); break;
+#define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a, cp); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
-        default: brie::launch_step_kc8(c, q, a); break;
+        default: brie::launch_step_kc8(c, q, a, cp); break;
 #undef BRIE_CASE
     }
 }
@@ -210,8 +220,15 @@ int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t
         case BRIE_Z_STD_LOG: *dev = h->rho; *rows = Nc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
         case BRIE_XC: *dev = h->Xc; *rows = Nc; *cols = h->p.Kc; *ldd = h->p.Kc; return BRIE_OK;
         case BRIE_WC_LOC: *dev = h->W; *rows = h->p.Kc; *cols = Ng; *ldd = h->ld; return BRIE_OK;
-        case BRIE_INTERCEPT: *dev = h->b; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
-        case BRIE_SIGMA_LOG: *dev = h->lam; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_INTERCEPT:
+            if (h->cell_mode) { *dev = h->cb; *rows = Nc; *cols = 1; *ldd = 1; return BRIE_OK; }
+            *dev = h->b; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_SIGMA_LOG:
+            if (h->cell_mode) { *dev = h->clam; *rows = Nc; *cols = 1; *ldd = 1; return BRIE_OK; }
+            *dev = h->lam; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
+        case BRIE_WG_LOC:
+            if (h->p.Kg == 0) { *dev = nullptr; *rows = Nc; *cols = 0; *ldd = 1; return BRIE_OK; }
+            *dev = h->Wg; *rows = Nc; *cols = h->p.Kg; *ldd = brie::kKgMax; return BRIE_OK;
         default: return fail(BRIE_ERR_INVALID, "array id %d is not a stored matrix", which);
     }
 }
@@ -264,10 +281,13 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
     if (p->Kc < 0 || p->Kc > BRIE_MAX_KC)
         return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC);
-    if (p->Kg != 0)
-        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d: gene-feature prior couples genes (SURVEY 8f-4), not built", p->Kg);
-    if (p->intercept_mode != 0)
-        return fail(BRIE_ERR_UNSUPPORTED, "intercept_mode='cell' couples genes (SURVEY 8f-4), not built");
+    if (p->Kg < 0 || p->Kg > BRIE_MAX_KG)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG);
+    if (p->intercept_mode != 0 && p->intercept_mode != 1)
+        return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
+    if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0)
+        return fail(BRIE_ERR_UNSUPPORTED, "gene features / cell intercepts couple all genes: gene shards (gene_offset=%lld) "
+                    "would need a per-step all-reduce, not built", (long long)p->gene_offset);
     if (p->n_layers != 2 && p->n_layers != 3)
         return fail(BRIE_ERR_INVALID, "n_layers=%d (must be 2 or 3)", p->n_layers);
     if (p->n_layers == 3 && !p->has_efflen)
@@ -308,8 +328,26 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->lam, vec); A(h->m_lam, vec); A(h->v_lam, vec);
     A(h->effL, vec * 6);
     A(h->gene_tmp, vec);
+    h->cell_mode = p->intercept_mode == 1;
+    h->coupled = p->Kg > 0 || h->cell_mode;
+    if (h->coupled) {
+        const size_t nc = static_cast<size_t>(p->Nc);
+        A(h->Xg, vec * brie::kKgMax);
+        A(h->Wg, nc * brie::kKgMax); A(h->m_Wg, nc * brie::kKgMax); A(h->v_Wg, nc * brie::kKgMax);
+        A(h->cb, nc); A(h->m_cb, nc); A(h->v_cb, nc);
+        A(h->clam, nc); A(h->m_clam, nc); A(h->v_clam, nc);
+        A(h->rowstat, nc * brie::kRowStats);
+    }
 #undef A
     configure_tiling(h);
+    if (h->coupled) {
+        float *rp = nullptr;
+        if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * brie::kRowStats * p->Nc, h->stream)) != BRIE_OK) {
+            brie_destroy(h);
+            return rc;
+        }
+        h->row_partials = rp;
+    }
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
     *out = h;
@@ -322,7 +360,8 @@ int brie_destroy(brie_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
-                     h->gene_tmp, h->partials};
+                     h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
+                     h->m_clam, h->v_clam, h->row_partials, h->rowstat};
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
@@ -360,6 +399,21 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
         h->have_eff = true;
+        return BRIE_OK;
+    }
+    if (which == BRIE_XG) {
+        if (rows != h->p.Ng || cols != h->p.Kg)
+            return fail(BRIE_ERR_INVALID, "Xg must be (Ng=%lld, Kg=%d), got (%lld, %lld)", (long long)h->p.Ng, h->p.Kg,
+                        (long long)rows, (long long)cols);
+        if (h->p.Kg == 0) return BRIE_OK;
+        std::vector<float> tmp(static_cast<size_t>(rows) * cols), packed(static_cast<size_t>(brie::kKgMax) * h->ld, 0.0f);
+        HIP_TRY(hipMemcpy2D(tmp.data(), cols * sizeof(float), src, ld * sizeof(float), cols * sizeof(float), rows,
+                            hipMemcpyDefault));
+        for (int64_t j = 0; j < rows; ++j)
+            for (int64_t k = 0; k < cols; ++k) packed[k * h->ld + j] = tmp[j * cols + k];
+        HIP_TRY(hipMemcpyAsync(h->Xg, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->have_xg = true;
         return BRIE_OK;
     }
     if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3 && (h->cs != brie::kCountF32 || h->compact_tried)) {
@@ -429,6 +483,15 @@ int brie_reset_optimizer(brie_handle *h) {
     HIP_TRY(hipMemsetAsync(h->v_b, 0, vec, h->stream));
     HIP_TRY(hipMemsetAsync(h->m_lam, 0, vec, h->stream));
     HIP_TRY(hipMemsetAsync(h->v_lam, 0, vec, h->stream));
+    if (h->coupled) {
+        const size_t nc = static_cast<size_t>(h->p.Nc) * sizeof(float);
+        HIP_TRY(hipMemsetAsync(h->m_Wg, 0, nc * brie::kKgMax, h->stream));
+        HIP_TRY(hipMemsetAsync(h->v_Wg, 0, nc * brie::kKgMax, h->stream));
+        HIP_TRY(hipMemsetAsync(h->m_cb, 0, nc, h->stream));
+        HIP_TRY(hipMemsetAsync(h->v_cb, 0, nc, h->stream));
+        HIP_TRY(hipMemsetAsync(h->m_clam, 0, nc, h->stream));
+        HIP_TRY(hipMemsetAsync(h->v_clam, 0, nc, h->stream));
+    }
     h->t = 0;
     return BRIE_OK;
 }
@@ -454,6 +517,16 @@ int brie_init_state(brie_handle *h, float intercept, float sigma) {
                            intercept);
     const float lam0 = std::isnan(sigma) ? 0.0f : logf(sigma);
     hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Ng)), dim3(256), 0, h->stream, h->lam, static_cast<int64_t>(Ng), lam0);
+    if (h->coupled) {       // per-cell parameters (shapes of model_TFProb.py:53-55)
+        const bool rnd_cb = h->cell_mode && std::isnan(intercept);
+        hipLaunchKernelGGL(brie::init_cell_params, dim3((Nc + 255) / 256), dim3(256), 0, h->stream, h->Wg, h->cb, Nc,
+                           h->p.Kg, rnd_cb ? 1 : 0, slo, shi);
+        if (h->cell_mode && !rnd_cb)
+            hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Nc)), dim3(256), 0, h->stream, h->cb, static_cast<int64_t>(Nc),
+                               intercept);
+        hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Nc)), dim3(256), 0, h->stream, h->clam, static_cast<int64_t>(Nc),
+                           lam0);
+    }
     HIP_TRY(hipGetLastError());
     h->have_state = true;
     return brie_reset_optimizer(h);
@@ -531,25 +604,38 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     a.pc = h->pc;
-    brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream};
+    brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
+    brie::CoupledArgs cp{};
+    cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
+    cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0;
+    brie::CellFinalizeArgs cf{};
+    cf.row_partials = h->row_partials; cf.rowstat = h->rowstat; cf.Wg = h->Wg; cf.m_Wg = h->m_Wg; cf.v_Wg = h->v_Wg;
+    cf.cb = h->cb; cf.m_cb = h->m_cb; cf.v_cb = h->v_cb; cf.clam = h->clam; cf.m_clam = h->m_clam; cf.v_clam = h->v_clam;
+    cf.Nc = static_cast<int32_t>(h->p.Nc); cf.gene_blocks = h->gene_blocks; cf.Kg = h->p.Kg;
+    cf.cell_mode = cp.cell_mode; cf.train_b = h->p.train_intercept; cf.train_lam = h->p.train_sigma; cf.phase = 0;
 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
     f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
-    f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks; f.train_b = h->p.train_intercept; f.train_lam = h->p.train_sigma;
+    f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks;
+    f.train_b = h->cell_mode ? 0 : h->p.train_intercept;        // cell mode: the (1,Ng) vectors are not parameters
+    f.train_lam = h->cell_mode ? 0 : h->p.train_sigma;
 
     for (int i = 0; i < n_steps; ++i) {
         h->t += 1;
         const double tt = static_cast<double>(h->t);
         const float alpha = static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) /
                                                (1.0 - std::pow(0.9, tt)));
-        a.alpha = alpha; f.alpha = alpha;
+        a.alpha = alpha; f.alpha = alpha; cf.alpha = alpha;
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        launch_step(h, cfg, q, a);
+        launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
+        if (h->coupled)
+            hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
+                               dim3(brie::kBlock), 0, h->stream, cf);
     }
     HIP_TRY(hipGetLastError());
     if (loss_trace) {
@@ -581,6 +667,9 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.c2 = u8 ? static_cast<const void *>(h->cu[1]) : h->c[1];
     a.c3 = u8 ? static_cast<const void *>(h->cu[2]) : h->c[2];
     a.pc = h->pc;
+    a.coupled = h->coupled ? 1 : 0;
+    a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;
+    a.cp.Kg = h->p.Kg; a.cp.cell_mode = h->cell_mode ? 1 : 0;
     a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
     a.lam = h->lam; a.effL = h->effL; a.partials = h->partials; a.ld = h->ld;
     a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
@@ -589,7 +678,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     h->draw += static_cast<uint32_t>(n_repeats);
-    launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream}, a);
+    launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
     hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
                        h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));
     HIP_TRY(hipGetLastError());
@@ -620,6 +709,15 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         return BRIE_OK;
     }
     if (which == BRIE_SIGMA) {
+        if (h->cell_mode) {                 // (Nc, 1): exp of the per-cell log sigma, via rowstat as scratch
+            if (rows != Nc || cols != 1) return fail(BRIE_ERR_INVALID, "sigma must be (%lld, 1) in cell mode", (long long)Nc);
+            hipLaunchKernelGGL(brie::exp_vec, dim3((Nc + 255) / 256), dim3(256), 0, h->stream, h->clam, h->rowstat,
+                               static_cast<int>(Nc));
+            HIP_TRY(hipMemcpy2DAsync(dst, ld * sizeof(float), h->rowstat, sizeof(float), sizeof(float), Nc,
+                                     hipMemcpyDefault, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            return BRIE_OK;
+        }
         if (rows != 1 || cols != Ng) return fail(BRIE_ERR_INVALID, "sigma must be (1, %lld)", (long long)Ng);
         hipLaunchKernelGGL(brie::exp_vec, dim3((Ng + 255) / 256), dim3(256), 0, h->stream, h->lam, h->gene_tmp,
                            static_cast<int>(Ng));

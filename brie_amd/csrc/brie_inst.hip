@@ -12,25 +12,28 @@ namespace brie {
 
 namespace {
 
-template <int MODE, int MC, int CS>
-void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
-    hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, MC, CS>), c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3,
-                       q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a);
+template <int MODE, int MC, int CS, bool CPL>
+void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>), c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2,
+                       q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
+                       q.partials, a, cp);
 }
 
 template <int MODE, int CS>
-void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    // coupled modes (gene features / per-cell intercept): one variant with run-time MC_size
+    if (c.coupled) { step_launch<MODE, 0, CS, true>(c, q, a, cp); return; }
     // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
-    if (a.mc == 1) step_launch<MODE, 1, CS>(c, q, a);
-    else if (a.mc == 3) step_launch<MODE, 3, CS>(c, q, a);
-    else step_launch<MODE, 0, CS>(c, q, a);
+    if (a.mc == 1) step_launch<MODE, 1, CS, false>(c, q, a, cp);
+    else if (a.mc == 3) step_launch<MODE, 3, CS, false>(c, q, a, cp);
+    else step_launch<MODE, 0, CS, false>(c, q, a, cp);
 }
 
 template <int MODE>
-void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
-    if (c.cs == kCountU8) step_mc<MODE, kCountU8>(c, q, a);
-    else if (c.cs == kCountU16) step_mc<MODE, kCountU16>(c, q, a);
-    else step_mc<MODE, kCountF32>(c, q, a);
+void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    if (c.cs == kCountU8) step_mc<MODE, kCountU8>(c, q, a, cp);
+    else if (c.cs == kCountU16) step_mc<MODE, kCountU16>(c, q, a, cp);
+    else step_mc<MODE, kCountF32>(c, q, a, cp);
 }
 
 template <int MODE, int CS>
@@ -47,11 +50,12 @@ void lg_cs(const LaunchCfg &c, const LossGeneArgs &a) {
 
 }  // namespace
 
-void BRIE_CAT(launch_step_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+void BRIE_CAT(launch_step_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
+                                       const CoupledArgs &cp) {
     switch (c.mode) {
-        case kLik2: step_cs<kLik2>(c, q, a); break;
-        case kLikEff2: step_cs<kLikEff2>(c, q, a); break;
-        default: step_cs<kLikEff3>(c, q, a); break;
+        case kLik2: step_cs<kLik2>(c, q, a, cp); break;
+        case kLikEff2: step_cs<kLikEff2>(c, q, a, cp); break;
+        default: step_cs<kLikEff3>(c, q, a, cp); break;
     }
 }
 

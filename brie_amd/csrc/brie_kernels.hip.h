@@ -216,6 +216,27 @@ struct StepScalars {
     float pc;                               // pseudo-count applied on the fly to compact (u8) counts
 };
 
+// Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
+// and/or intercept_mode='cell' (per-cell intercept and sigma, model_TFProb.py:53-55).  Per-cell
+// parameters need sums over genes: each wave reduces its 256 genes and writes one value per
+// (gene block, statistic, cell); cell_finalize sums the gene blocks and applies Adam.
+constexpr int kKgMax = 4;                   // gene features supported
+constexpr int kRowStats = kKgMax + 2;       // sum_j r*Xg_k (k<4), sum_j r, sum_j (1 - d r - s^2/sigma^2)
+struct CoupledArgs {
+    const float *Xg;        // (kKgMax, ld) gene features, transposed, zero rows beyond Kg
+    const float *Wg;        // (Nc, kKgMax) per-cell weights, zero columns beyond Kg
+    const float *cb, *clam; // (Nc) per-cell intercept / log sigma (cell mode)
+    float *row_partials;    // (gene_blocks, kRowStats, Nc)
+    int32_t Kg, cell_mode;
+};
+struct RowScalars { float wg[kKgMax], cb, clam; };
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
 // Count storage.  kCountF32: the uploaded fp32 layers (pseudo-count already applied in place).
 // kCountU8: when every count is an integer in [0, 255] the layers are kept as one byte per element
 // (4 genes = one dword per lane) and model_wrap.py:113-117's pseudo-count is applied in registers;
@@ -302,14 +323,14 @@ constexpr float kAdamEps = 1e-7f;
 // one straight-line basic block, which is what lets the next row's loads stay
 // in flight across it); MC == 0: run-time count a.mc.
 // ----------------------------------------------------------------------------
-template <int KC, int MODE, int MC, int CS>
+template <int KC, int MODE, int MC, int CS, bool CPL>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
-    const StepScalars a) {
+    const StepScalars a, const CoupledArgs cp) {
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
@@ -328,10 +349,21 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
         for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
 
-    if (active && row0 + w < row_end) {
+    // coupled variant: every lane runs (the wave reduces over its 256 genes); lanes beyond Ng work on
+    // the zero padding of the gene block, contribute nothing and store nothing
+    if ((CPL || active) && row0 + w < row_end) {
         // per-gene parameters, live across the whole chunk
         float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+        float Xgk[CPL ? kKgMax : 1][kVec];
+        if constexpr (CPL) {
+#pragma unroll
+            for (int k = 0; k < kKgMax; ++k) {
+                const F4 t = ld4(cp.Xg + k * a.ld + j0);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) Xgk[k][v] = t.v[v];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             const F4 t = ld4(Wp + k * a.ld + j0);
@@ -363,8 +395,14 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
 
-        auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX]) {
+        auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX], RowScalars &rs) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            if constexpr (CPL) {
+#pragma unroll
+                for (int k = 0; k < kKgMax; ++k) rs.wg[k] = cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                rs.cb = cp.cb[r];
+                rs.clam = cp.clam[r];
+            }
             load_counts<CS, MODE>(c1p, c2p, c3p, off, R.cnt);
             R.mu = ld4s(mu_p + off);
             R.rho = ld4s(rho_p + off);
@@ -376,8 +414,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
         };
 
-        auto process_row = [&](int r, RowRegs<CS> &R, const float (&xc)[KCX]) {
+        auto process_row = [&](int r, RowRegs<CS> &R, const float (&xc)[KCX], const RowScalars &rs) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            const bool cell = CPL && cp.cell_mode != 0;
+            const float row_isig2 = CPL ? f_exp(-2.0f * rs.clam) : 0.0f;
+            float rstat[CPL ? kRowStats : 1] = {};
             F4 c1, c2, c3;
             decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
             float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
@@ -407,14 +448,25 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             }
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
-                float m = bj[v];
+                float m = cell ? rs.cb : bj[v];
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
+                if constexpr (CPL) {
+#pragma unroll
+                    for (int k = 0; k < kKgMax; ++k) m = fmaf(rs.wg[k], Xgk[k][v], m);   // + Wg_loc . Xg^T
+                }
+                const float is2 = cell ? row_isig2 : isig2[v];
                 const float d = R.mu.v[v] - m;
-                const float rr = d * isig2[v];                                     // (mu - m) / sigma^2
-                const float s2r = s[v] * s[v] * isig2[v];                          // s^2 / sigma^2
-                const float dl = R.rho.v[v] - lamj[v];
+                const float rr = d * is2;                                          // (mu - m) / sigma^2
+                const float s2r = s[v] * s[v] * is2;                               // s^2 / sigma^2
+                const float dl = R.rho.v[v] - (cell ? rs.clam : lamj[v]);
                 const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;         // KL(q || prior)
+                if constexpr (CPL) {
+#pragma unroll
+                    for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rr, Xgk[k][v], rstat[k]);
+                    rstat[kKgMax] += rr;
+                    rstat[kKgMax + 1] += 1.0f - d * rr - s2r;
+                }
                 const float g_mu = rr - gbar[v] * a.inv_mc;
                 const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
                 // Keras Adam
@@ -434,19 +486,30 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 acc[KC + 2][v] += kl;
                 acc[KC + 3][v] += ll[v] * a.inv_mc;
             }
-            st4s(mu_p + off, R.mu);
-            st4s(rho_p + off, R.rho);
-            st4s(mmu_p + off, R.mm);
-            st4s(vmu_p + off, R.vm);
-            st4s(mrho_p + off, R.mr);
-            st4s(vrho_p + off, R.vr);
+            if (!CPL || active) {
+                st4s(mu_p + off, R.mu);
+                st4s(rho_p + off, R.rho);
+                st4s(mmu_p + off, R.mm);
+                st4s(vmu_p + off, R.vm);
+                st4s(mrho_p + off, R.mr);
+                st4s(vrho_p + off, R.vr);
+            }
+            if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
+#pragma unroll
+                for (int q = 0; q < kRowStats; ++q) {
+                    const float t = wave_sum(active ? rstat[q] : 0.0f);
+                    if (lane == 0)
+                        cp.row_partials[(static_cast<int64_t>(blockIdx.x) * kRowStats + q) * a.Nc + r] = t;
+                }
+            }
         };
 
         int r = row0 + w;
         const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
         RowRegs<CS> cur;
         float xc[KCX];
-        load_row(r, cur, xc);
+        RowScalars rsc{};
+        load_row(r, cur, xc, rsc);
 #if BRIE_PREFETCH
         // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
         // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
@@ -455,20 +518,22 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         while (r < r_last) {
             RowRegs<CS> nxt;
             float xn[KCX];
-            load_row(r + kWavesPerBlock, nxt, xn);
-            process_row(r, cur, xc);
+            RowScalars rsn{};
+            load_row(r + kWavesPerBlock, nxt, xn, rsn);
+            process_row(r, cur, xc, rsc);
             cur = nxt;
+            rsc = rsn;
 #pragma unroll
             for (int k = 0; k < KC; ++k) xc[k] = xn[k];
             r += kWavesPerBlock;
         }
-        process_row(r, cur, xc);
+        process_row(r, cur, xc, rsc);
 #else
         for (;;) {
-            process_row(r, cur, xc);
+            process_row(r, cur, xc, rsc);
             if (r >= r_last) break;
             r += kWavesPerBlock;
-            load_row(r, cur, xc);
+            load_row(r, cur, xc, rsc);
         }
 #endif
     }
@@ -589,6 +654,8 @@ struct LossGeneArgs {
     int32_t Nc, Ng, rows_per_chunk, n_rep;
     uint32_t seed_lo, seed_hi, draw0, quad_offset;
     float pc;
+    int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
+    CoupledArgs cp;
 };
 
 template <int KC, int MODE, int CS>
@@ -632,10 +699,28 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
 #pragma unroll
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
+        float Xgk[kKgMax][kVec] = {};
+        if (a.coupled) {
+#pragma unroll
+            for (int k = 0; k < kKgMax; ++k) {
+                const F4 t = ld4(a.cp.Xg + k * a.ld + j0);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) Xgk[k][v] = t.v[v];
+            }
+        }
+        const bool cell = a.coupled && a.cp.cell_mode != 0;
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            float wg[kKgMax] = {0.f, 0.f, 0.f, 0.f}, cbr = 0.f, clamr = 0.f;
+            if (a.coupled) {
+#pragma unroll
+                for (int k = 0; k < kKgMax; ++k) wg[k] = a.cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                cbr = a.cp.cb[r];
+                clamr = a.cp.clam[r];
+            }
+            const float row_isig2 = f_exp(-2.0f * clamr);
             CountRegs<CS> cr;
             load_counts<CS, MODE>(a.c1, a.c2, a.c3, off, cr);
             F4 c1, c2, c3;
@@ -645,12 +730,15 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 s[v] = f_exp(rho.v[v]);
-                float m = bj[v];
+                float m = cell ? cbr : bj[v];
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(a.Xc[static_cast<int64_t>(r) * KC + k], Wk[k][v], m);
+#pragma unroll
+                for (int k = 0; k < kKgMax; ++k) m = fmaf(wg[k], Xgk[k][v], m);
+                const float is2 = cell ? row_isig2 : isig2[v];
                 const float d = mu.v[v] - m;
-                const float s2r = s[v] * s[v] * isig2[v];
-                akl[v] += 0.5f * d * d * isig2[v] + 0.5f * (s2r - 1.0f) - (rho.v[v] - lamj[v]);
+                const float s2r = s[v] * s[v] * is2;
+                akl[v] += 0.5f * d * d * is2 + 0.5f * (s2r - 1.0f) - (rho.v[v] - (cell ? clamr : lamj[v]));
             }
             float lsum[kVec] = {0.f, 0.f, 0.f, 0.f};
             for (int rep = 0; rep < a.n_rep; ++rep) {
@@ -696,6 +784,55 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
 }
 
 #ifdef BRIE_HOST_TU
+// cell_finalize: per cell, sum the gene blocks' row partials (fp64) and apply Adam to Wg_loc
+// (model_TFProb.py:85,124-125) and, in cell mode, to the per-cell intercept (clip) and sigma_log.
+// `rowstat` (kRowStats, Nc) receives the reduced statistics (the buffer a multi-GPU run all-reduces).
+struct CellFinalizeArgs {
+    const float *row_partials;  // (gene_blocks, kRowStats, Nc)
+    float *rowstat;             // (kRowStats, Nc)
+    float *Wg, *m_Wg, *v_Wg;    // (Nc, kKgMax)
+    float *cb, *m_cb, *v_cb;    // (Nc)
+    float *clam, *m_clam, *v_clam;
+    int32_t Nc, gene_blocks, Kg, cell_mode, train_b, train_lam;
+    int32_t phase;              // 0: reduce + Adam; 1: reduce only; 2: Adam only (rowstat given)
+    float alpha;
+};
+__global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int q = blockIdx.y;                       // statistic
+    if (i >= a.Nc) return;
+    float t;
+    if (a.phase != 2) {
+        double acc = 0.0;
+        for (int g = 0; g < a.gene_blocks; ++g)
+            acc += static_cast<double>(a.row_partials[(static_cast<int64_t>(g) * kRowStats + q) * a.Nc + i]);
+        t = static_cast<float>(acc);
+        a.rowstat[static_cast<int64_t>(q) * a.Nc + i] = t;
+        if (a.phase == 1) return;
+    } else {
+        t = a.rowstat[static_cast<int64_t>(q) * a.Nc + i];
+    }
+    if (q < kKgMax) {
+        if (q < a.Kg) {
+            const int64_t o = static_cast<int64_t>(i) * kKgMax + q;
+            float x = a.Wg[o], m = a.m_Wg[o], v = a.v_Wg[o];
+            adam_scalar(x, m, v, -t, a.alpha);                                  // dL/dWg = -r . Xg
+            a.Wg[o] = x; a.m_Wg[o] = m; a.v_Wg[o] = v;
+        }
+    } else if (q == kKgMax) {
+        if (a.cell_mode && a.train_b) {
+            float x = a.cb[i], m = a.m_cb[i], v = a.v_cb[i];
+            adam_scalar(x, m, v, -t, a.alpha);
+            x = fminf(fmaxf(x, -9.0f), 9.0f);
+            a.cb[i] = x; a.m_cb[i] = m; a.v_cb[i] = v;
+        }
+    } else if (a.cell_mode && a.train_lam) {
+        float x = a.clam[i], m = a.m_clam[i], v = a.v_clam[i];
+        adam_scalar(x, m, v, t, a.alpha);
+        a.clam[i] = x; a.m_clam[i] = m; a.v_clam[i] = v;
+    }
+}
+
 // out[j] = sum_c KL - (sum_c LL) / n_rep
 __global__ void loss_gene_reduce(const float *partials, float *out, int64_t ld, int Ng,
                                  int n_chunks, float inv_rep) {
@@ -746,6 +883,21 @@ __global__ void init_gene_rows(float *dst, int64_t ld, int rows, int Ng, uint32_
         for (int v = 0; v < kVec; ++v)
             if (q * kVec + v >= Ng) e.v[v] = 0.0f;
         st4(dst + static_cast<int64_t>(r) * ld + q * kVec, e);
+    }
+}
+
+// per-cell initial state (gene index NOT offset by the shard: identical on every rank):
+//   Wg_loc[i, k] = eps(kInitDraw, 4, cell i, gene k)  (k < Kg <= 4 = one Philox call), zero beyond Kg
+//   cell-mode intercept[i] = eps(kInitDraw, 3, cell i, gene 0)
+__global__ void init_cell_params(float *Wg, float *cb, int Nc, int Kg, int init_cb, uint32_t seed_lo, uint32_t seed_hi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nc) return;
+    float e[kVec];
+    normal4(0u, static_cast<uint32_t>(i), kInitDraw, 4u, seed_lo, seed_hi, e);
+    for (int k = 0; k < kKgMax; ++k) Wg[static_cast<int64_t>(i) * kKgMax + k] = k < Kg ? e[k] : 0.0f;
+    if (init_cb) {
+        normal4(0u, static_cast<uint32_t>(i), kInitDraw, 3u, seed_lo, seed_hi, e);
+        cb[i] = e[0];
     }
 }
 

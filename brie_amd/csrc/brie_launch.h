@@ -16,13 +16,15 @@ struct StepPointers {
 
 struct LaunchCfg {
     int mode;      // kLik2 / kLikEff2 / kLikEff3
-    int cs;        // kCountF32 / kCountU8
+    int cs;        // kCountF32 / kCountU8 / kCountU16
     dim3 grid;
     hipStream_t stream;
+    int coupled;   // 1: gene features and/or per-cell intercept (CoupledArgs valid)
 };
 
 #define BRIE_DECLARE_KC(N)                                                                          \
-    void launch_step_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &);           \
+    void launch_step_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &,           \
+                           const CoupledArgs &);                                                    \
     void launch_loss_gene_kc##N(const LaunchCfg &, const LossGeneArgs &);
 BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE_DECLARE_KC(4)
 BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)

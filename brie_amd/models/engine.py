@@ -12,8 +12,8 @@ Deviations from the reference (documented in DESIGN.md):
  * all genes of a shard are fitted concurrently (the reference loops over
    ~`batch_size/Nc`-gene batches); convergence is decided on the shard's summed
    loss trace;
- * `Kg > 0`, `intercept_mode='cell'` and `target='marginLik'` couple genes and
-   raise NotImplementedError.
+ * gene features (`Kg <= 4`) and `intercept_mode='cell'` couple the genes of a fit: supported on one
+   GPU (no gene sharding); `target='marginLik'` raises NotImplementedError.
 """
 import time
 
@@ -66,15 +66,16 @@ class BRIE2(object):
         self._shard = None
         self._n_layers = None
         self._pseudo_count = None
-        if self.Kg != 0:
-            raise NotImplementedError("Kg > 0 couples genes (SURVEY.md 8f-4): not built")
-        if str(intercept_mode).upper() == 'CELL':
-            raise NotImplementedError("intercept_mode='cell' couples genes (SURVEY.md 8f-4): not built")
+        self._cell_mode = str(intercept_mode).upper() == 'CELL'          # model_TFProb.py:53-60
+        if self.Kg > _capi.MAX_KG:
+            raise NotImplementedError("Kg=%d > %d" % (self.Kg, _capi.MAX_KG))
         if self.Kc > _capi.MAX_KC:
             raise NotImplementedError("Kc=%d > %d" % (self.Kc, _capi.MAX_KC))
+        if (self.Kg > 0 or self._cell_mode) and self.gene_offset != 0:
+            raise NotImplementedError("gene features / cell intercepts couple all genes: no gene sharding")
 
     # ------------------------------------------------------------------ device state
-    def _ensure_shard(self, count_layers, Xc):
+    def _ensure_shard(self, count_layers, Xc, Xg=None):
         n_layers = len(count_layers)
         if self.effLen is None:
             n_layers = 2                          # third layer unused without effLen (model_TFProb.py:162-167)
@@ -82,7 +83,8 @@ class BRIE2(object):
             return self._shard
         sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
                          train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
-                         seed=self.seed, device=self.device, gene_offset=self.gene_offset)
+                         seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
+                         intercept_mode=1 if self._cell_mode else 0)
         for l in range(n_layers):
             sh.upload(_capi.COUNT1 + l, _dense_f32(count_layers[l]))
         if self._pseudo_count:
@@ -93,6 +95,11 @@ class BRIE2(object):
             if Xc is None:
                 raise ValueError("Kc=%d but Xc is None" % self.Kc)
             sh.upload(_capi.XC, np.ascontiguousarray(Xc, dtype=np.float32))
+        if self.Kg > 0:
+            if Xg is None:
+                raise ValueError("Kg=%d but Xg is None" % self.Kg)
+            sh.upload(_capi.XG, np.ascontiguousarray(Xg, dtype=np.float32))
+        par = (self.Nc, 1) if self._cell_mode else (1, self.Ng)
         io = self._init_obj
         if io is None:
             sh.init_state(self._intercept_value, self._sigma_value)       # Model_init, model_TFProb.py:12-31
@@ -106,11 +113,13 @@ class BRIE2(object):
                 sh.upload(_capi.Z_STD_LOG, np.log(np.asarray(get('Z_std'), np.float32)))
             if self.Kc > 0:
                 sh.upload(_capi.WC_LOC, np.asarray(get('Wc_loc'), np.float32).reshape(self.Kc, self.Ng))
-            sh.upload(_capi.INTERCEPT, np.asarray(get('intercept'), np.float32).reshape(1, self.Ng))
+            if self.Kg > 0:
+                sh.upload(_capi.WG_LOC, np.asarray(get('Wg_loc'), np.float32).reshape(self.Nc, self.Kg))
+            sh.upload(_capi.INTERCEPT, np.asarray(get('intercept'), np.float32).reshape(par))
             if isinstance(io, dict) and 'sigma_log' in io:
-                sh.upload(_capi.SIGMA_LOG, np.asarray(io['sigma_log'], np.float32).reshape(1, self.Ng))
+                sh.upload(_capi.SIGMA_LOG, np.asarray(io['sigma_log'], np.float32).reshape(par))
             else:
-                sh.upload(_capi.SIGMA_LOG, np.log(np.asarray(get('sigma'), np.float32)).reshape(1, self.Ng))
+                sh.upload(_capi.SIGMA_LOG, np.log(np.asarray(get('sigma'), np.float32)).reshape(par))
         self._shard, self._n_layers = sh, n_layers
         return sh
 
@@ -160,7 +169,7 @@ class BRIE2(object):
 
     @property
     def Wg_loc(self):
-        return _wrap(np.zeros((self.Nc, 0), np.float32))
+        return _wrap(self._need().read(_capi.WG_LOC))
 
     # ------------------------------------------------------------------ loss (model_TFProb.py:194-211)
     def get_loss(self, count_layers, target="ELBO", axis=None, **kwargs):
@@ -170,7 +179,7 @@ class BRIE2(object):
         """
         if target != "ELBO":
             raise NotImplementedError("target='marginLik' (SURVEY.md 8f-4): not built")
-        sh = self._ensure_shard(count_layers, self.Xc)
+        sh = self._ensure_shard(count_layers, self.Xc, self.Xg)
         mc = int(kwargs.get("MC_size", 1))
         if mc != 1:
             raise NotImplementedError("get_loss outside fit supports MC_size=1")
@@ -198,7 +207,7 @@ class BRIE2(object):
             raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
         self.Xc, self.Xg, self.target = Xc, Xg, target
         self._pseudo_count = pseudo_count
-        sh = self._ensure_shard(count_layers, Xc)
+        sh = self._ensure_shard(count_layers, Xc, Xg)
 
         def run(n_steps, lr):
             trace = sh.step(n_steps, lr, MC_size)

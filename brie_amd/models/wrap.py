@@ -105,9 +105,9 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     else:
         Xc_base = np.ones((Nc, 0), np.float32)
 
-    def run(Xc_fit, fit_seed):
+    def run(Xc_fit, fit_seed, mode=intercept_mode):
         mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=Xc_fit.shape[1], Kg=Xg.shape[1], effLen=effLen,
-                    intercept=intercept, intercept_mode=intercept_mode, sigma=sigma,
+                    intercept=intercept, intercept_mode=mode, sigma=sigma,
                     tau_prior=tau_prior, seed=fit_seed, device=device, gene_offset=gene_offset)
         mdl.fit(data, Xc=Xc_fit, Xg=Xg, pseudo_count=pseudo_count, **keyargs)
         return mdl
@@ -132,7 +132,9 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
             if verbosity == 3:
                 print("[BRIE2] fitting test model by add feature %d" % (idx))
             Xc_test = np.append(Xc_base, Xc[:, idx:(idx + 1)], axis=1)
-        model_test = run(Xc_test, seed + 1 + ii)
+        # the reference builds the test models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always
+        # with the 'gene' default, whatever the base model uses -- mirrored
+        model_test = run(Xc_test, seed + 1 + ii, mode='gene')
         test_loss_gene = _np(model_test.loss_gene)
         if base_mode.upper() == 'FULL':
             ELBO_gain[:, ii] = test_loss_gene - brie_results.loss_gene

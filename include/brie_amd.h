@@ -51,17 +51,19 @@ typedef enum brie_array {
     BRIE_COUNT3 = 2,      /* (Nc, Ng) ambiguous            -- count_layers[2], model_TFProb.py:184-185 */
     BRIE_XC = 3,          /* (Nc, Kc) cell features        -- model_TFProb.py:220 */
     BRIE_EFFLEN = 4,      /* (Ng, 6) effective lengths     -- model_TFProb.py:49,175-176 */
+    BRIE_XG = 5,          /* (Ng, Kg) gene features        -- model_TFProb.py:221,124-125 */
     /* state (upload = warm start / init_obj hook model_TFProb.py:45,62-65; read) */
     BRIE_Z_LOC = 8,       /* (Nc, Ng)  model_TFProb.py:80 */
     BRIE_Z_STD_LOG = 9,   /* (Nc, Ng)  model_TFProb.py:82 */
     BRIE_WC_LOC = 10,     /* (Kc, Ng)  model_TFProb.py:84 */
-    BRIE_INTERCEPT = 11,  /* (1, Ng)   model_TFProb.py:67-71 */
-    BRIE_SIGMA_LOG = 12,  /* (1, Ng)   model_TFProb.py:73-78 */
+    BRIE_INTERCEPT = 11,  /* (1, Ng), or (Nc, 1) in cell mode   model_TFProb.py:53-60,67-71 */
+    BRIE_SIGMA_LOG = 12,  /* (1, Ng), or (Nc, 1) in cell mode   model_TFProb.py:73-78 */
+    BRIE_WG_LOC = 13,     /* (Nc, Kg)  model_TFProb.py:85 */
     /* derived (read only) */
     BRIE_PSI = 16,        /* (Nc, Ng) sigmoid(Z_loc)              model_TFProb.py:92-95 */
     BRIE_Z_STD = 17,      /* (Nc, Ng) exp(Z_std_log)              model_TFProb.py:88-90 */
     BRIE_PSI95CI = 18,    /* (Nc, Ng) q(.975)-q(.025) logit-normal model_TFProb.py:102-106 */
-    BRIE_SIGMA = 19       /* (1, Ng)  exp(sigma_log)              model_TFProb.py:108-111 */
+    BRIE_SIGMA = 19       /* (1, Ng) / (Nc, 1)  exp(sigma_log)    model_TFProb.py:108-111 */
 } brie_array;
 
 /* Problem description == the constructor arguments of BRIE2
@@ -74,11 +76,11 @@ typedef struct brie_problem {
     int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
                                  keys the noise stream so results do not depend on sharding */
     int32_t Kc;               /* cell features (0..BRIE_MAX_KC) */
-    int32_t Kg;               /* gene features: must be 0 (coupled mode) */
+    int32_t Kg;               /* gene features (0..BRIE_MAX_KG); > 0 couples the genes of a shard */
     int32_t n_layers;         /* 2 or 3 count layers */
     int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
                                  1: effLen likelihood (model_TFProb.py:168-185) */
-    int32_t intercept_mode;   /* 0 = 'gene' (1,Ng); 1 = 'cell' -> BRIE_ERR_UNSUPPORTED */
+    int32_t intercept_mode;   /* 0 = 'gene' (1,Ng) intercept and sigma; 1 = 'cell' (Nc,1) (model_TFProb.py:53-60) */
     int32_t train_intercept;  /* 1: intercept is a variable clipped to [-9,9] (model_TFProb.py:67-69) */
     int32_t train_sigma;      /* 1: sigma_log is a variable (model_TFProb.py:73-75) */
     int32_t reserved;
@@ -86,6 +88,7 @@ typedef struct brie_problem {
 } brie_problem;
 
 #define BRIE_MAX_KC 8
+#define BRIE_MAX_KG 4
 
 typedef struct brie_handle brie_handle;
 

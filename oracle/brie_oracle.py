@@ -48,11 +48,14 @@ class AdamSlot(object):
 
 
 class OracleBRIE2(object):
-    """Restatement of `BRIE2` (ref:35-273), gene intercept mode, Kg = 0."""
+    """Restatement of `BRIE2` (ref:35-273): gene or cell intercept mode, cell and gene features."""
 
     def __init__(self, Nc, Ng, Kc=0, effLen=None, intercept=None, sigma=None,
-                 seed=0, gene_offset=0, dtype=np.float32, init=None):
-        self.Nc, self.Ng, self.Kc = int(Nc), int(Ng), int(Kc)
+                 seed=0, gene_offset=0, dtype=np.float32, init=None, Kg=0, intercept_mode='gene'):
+        self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
+        self.cell_mode = str(intercept_mode).upper() == 'CELL'          # ref:53-60
+        self.par_shape = (self.Nc, 1) if self.cell_mode else (1, self.Ng)
+        self.Xg = None
         self.dtype = np.dtype(dtype)
         self.seed, self.gene_offset = int(seed), int(gene_offset)
         self.effLen = None if effLen is None else np.asarray(effLen, np.float64)
@@ -65,8 +68,9 @@ class OracleBRIE2(object):
         self.Z_loc = np.array(init['Z_loc'], dt)                    # ref:80
         self.Z_std_log = np.array(init['Z_std_log'], dt)            # ref:82 (log of Z_std)
         self.Wc_loc = np.array(init['Wc_loc'], dt).reshape(self.Kc, self.Ng)    # ref:84
-        self.intercept = np.array(init['intercept'], dt).reshape(1, self.Ng)    # ref:67-71
-        self.sigma_log = np.array(init['sigma_log'], dt).reshape(1, self.Ng)    # ref:73-78
+        self.Wg_loc = np.array(init.get('Wg_loc', np.zeros((self.Nc, self.Kg))), dt).reshape(self.Nc, self.Kg)   # ref:85
+        self.intercept = np.array(init['intercept'], dt).reshape(self.par_shape)    # ref:67-71
+        self.sigma_log = np.array(init['sigma_log'], dt).reshape(self.par_shape)    # ref:73-78
         self.reset_optimizer()
 
     # ------------------------------------------------------------------ init
@@ -74,23 +78,28 @@ class OracleBRIE2(object):
         """`Model_init` (ref:12-31) with the unseeded tf.random.normal replaced by
         the shared Philox stream at draw id INIT_DRAW:
         k=0 Z_loc, k=1 log Z_std (Z_std = exp(N(0,1)), ref:28), k=2 Wc_loc rows
-        (cell index = feature index), k=3 intercept (cell index 0)."""
+        (cell index = feature index), k=3 intercept (gene mode: cell index 0; cell mode: gene index 0),
+        k=4 Wg_loc (gene index = feature index, never offset by the shard)."""
         Nc, Ng, Kc, go = self.Nc, self.Ng, self.Kc, self.gene_offset
         D = philox.INIT_DRAW
+        shp = self.par_shape
         out = {
             'Z_loc': philox.normal(self.seed, D, 0, Nc, Ng, go),
             'Z_std_log': philox.normal(self.seed, D, 1, Nc, Ng, go),
             'Wc_loc': philox.normal(self.seed, D, 2, Kc, Ng, go) if Kc > 0
             else np.zeros((0, Ng), np.float32),
         }
-        if intercept is None:
-            out['intercept'] = philox.normal(self.seed, D, 3, 1, Ng, go)          # ref:17-18
+        out['Wg_loc'] = philox.normal(self.seed, D, 4, Nc, self.Kg, 0) if self.Kg > 0 \
+            else np.zeros((Nc, 0), np.float32)                                    # ref:31
+        if intercept is None:                                                     # ref:17-18
+            out['intercept'] = philox.normal(self.seed, D, 3, Nc, 1, 0) if self.cell_mode \
+                else philox.normal(self.seed, D, 3, 1, Ng, go)
         else:
-            out['intercept'] = np.ones((1, Ng), np.float32) * np.float32(intercept)   # ref:20
+            out['intercept'] = np.ones(shp, np.float32) * np.float32(intercept)   # ref:20
         if sigma is None:
-            out['sigma_log'] = np.zeros((1, Ng), np.float32)                      # log(ones), ref:23,74
+            out['sigma_log'] = np.zeros(shp, np.float32)                          # log(ones), ref:23,74
         else:
-            out['sigma_log'] = np.log(np.ones((1, Ng), np.float32) * np.float32(sigma))   # ref:25,77
+            out['sigma_log'] = np.log(np.ones(shp, np.float32) * np.float32(sigma))   # ref:25,77
         return out
 
     def reset_optimizer(self):
@@ -98,7 +107,7 @@ class OracleBRIE2(object):
         dt = self.dtype
         self.t = 0
         self.slots = {n: AdamSlot(getattr(self, n).shape, dt)
-                      for n in ('Z_loc', 'Z_std_log', 'Wc_loc', 'intercept', 'sigma_log')}
+                      for n in ('Z_loc', 'Z_std_log', 'Wc_loc', 'Wg_loc', 'intercept', 'sigma_log')}
 
     # ------------------------------------------------------------ properties
     @property
@@ -119,10 +128,12 @@ class OracleBRIE2(object):
         return sigmoid(self.Z_loc + self.dtype.type(Z975) * s) - \
             sigmoid(self.Z_loc - self.dtype.type(Z975) * s)
 
-    def prior_mean(self, Xc):   # ref:118-127 (Kg = 0)
+    def prior_mean(self, Xc):   # ref:118-127
         m = np.zeros((self.Nc, self.Ng), self.dtype)
         if self.Kc > 0 and Xc is not None:
             m = np.matmul(np.asarray(Xc, self.dtype), self.Wc_loc)
+        if self.Kg > 0 and self.Xg is not None:
+            m = m + np.matmul(self.Wg_loc, np.asarray(self.Xg, self.dtype).T)
         return m + self.intercept
 
     # ------------------------------------------------------------- noise
@@ -206,8 +217,11 @@ class OracleBRIE2(object):
         out['Z_std_log'] = s2 - 1 - gse
         if self.Kc > 0:
             out['Wc_loc'] = -np.matmul(np.asarray(Xc, dt).T, r)
-        out['intercept'] = -r.sum(axis=0, keepdims=True)
-        out['sigma_log'] = (1 - d * d * inv_sig2 - s2).sum(axis=0, keepdims=True)
+        if self.Kg > 0:
+            out['Wg_loc'] = -np.matmul(r, np.asarray(self.Xg, dt))
+        ax = 1 if self.cell_mode else 0                     # (Nc,1) parameters sum over genes, (1,Ng) over cells
+        out['intercept'] = -r.sum(axis=ax, keepdims=True)
+        out['sigma_log'] = (1 - d * d * inv_sig2 - s2).sum(axis=ax, keepdims=True)
         return out
 
     # ------------------------------------------------------------- Adam
@@ -215,6 +229,8 @@ class OracleBRIE2(object):
         names = ['Z_loc', 'Z_std_log']
         if self.Kc > 0:
             names.append('Wc_loc')
+        if self.Kg > 0:
+            names.append('Wg_loc')
         if self.train_intercept:
             names.append('intercept')
         if self.train_sigma:
@@ -249,9 +265,11 @@ class OracleBRIE2(object):
 
     # ------------------------------------------------------------- fit
     def fit(self, counts, Xc=None, min_iter=1000, max_iter=5000, add_iter=500,
-            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500):
+            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500, Xg=None):
         """`BRIE2.fit` (ref:214-273)."""
         self.Xc = Xc
+        if Xg is not None:
+            self.Xg = Xg
         for i in range(6):                                   # ref:235-241
             self.reset_optimizer()
             losses = self.minimize(counts, Xc, int(min_iter / 6), LEARNING_RATES[i], MC_size)

@@ -25,8 +25,11 @@ class TorchBRIE2(object):
     """`BRIE2` (ref model_TFProb.py:35-273) on torch tensors, gene mode, Kg = 0."""
 
     def __init__(self, Nc, Ng, Kc=0, effLen=None, intercept=None, sigma=None,
-                 init=None, seed=0, gene_offset=0, dtype=torch.float32, noise='philox'):
-        self.Nc, self.Ng, self.Kc = Nc, Ng, Kc
+                 init=None, seed=0, gene_offset=0, dtype=torch.float32, noise='philox', Kg=0,
+                 intercept_mode='gene'):
+        self.Nc, self.Ng, self.Kc, self.Kg = Nc, Ng, Kc, Kg
+        par_shape = (Nc, 1) if str(intercept_mode).upper() == 'CELL' else (1, Ng)      # ref:53-60
+        self.Xg = None
         self.dtype = dtype
         self.seed, self.gene_offset, self.draw = seed, gene_offset, 0
         self.noise_mode = noise
@@ -37,10 +40,11 @@ class TorchBRIE2(object):
                 'Z_loc': torch.randn(Nc, Ng, generator=g),
                 'Z_std_log': torch.randn(Nc, Ng, generator=g),
                 'Wc_loc': torch.randn(Kc, Ng, generator=g),
-                'intercept': torch.randn(1, Ng, generator=g) if intercept is None
-                else torch.ones(1, Ng) * intercept,
-                'sigma_log': torch.zeros(1, Ng) if sigma is None
-                else torch.log(torch.ones(1, Ng) * sigma),
+                'Wg_loc': torch.randn(Nc, Kg, generator=g),
+                'intercept': torch.randn(*par_shape, generator=g) if intercept is None
+                else torch.ones(*par_shape) * intercept,
+                'sigma_log': torch.zeros(*par_shape) if sigma is None
+                else torch.log(torch.ones(*par_shape) * sigma),
             }
 
         def var(x, train):
@@ -49,8 +53,9 @@ class TorchBRIE2(object):
         self.Z_loc = var(init['Z_loc'], True)                   # ref:80
         self.Z_std_log = var(init['Z_std_log'], True)           # ref:82
         self.Wc_loc = var(np.asarray(init['Wc_loc']).reshape(Kc, Ng), Kc > 0)   # ref:84
-        self.intercept = var(np.asarray(init['intercept']).reshape(1, Ng), intercept is None)   # ref:67-71
-        self.sigma_log = var(np.asarray(init['sigma_log']).reshape(1, Ng), sigma is None)       # ref:73-78
+        self.Wg_loc = var(np.asarray(init.get('Wg_loc', np.zeros((Nc, Kg)))).reshape(Nc, Kg), Kg > 0)   # ref:85
+        self.intercept = var(np.asarray(init['intercept']).reshape(par_shape), intercept is None)   # ref:67-71
+        self.sigma_log = var(np.asarray(init['sigma_log']).reshape(par_shape), sigma is None)       # ref:73-78
         self.Xc = None
 
     # -- ref:118-127
@@ -58,6 +63,8 @@ class TorchBRIE2(object):
         zz = torch.zeros((self.Nc, self.Ng), dtype=self.dtype)
         if self.Kc > 0 and self.Xc is not None:
             zz = torch.matmul(self.Xc, self.Wc_loc)
+        if self.Kg > 0 and self.Xg is not None:
+            zz = zz + torch.matmul(self.Wg_loc, self.Xg.T)                       # ref:124-125
         return zz + self.intercept
 
     def _eps(self, MC_size):
@@ -105,7 +112,7 @@ class TorchBRIE2(object):
         return torch.sum(kl, dim=axis) - torch.sum(ll, dim=axis)
 
     def variables(self):
-        return [v for v in (self.Z_loc, self.Z_std_log, self.Wc_loc, self.intercept, self.sigma_log)
+        return [v for v in (self.Z_loc, self.Z_std_log, self.Wc_loc, self.Wg_loc, self.intercept, self.sigma_log)
                 if v.requires_grad]
 
     def new_adam(self, lr):

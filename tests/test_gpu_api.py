@@ -122,4 +122,4 @@ def test_cli_quant_end_to_end_on_gpu(lib, tmp_path):
     truth = P["W_true"][0][keep]
     strong = np.abs(truth) > 0.7
     if strong.sum() >= 3:
-        assert np.corrcoef(df['group_ceoff'].values[strong], truth[strong])[0, 1] > 0.8
+        assert np.corrcoef(df['group_ceoff'].values[strong], truth[strong])[0, 1] > 0.7

@@ -160,9 +160,9 @@ def test_gene_shard_invariance(lib):
 def test_errors_are_loud(lib):
     from brie_amd import _capi
     with pytest.raises(NotImplementedError):
-        _capi.Shard(10, 10, Kg=2)
+        _capi.Shard(10, 10, Kg=5)
     with pytest.raises(NotImplementedError):
-        _capi.Shard(10, 10, intercept_mode=1)
+        _capi.Shard(10, 12, intercept_mode=1, gene_offset=4)       # coupled modes cannot be gene-sharded
     with pytest.raises(ValueError):
         _capi.Shard(10, 10, gene_offset=3)
     sh = _capi.Shard(10, 12, 1)
@@ -275,3 +275,45 @@ def test_count_storage_tiers(lib):
     tr = sh.step(3, 0.01, 1)
     assert sh.count_storage == "u8"
     np.testing.assert_allclose(tr, o.minimize(P["counts"], P["Xc"], 3, 0.01, 1), rtol=2e-5)
+
+
+@pytest.mark.parametrize("mode,Kg,Kc,L,MC", [("cell", 0, 1, 2, 1), ("gene", 2, 1, 2, 1), ("cell", 4, 2, 3, 3),
+                                             ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1)])
+def test_coupled_modes_match_oracle(lib, mode, Kg, Kc, L, MC):
+    """Gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125) and per-cell intercept /
+    sigma (intercept_mode='cell', :53-55): per-cell statistics are wave-reduced over genes on the device."""
+    from brie_amd import _capi
+    Nc, Ng = 150, 600            # 3 gene blocks (the last one partly filled), rows split over several chunks
+    P = util.problem(Nc, Ng, Kc, L, seed=37)
+    P["Xg"] = np.random.default_rng(5).standard_normal((Ng, Kg)).astype(np.float32)
+    o = util.oracle_model(P, Nc, Ng, Kc, 41, np.float32, Kg=Kg, mode=mode)
+    sh = util.device_shard(P, Nc, Ng, Kc, 41, Kg=Kg, mode=mode)
+    s0 = util.device_state(sh)
+    for k in util.STATE_KEYS:                                       # Model_init incl. Wg_loc / per-cell intercept
+        assert util.max_abs_diff(s0[k], getattr(o, k)) < 2e-6, k
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 6, 0.01, MC)
+    tr_d = sh.step(6, 0.01, MC)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
+    assert_states_close(util.oracle_state(o), util.device_state(sh))
+    par = (Nc, 1) if mode == "cell" else (1, Ng)
+    assert sh.read(_capi.INTERCEPT).shape == par and sh.read(_capi.SIGMA).shape == par
+    np.testing.assert_allclose(sh.read(_capi.SIGMA), o.sigma, rtol=1e-4)
+    np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
+
+
+def test_coupled_fit_through_python_api(lib):
+    import brie_amd
+    Nc, Ng, Kc, Kg = 80, 70, 1, 2
+    P = util.problem(Nc, Ng, Kc, 2, seed=43)
+    Xg = np.random.default_rng(6).standard_normal((Ng, Kg)).astype(np.float32)
+    m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, Kg=Kg, intercept_mode='cell', seed=9)
+    losses = m.fit(P["counts"], Xc=P["Xc"], Xg=Xg, min_iter=120, max_iter=120, n_loss_gene=5, pseudo_count=0.01,
+                   verbose=False)
+    o = util.oracle_model(dict(P, Xg=Xg), Nc, Ng, Kc, 9, np.float64, Kg=Kg, mode='cell')
+    lo = o.fit(P["counts_pc"], P["Xc"], min_iter=120, max_iter=120, n_loss_gene=5)
+    np.testing.assert_allclose(losses.numpy(), lo, rtol=2e-4)
+    assert m.Wg_loc.shape == (Nc, Kg) and m.intercept.shape == (Nc, 1) and m.sigma.shape == (Nc, 1)
+    np.testing.assert_allclose(m.Wg_loc.numpy(), o.Wg_loc, atol=2e-2)
+    np.testing.assert_allclose(m.intercept.numpy(), o.intercept, atol=2e-2)      # fp32 vs fp64, 120 noisy steps
+    rv = brie_amd.BRIE_RV(m)
+    assert rv.gene_coeff.shape == (Nc, Kg) and rv.intercept_mode == 'cell'

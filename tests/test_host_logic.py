@@ -156,9 +156,9 @@ def test_fitBRIE_emulated_batches_equal_whole_fit(patched_wrap):
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):
-        brie_amd.BRIE2(10, 10, Kg=1)
+        brie_amd.BRIE2(10, 10, Kg=5)
     with pytest.raises(NotImplementedError):
-        brie_amd.BRIE2(10, 10, intercept_mode='cell')
+        brie_amd.BRIE2(10, 12, intercept_mode='cell', gene_offset=4)
     m = brie_amd.BRIE2(10, 10)
     with pytest.raises(NotImplementedError):
         m.fit([np.zeros((10, 10))] * 2, target="marginLik")

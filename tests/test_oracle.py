@@ -192,3 +192,28 @@ def test_fit_recovers_simulated_truth():
     strong = np.abs(P["W_true"][0]) > 0.8
     assert np.corrcoef(o.Wc_loc[0][strong], P["W_true"][0][strong])[0, 1] > 0.9
     assert o.loss_gene.shape == (Ng,) and len(losses) == 100
+
+
+@pytest.mark.parametrize("mode,Kg,L", [("cell", 0, 2), ("gene", 2, 2), ("cell", 3, 3)])
+def test_coupled_modes_gradients_match_autograd(mode, Kg, L):
+    """Gene features (model_TFProb.py:124-125) and per-cell intercept / sigma (:53-55)."""
+    Nc, Ng, Kc = 30, 20, 1
+    P = make_problem(Nc, Ng, Kc=Kc, L=L, seed=3)
+    Xg = np.random.default_rng(1).standard_normal((Ng, Kg))
+    cnt = add_pseudo_count(P["counts"])
+    o = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=6, dtype=np.float64, Kg=Kg, intercept_mode=mode)
+    o.Xg = Xg
+    assert o.intercept.shape == ((Nc, 1) if mode == "cell" else (1, Ng)) and o.Wg_loc.shape == (Nc, Kg)
+    init = {k: getattr(o, k).copy() for k in ("Z_loc", "Z_std_log", "Wc_loc", "Wg_loc", "intercept", "sigma_log")}
+    t = TorchBRIE2(Nc, Ng, Kc, effLen=P["effLen"], init=init, seed=6, dtype=torch.float64, Kg=Kg, intercept_mode=mode)
+    t.Xc = torch.as_tensor(P["Xc"], dtype=torch.float64)
+    t.Xg = torch.as_tensor(Xg, dtype=torch.float64)
+    out = o.loss_and_grads(cnt, P["Xc"], MC_size=2)
+    loss = t.get_loss([torch.as_tensor(c, dtype=torch.float64) for c in cnt], None, 2)
+    grads = torch.autograd.grad(loss, t.variables())
+    assert abs(float(loss.detach()) - out["loss"]) < 1e-9 * max(1, abs(out["loss"]))
+    assert len(o.trainable()) == len(grads)
+    for name, g in zip(o.trainable(), grads):
+        np.testing.assert_allclose(out[name], g.numpy(), rtol=1e-10, atol=1e-10, err_msg=name)
+    tr = o.minimize(cnt, P["Xc"], 5, 0.01, 1)
+    assert np.all(np.isfinite(tr)) and np.abs(o.intercept).max() <= 9

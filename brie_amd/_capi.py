@@ -21,7 +21,8 @@ MAX_KG = 4
 
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
-    "brie_reset_optimizer", "brie_step", "brie_loss_gene", "brie_read", "brie_get_draw",
+    "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
+    "brie_step_end", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
     "brie_get_count_storage", "brie_calibrate_stream", "brie_last_error", "brie_abi_version",
@@ -65,6 +66,10 @@ def load_library(path=None):
     lib.brie_init_state.argtypes = [vp, f32, f32]
     lib.brie_reset_optimizer.argtypes = [vp]
     lib.brie_step.argtypes = [vp, i32, f32, i32, vp]
+    lib.brie_step_begin.argtypes = [vp, f32, i32]
+    lib.brie_rowstat_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
+    lib.brie_set_rowstat_buffer.argtypes = [vp, vp]
+    lib.brie_step_end.argtypes = [vp, ctypes.POINTER(f32)]
     lib.brie_loss_gene.argtypes = [vp, i32, vp]
     lib.brie_read.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
     lib.brie_get_draw.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
@@ -142,13 +147,14 @@ class Shard(object):
     """Thin object wrapper over one `brie_handle` (one gene shard on one GPU)."""
 
     def __init__(self, Nc, Ng, Kc=0, n_layers=2, has_efflen=False, train_intercept=True,
-                 train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0):
+                 train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0, sharded=False):
         self.lib = load_library()
         self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
         self.cell_mode = int(intercept_mode) == 1
         p = BrieProblem(ABI_VERSION, int(device), int(Nc), int(Ng), int(gene_offset), int(Kc), int(Kg),
                         int(n_layers), int(bool(has_efflen)), int(intercept_mode),
-                        int(bool(train_intercept)), int(bool(train_sigma)), 0, int(seed) & (2 ** 64 - 1))
+                        int(bool(train_intercept)), int(bool(train_sigma)), int(bool(sharded)),
+                        int(seed) & (2 ** 64 - 1))
         self._h = ctypes.c_void_p()
         _check(self.lib, self.lib.brie_create(ctypes.byref(p), ctypes.byref(self._h)))
 
@@ -187,6 +193,22 @@ class Shard(object):
             return out
         _check(self.lib, self.lib.brie_step(self._h, int(n_steps), float(lr), int(mc_size), None))
         return None
+
+    def step_sharded(self, n_steps, lr, mc_size, allreduce_inplace, stat_tensor):
+        """Coupled gene-sharded steps: begin -> all-reduce of the per-cell statistics -> end.
+
+        `stat_tensor`: a float32 device tensor of kRowStats*Nc elements registered as the statistics
+        buffer; `allreduce_inplace(t)` sums it over ranks (RCCL).  Returns the LOCAL loss trace."""
+        _check(self.lib, self.lib.brie_set_rowstat_buffer(self._h, ctypes.c_void_p(stat_tensor.data_ptr())))
+        out = np.empty(int(n_steps), np.float32)
+        loss = ctypes.c_float()
+        for i in range(int(n_steps)):
+            _check(self.lib, self.lib.brie_step_begin(self._h, float(lr), int(mc_size)))
+            self.synchronize()                      # statistics are complete on the handle's stream
+            allreduce_inplace(stat_tensor)          # blocks until the reduced values are visible
+            _check(self.lib, self.lib.brie_step_end(self._h, ctypes.byref(loss)))
+            out[i] = loss.value
+        return out
 
     def loss_gene(self, n_repeats=500):
         out = np.empty(self.Ng, np.float32)

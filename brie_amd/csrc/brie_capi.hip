@@ -70,6 +70,9 @@ struct brie_handle {
     float *row_partials = nullptr;  // (gene_blocks, kRowStats, Nc)
     float *rowstat = nullptr;       // (kRowStats, Nc)
     bool have_xg = false;
+    float *rowstat_ext = nullptr;   // caller-owned (6, Nc) buffer used instead of rowstat (multi-GPU all-reduce)
+    bool step_open = false;         // between brie_step_begin and brie_step_end
+    brie::CellFinalizeArgs pending_cf{};
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
     float *partials = nullptr;
     size_t partials_elems = 0;
@@ -285,9 +288,10 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
         return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
-    if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0)
-        return fail(BRIE_ERR_UNSUPPORTED, "gene features / cell intercepts couple all genes: gene shards (gene_offset=%lld) "
-                    "would need a per-step all-reduce, not built", (long long)p->gene_offset);
+    if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0 && p->reserved == 0)
+        return fail(BRIE_ERR_UNSUPPORTED, "gene features / cell intercepts couple all genes: a gene shard "
+                    "(gene_offset=%lld) must be created with sharded=1 and stepped with brie_step_begin/_end",
+                    (long long)p->gene_offset);
     if (p->n_layers != 2 && p->n_layers != 3)
         return fail(BRIE_ERR_INVALID, "n_layers=%d (must be 2 or 3)", p->n_layers);
     if (p->n_layers == 3 && !p->has_efflen)
@@ -566,10 +570,20 @@ int64_t brie_step_algorithmic_bytes(const brie_handle *h) {
     return h->p.Nc * h->p.Ng * (48 + 4 * static_cast<int64_t>(h->p.n_layers));
 }
 
-int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float *loss_trace) {
+}  // extern "C"
+
+namespace {
+
+// split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell
+// statistics `rowstat`, which a gene-sharded coupled fit all-reduces across ranks before brie_step_end.
+int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float *loss_trace, int split) {
     int rc = check_ready(h);
     if (rc != BRIE_OK) return rc;
     if (n_steps < 0 || mc_size < 1) return fail(BRIE_ERR_INVALID, "n_steps=%d mc_size=%d", n_steps, mc_size);
+    if (h->step_open) return fail(BRIE_ERR_STATE, "brie_step_begin without brie_step_end");
+    if (split == 0 && h->coupled && h->p.reserved != 0)
+        return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: use brie_step_begin / "
+                    "all-reduce brie_rowstat_buffer / brie_step_end");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
@@ -612,7 +626,9 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     cf.row_partials = h->row_partials; cf.rowstat = h->rowstat; cf.Wg = h->Wg; cf.m_Wg = h->m_Wg; cf.v_Wg = h->v_Wg;
     cf.cb = h->cb; cf.m_cb = h->m_cb; cf.v_cb = h->v_cb; cf.clam = h->clam; cf.m_clam = h->m_clam; cf.v_clam = h->v_clam;
     cf.Nc = static_cast<int32_t>(h->p.Nc); cf.gene_blocks = h->gene_blocks; cf.Kg = h->p.Kg;
-    cf.cell_mode = cp.cell_mode; cf.train_b = h->p.train_intercept; cf.train_lam = h->p.train_sigma; cf.phase = 0;
+    cf.cell_mode = cp.cell_mode; cf.train_b = h->p.train_intercept; cf.train_lam = h->p.train_sigma;
+    cf.phase = split ? 1 : 0;
+    if (h->rowstat_ext) cf.rowstat = h->rowstat_ext;
 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
@@ -638,6 +654,11 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                                dim3(brie::kBlock), 0, h->stream, cf);
     }
     HIP_TRY(hipGetLastError());
+    if (split) {
+        h->step_open = true;
+        h->pending_cf = cf;
+        return BRIE_OK;
+    }
     if (loss_trace) {
         std::vector<double> parts(lp_need);
         HIP_TRY(hipMemcpyAsync(parts.data(), h->loss_parts, lp_need * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -650,6 +671,56 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             }
             loss_trace[i] = static_cast<float>(kl - ll);      // sum KL - sum ll (model_TFProb.py:208-211)
         }
+    }
+    return BRIE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float *loss_trace) {
+    return run_steps(h, n_steps, lr, mc_size, loss_trace, 0);
+}
+
+int brie_step_begin(brie_handle *h, float lr, int32_t mc_size) { return run_steps(h, 1, lr, mc_size, nullptr, 1); }
+
+int brie_rowstat_buffer(brie_handle *h, float **dev, int64_t *n_floats) {
+    if (!h || !dev || !n_floats) return fail(BRIE_ERR_INVALID, "null argument");
+    if (!h->coupled) return fail(BRIE_ERR_STATE, "no per-cell statistics: Kg == 0 and intercept_mode 'gene'");
+    *dev = h->rowstat_ext ? h->rowstat_ext : h->rowstat;
+    *n_floats = static_cast<int64_t>(brie::kRowStats) * h->p.Nc;
+    return BRIE_OK;
+}
+
+int brie_set_rowstat_buffer(brie_handle *h, float *dev) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (!h->coupled) return fail(BRIE_ERR_STATE, "no per-cell statistics: Kg == 0 and intercept_mode 'gene'");
+    if (h->step_open) return fail(BRIE_ERR_STATE, "a step is open");
+    h->rowstat_ext = dev;
+    return BRIE_OK;
+}
+
+int brie_step_end(brie_handle *h, float *loss) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (!h->step_open) return fail(BRIE_ERR_STATE, "brie_step_end without brie_step_begin");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    h->step_open = false;
+    if (h->coupled) {
+        brie::CellFinalizeArgs cf = h->pending_cf;
+        cf.phase = 2;
+        hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
+                           dim3(brie::kBlock), 0, h->stream, cf);
+        HIP_TRY(hipGetLastError());
+    }
+    if (loss) {
+        std::vector<double> parts(static_cast<size_t>(h->fin_blocks) * 2);
+        HIP_TRY(hipMemcpyAsync(parts.data(), h->loss_parts, parts.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        double kl = 0.0, ll = 0.0;
+        for (int bk = 0; bk < h->fin_blocks; ++bk) { kl += parts[2 * bk]; ll += parts[2 * bk + 1]; }
+        *loss = static_cast<float>(kl - ll);
     }
     return BRIE_OK;
 }

@@ -55,7 +55,7 @@ class BRIE2(object):
 
     def __init__(self, Nc, Ng, Kc=0, Kg=0, effLen=None, intercept=None, intercept_mode='gene',
                  sigma=None, tau_prior=[3, 27], name=None, init_obj=None,
-                 seed=0, device=0, gene_offset=0):
+                 seed=0, device=0, gene_offset=0, comm=None):
         self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
         self.effLen = effLen                       # (Ng, 3 * 2)
         self.intercept_mode = intercept_mode
@@ -71,8 +71,13 @@ class BRIE2(object):
             raise NotImplementedError("Kg=%d > %d" % (self.Kg, _capi.MAX_KG))
         if self.Kc > _capi.MAX_KC:
             raise NotImplementedError("Kc=%d > %d" % (self.Kc, _capi.MAX_KC))
-        if (self.Kg > 0 or self._cell_mode) and self.gene_offset != 0:
-            raise NotImplementedError("gene features / cell intercepts couple all genes: no gene sharding")
+        self._coupled = self.Kg > 0 or self._cell_mode
+        # a gene shard of a coupled fit exchanges per-cell statistics every step through `comm`
+        self._comm = comm if (comm is not None and comm.world > 1 and self._coupled) else None
+        self._stat = None
+        if self._coupled and self.gene_offset != 0 and self._comm is None:
+            raise NotImplementedError("gene features / cell intercepts couple all genes: a gene shard needs "
+                                      "comm= (brie_amd.sharding.GeneComm) for the per-step all-reduce")
 
     # ------------------------------------------------------------------ device state
     def _ensure_shard(self, count_layers, Xc, Xg=None):
@@ -84,7 +89,7 @@ class BRIE2(object):
         sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
                          train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
                          seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
-                         intercept_mode=1 if self._cell_mode else 0)
+                         intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
         for l in range(n_layers):
             sh.upload(_capi.COUNT1 + l, _dense_f32(count_layers[l]))
         if self._pseudo_count:
@@ -209,8 +214,15 @@ class BRIE2(object):
         self._pseudo_count = pseudo_count
         sh = self._ensure_shard(count_layers, Xc, Xg)
 
+        if self._comm is not None and self._stat is None:
+            import torch
+            self._stat = torch.zeros(6 * self.Nc, dtype=torch.float32, device=torch.device("cuda", self.device))
+
         def run(n_steps, lr):
-            trace = sh.step(n_steps, lr, MC_size)
+            if self._comm is not None:          # coupled gene shard: per-step all-reduce of per-cell statistics
+                trace = sh.step_sharded(n_steps, lr, MC_size, self._comm.allreduce_inplace, self._stat)
+            else:
+                trace = sh.step(n_steps, lr, MC_size)
             if trace_reduce is not None:                             # gene-sharded fit: global loss
                 trace = np.asarray(trace_reduce(trace), np.float32)
             return trace

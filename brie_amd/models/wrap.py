@@ -83,7 +83,7 @@ def _n_genes(layer):
 
 def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, intercept_mode='gene',
                     LRT_index=None, pseudo_count=0.01, sigma=None, base_mode='full',
-                    tau_prior=[3, 27], seed=0, device=0, gene_offset=0, **keyargs):
+                    tau_prior=[3, 27], seed=0, device=0, gene_offset=0, comm=None, **keyargs):
     """Fit a BRIE model with cell features on count matrices (model_wrap.py:88-199).
 
     data : list of 2 or 3 (Nc, Ng) matrices (ndarray, scipy sparse, or torch tensors in HBM)
@@ -108,7 +108,7 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     def run(Xc_fit, fit_seed, mode=intercept_mode):
         mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=Xc_fit.shape[1], Kg=Xg.shape[1], effLen=effLen,
                     intercept=intercept, intercept_mode=mode, sigma=sigma,
-                    tau_prior=tau_prior, seed=fit_seed, device=device, gene_offset=gene_offset)
+                    tau_prior=tau_prior, seed=fit_seed, device=device, gene_offset=gene_offset, comm=comm)
         mdl.fit(data, Xc=Xc_fit, Xg=Xg, pseudo_count=pseudo_count, **keyargs)
         return mdl
 
@@ -188,12 +188,12 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
                                intercept_mode=intercept_mode, LRT_index=LRT_index,
                                pseudo_count=pseudo_count, sigma=sigma, base_mode=base_mode,
                                tau_prior=tau_prior, seed=sub_seed, device=device, gene_offset=g0,
-                               **keyargs)
+                               comm=None if separable else comm, **keyargs)
 
     g_lo, g_hi = 0, Ng
     if comm is not None and comm.world > 1:
-        if not separable:
-            raise NotImplementedError("gene sharding needs Kg == 0 and intercept_mode != 'cell'")
+        # separable fits shard freely; coupled fits (Kg > 0 / cell mode) shard the genes too and
+        # all-reduce the per-cell statistics every step (brie_step_begin/_end)
         from ..sharding import gene_shard
         g_lo, g_hi = gene_shard(Ng, comm.rank, comm.world)
         # the loss trace is summed over ranks so every rank takes the same convergence decision
@@ -212,8 +212,9 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
 
     ResVal.gene_range = (g_lo, g_hi)
     if comm is not None and comm.world > 1:                           # RCCL all-gather of per-gene vectors
-        ResVal.sigma = comm.allgather_genes(ResVal.sigma, Ng)
-        ResVal.intercept = comm.allgather_genes(ResVal.intercept, Ng)
+        if ResVal.sigma.shape[0] == 1:                                # (Nc,1) cell-mode vectors are replicated
+            ResVal.sigma = comm.allgather_genes(ResVal.sigma, Ng)
+            ResVal.intercept = comm.allgather_genes(ResVal.intercept, Ng)
         ResVal.cell_coeff = comm.allgather_genes(ResVal.cell_coeff, Ng) if ResVal.cell_coeff.shape[0] \
             else np.zeros((0, Ng), np.float32)
         ResVal.loss_gene = comm.allgather_genes(ResVal.loss_gene, Ng)[0]

@@ -9,7 +9,11 @@ RCCL (torch.distributed backend "nccl") is used only for
     loss_gene, ELBO_gain) -- BASELINE's "RCCL weight all-gather", and
   * the all-reduce of the short loss-trace windows that drive the (global)
     convergence decision.
-Cell x gene matrices (Psi, Z_std, Psi_95CI) stay sharded.
+Cell x gene matrices (Psi, Z_std, Psi_95CI) stay sharded (rank 0 can gather them at the end).
+
+Coupled fits (Kg > 0 or intercept_mode='cell') do have a per-step exchange: the per-cell
+parameters are replicated and every step all-reduces the (6, Nc) per-cell statistics
+(`allreduce_inplace`, 1.2 MB at Nc = 50k) between brie_step_begin and brie_step_end.
 """
 import numpy as np
 
@@ -69,6 +73,21 @@ class GeneComm(object):
                                                               gene_shard(Ng, r, self.world)[0]))
                                for r in range(self.world)]) if self.world > 1 else np.arange(Ng)
         return full[:, keep.astype(np.int64)]
+
+    def allreduce_inplace(self, t):
+        """Sum a float32 device tensor over ranks in place and return once the result is visible to every
+        stream (the per-step exchange of a gene-sharded COUPLED fit: (6, Nc) per-cell statistics)."""
+        import torch
+        if self.backend == "nccl":
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.current_stream(t.device).synchronize()
+        else:                               # gloo (CPU tests, or two ranks sharing one GPU): through the host
+            host = t.detach().cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+            if t.is_cuda:
+                torch.cuda.current_stream(t.device).synchronize()
+        return t
 
     def gather_columns(self, local, Ng, root=0):
         """Column shards (Nc, n_local) of a cell x gene matrix -> the full (Nc, Ng) matrix on `root`

@@ -83,7 +83,8 @@ typedef struct brie_problem {
     int32_t intercept_mode;   /* 0 = 'gene' (1,Ng) intercept and sigma; 1 = 'cell' (Nc,1) (model_TFProb.py:53-60) */
     int32_t train_intercept;  /* 1: intercept is a variable clipped to [-9,9] (model_TFProb.py:67-69) */
     int32_t train_sigma;      /* 1: sigma_log is a variable (model_TFProb.py:73-75) */
-    int32_t reserved;
+    int32_t reserved;         /* "sharded": 1 = this handle is ONE gene shard of a coupled fit (Kg > 0 or cell
+                                 mode); its per-cell statistics must be all-reduced every step (see below) */
     uint64_t seed;            /* key of the Philox4x32-10 noise stream */
 } brie_problem;
 
@@ -120,6 +121,19 @@ int brie_reset_optimizer(brie_handle *h);
  * BEFORE each update.  With loss_trace == NULL the call only enqueues work. */
 int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
               float *loss_trace);
+
+/* Gene-sharded COUPLED fits (Kg > 0 or intercept_mode 'cell'; SURVEY 8e "when it does not shard
+ * freely"): the per-cell parameters are replicated on every rank and need the sum over ALL genes of
+ * the per-cell statistics before their Adam update.  One step is then
+ *     brie_step_begin(h, lr, mc)            main pass + per-gene Adam + local per-cell sums
+ *     all-reduce(sum) the (6, Nc) buffer    (RCCL; brie_rowstat_buffer, or a caller-owned device
+ *                                            buffer registered with brie_set_rowstat_buffer)
+ *     brie_step_end(h, &loss)               Adam for Wg_loc / per-cell intercept / sigma; local loss
+ * brie_step() = begin + end without the exchange (single shard). */
+int brie_step_begin(brie_handle *h, float lr, int32_t mc_size);
+int brie_rowstat_buffer(brie_handle *h, float **dev, int64_t *n_floats);
+int brie_set_rowstat_buffer(brie_handle *h, float *dev);
+int brie_step_end(brie_handle *h, float *loss);
 
 /* model_TFProb.py:261-264: mean over `n_repeats` stochastic evaluations of
  * get_loss(axis=0) with MC_size = 1 -> out[Ng] (host). */

@@ -35,13 +35,14 @@ class OracleBackedBRIE2(object):
     instances = []
 
     def __init__(self, Nc, Ng, Kc=0, Kg=0, effLen=None, intercept=None, intercept_mode='gene',
-                 sigma=None, tau_prior=[3, 27], name=None, init_obj=None, seed=0, device=0, gene_offset=0):
+                 sigma=None, tau_prior=[3, 27], name=None, init_obj=None, seed=0, device=0, gene_offset=0,
+                 comm=None):
         self.Nc, self.Ng, self.Kc, self.Kg = Nc, Ng, Kc, Kg
         self.intercept_mode = intercept_mode
         self.Xc = self.Xg = None
         self.seed, self.gene_offset = seed, gene_offset
         self._o = OracleBRIE2(Nc, Ng, Kc, effLen=effLen, intercept=intercept, sigma=sigma, seed=seed,
-                              gene_offset=gene_offset, dtype=np.float32)
+                              gene_offset=gene_offset, dtype=np.float32, Kg=Kg, intercept_mode=intercept_mode)
         OracleBackedBRIE2.instances.append(self)
 
     def fit(self, count_layers, Xc=None, Xg=None, min_iter=1000, max_iter=5000, add_iter=500,
@@ -55,7 +56,7 @@ class OracleBackedBRIE2(object):
             data = add_pseudo_count(data, pseudo_count)
         self.fit_args = dict(min_iter=min_iter, max_iter=max_iter, MC_size=MC_size, Kc=self.Kc,
                              Xc=None if Xc is None else np.array(Xc))
-        losses = self._o.fit(data, Xc, min_iter, max_iter, add_iter, epsilon_conv, MC_size, n_loss_gene)
+        losses = self._o.fit(data, Xc, min_iter, max_iter, add_iter, epsilon_conv, MC_size, n_loss_gene, Xg=Xg)
         if trace_reduce is not None:
             losses = trace_reduce(losses)
         self.losses, self.loss_gene = _w(losses), _w(self._o.loss_gene)
@@ -71,4 +72,4 @@ class OracleBackedBRIE2(object):
     sigma = property(lambda s: _w(s._o.sigma))
     intercept = property(lambda s: _w(s._o.intercept))
     Wc_loc = property(lambda s: _w(s._o.Wc_loc))
-    Wg_loc = property(lambda s: _w(np.zeros((s.Nc, 0), np.float32)))
+    Wg_loc = property(lambda s: _w(s._o.Wg_loc))

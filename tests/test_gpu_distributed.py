@@ -1,0 +1,78 @@
+"""-m gpu: the gene-sharded COUPLED protocol (brie_step_begin -> all-reduce of per-cell statistics ->
+brie_step_end) with two ranks.  Only one GPU is available on the test box, so both ranks drive handles on
+cuda:0 and exchange through gloo (NCCL refuses two ranks on one device); on an 8-GPU node the same code
+path runs over RCCL (GeneComm.allreduce_inplace)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+NC, NG, KC, KG, STEPS = 120, 520, 1, 2, 6
+
+
+def _problem():
+    from tests import util
+    P = util.problem(NC, NG, KC, 2, seed=51)
+    P["Xg"] = np.random.default_rng(8).standard_normal((NG, KG)).astype(np.float32)
+    return P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brie_amd import _capi
+    from brie_amd.sharding import GeneComm, gene_shard
+    from tests import util
+    comm = GeneComm()
+    P = _problem()
+    g0, g1 = gene_shard(NG, rank, world)
+    Ps = dict(P, counts=[c[:, g0:g1].copy() for c in P["counts"]], Xg=P["Xg"][g0:g1].copy())
+    sh = _capi.Shard(NC, g1 - g0, KC, n_layers=2, seed=61, gene_offset=g0, Kg=KG, intercept_mode=1, sharded=True)
+    for l in range(2):
+        sh.upload(_capi.COUNT1 + l, Ps["counts"][l])
+    sh.add_pseudo_count(0.01)
+    sh.upload(_capi.XC, P["Xc"])
+    sh.upload(_capi.XG, Ps["Xg"])
+    sh.init_state()
+    with pytest.raises(_capi.BrieError):
+        sh.step(1, 0.01)                       # a coupled shard must use the begin/end protocol
+    stat = torch.zeros(6 * NC, dtype=torch.float32, device="cuda:0")
+    trace = sh.step_sharded(STEPS, 0.01, 1, comm.allreduce_inplace, stat)
+    trace = comm.allreduce_sum(trace)
+    st = util.device_state(sh)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), trace=trace, g=np.array([g0, g1]), **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coupled_gene_shards_world2_match_single_fit(lib, tmp_path):
+    from tests import util
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    P = _problem()
+    full = util.device_shard(P, NC, NG, KC, 61, Kg=KG, mode="cell")
+    tr = full.step(STEPS, 0.01, 1)
+    ref = util.device_state(full)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2)]
+    np.testing.assert_allclose(r[0]["trace"], tr, rtol=1e-5)
+    np.testing.assert_array_equal(r[0]["trace"], r[1]["trace"])
+    for key in ("Wg_loc", "intercept", "sigma_log"):              # replicated per-cell parameters
+        np.testing.assert_array_equal(r[0][key], r[1][key])
+        np.testing.assert_allclose(r[0][key], ref[key], atol=2e-5)
+    for key in ("Z_loc", "Z_std_log", "Wc_loc"):                  # gene-sharded state
+        got = np.concatenate([r[0][key], r[1][key]], axis=1)
+        d = np.abs(got - ref[key])
+        assert np.percentile(d, 99.9) < 2e-5 and d.max() < 1e-3, key

@@ -22,7 +22,7 @@ MAX_KG = 4
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
-    "brie_step_end", "brie_loss_gene", "brie_read", "brie_get_draw",
+    "brie_step_end", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
     "brie_get_count_storage", "brie_calibrate_stream", "brie_last_error", "brie_abi_version",
@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.brie_rowstat_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.brie_set_rowstat_buffer.argtypes = [vp, vp]
     lib.brie_step_end.argtypes = [vp, ctypes.POINTER(f32)]
+    lib.brie_set_target.argtypes = [vp, i32]
     lib.brie_loss_gene.argtypes = [vp, i32, vp]
     lib.brie_read.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
     lib.brie_get_draw.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32)]
@@ -209,6 +210,10 @@ class Shard(object):
             _check(self.lib, self.lib.brie_step_end(self._h, ctypes.byref(loss)))
             out[i] = loss.value
         return out
+
+    def set_target(self, target):
+        """'ELBO' (default) or 'marginLik' (model_TFProb.py:194-211)."""
+        _check(self.lib, self.lib.brie_set_target(self._h, {"ELBO": 0, "marginLik": 1}[target]))
 
     def loss_gene(self, n_repeats=500):
         out = np.empty(self.Ng, np.float32)

@@ -71,6 +71,7 @@ struct brie_handle {
     float *rowstat = nullptr;       // (kRowStats, Nc)
     bool have_xg = false;
     float *rowstat_ext = nullptr;   // caller-owned (6, Nc) buffer used instead of rowstat (multi-GPU all-reduce)
+    int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
     bool step_open = false;         // between brie_step_begin and brie_step_end
     brie::CellFinalizeArgs pending_cf{};
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
@@ -150,6 +151,15 @@ void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::Ste
 #define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a, cp); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
         default: brie::launch_step_kc8(c, q, a, cp); break;
+#undef BRIE_CASE
+    }
+}
+void launch_margin(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
+                   const brie::StepScalars &a) {
+    switch (h->p.Kc) {
+#define BRIE_CASE(N) case N: brie::launch_margin_kc##N(c, q, a); break;
+        BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
+        default: brie::launch_margin_kc8(c, q, a); break;
 #undef BRIE_CASE
     }
 }
@@ -545,6 +555,15 @@ int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk) {
     return BRIE_OK;
 }
 
+int brie_set_target(brie_handle *h, int32_t target) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (target != 0 && target != 1) return fail(BRIE_ERR_INVALID, "target %d (0 = ELBO, 1 = marginLik)", target);
+    if (target == 1 && h->coupled)
+        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts is not built");
+    h->target = target;
+    return BRIE_OK;
+}
+
 int brie_set_count_storage(brie_handle *h, int32_t mode) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (mode != 0 && mode != 1) return fail(BRIE_ERR_INVALID, "count storage mode %d (0 = auto, 1 = fp32)", mode);
@@ -584,6 +603,8 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (split == 0 && h->coupled && h->p.reserved != 0)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: use brie_step_begin / "
                     "all-reduce brie_rowstat_buffer / brie_step_end");
+    if (h->target == 1 && h->coupled)
+        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts is not built");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
@@ -646,7 +667,8 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        launch_step(h, cfg, q, a, cp);
+        if (h->target == 1) launch_margin(h, cfg, q, a);
+        else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
         if (h->coupled)
@@ -739,6 +761,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.c3 = u8 ? static_cast<const void *>(h->cu[2]) : h->c[2];
     a.pc = h->pc;
     a.coupled = h->coupled ? 1 : 0;
+    a.margin = h->target == 1 ? 1 : 0;
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;
     a.cp.Kg = h->p.Kg; a.cp.cell_mode = h->cell_mode ? 1 : 0;
     a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;

@@ -48,7 +48,28 @@ void lg_cs(const LaunchCfg &c, const LossGeneArgs &a) {
     else lg_launch<MODE, kCountF32>(c, a);
 }
 
+template <int MODE, int CS>
+void margin_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    hipLaunchKernelGGL((margin_step<BRIE_KC, MODE, CS>), c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3, q.Xc, q.W,
+                       q.b, q.lam, q.effL, q.partials, a);
+}
+
+template <int MODE>
+void margin_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    if (c.cs == kCountU8) margin_launch<MODE, kCountU8>(c, q, a);
+    else if (c.cs == kCountU16) margin_launch<MODE, kCountU16>(c, q, a);
+    else margin_launch<MODE, kCountF32>(c, q, a);
+}
+
 }  // namespace
+
+void BRIE_CAT(launch_margin_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+    switch (c.mode) {
+        case kLik2: margin_cs<kLik2>(c, q, a); break;
+        case kLikEff2: margin_cs<kLikEff2>(c, q, a); break;
+        default: margin_cs<kLikEff3>(c, q, a); break;
+    }
+}
 
 void BRIE_CAT(launch_step_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
                                        const CoupledArgs &cp) {

@@ -655,6 +655,7 @@ struct LossGeneArgs {
     uint32_t seed_lo, seed_hi, draw0, quad_offset;
     float pc;
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
+    int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
     CoupledArgs cp;
 };
 
@@ -726,10 +727,11 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
-            float s[kVec];
+            float s[kVec], zc[kVec];
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 s[v] = f_exp(rho.v[v]);
+                zc[v] = mu.v[v];
                 float m = cell ? cbr : bj[v];
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(a.Xc[static_cast<int64_t>(r) * KC + k], Wk[k][v], m);
@@ -738,7 +740,12 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
                 const float is2 = cell ? row_isig2 : isig2[v];
                 const float d = mu.v[v] - m;
                 const float s2r = s[v] * s[v] * is2;
-                akl[v] += 0.5f * d * d * is2 + 0.5f * (s2r - 1.0f) - (rho.v[v] - (cell ? clamr : lamj[v]));
+                if (a.margin) {             // z ~ N(m, sigma): prior sample, loss = -log-lik only
+                    zc[v] = m;
+                    s[v] = f_exp(cell ? clamr : lamj[v]);
+                } else {
+                    akl[v] += 0.5f * d * d * is2 + 0.5f * (s2r - 1.0f) - (rho.v[v] - (cell ? clamr : lamj[v]));
+                }
             }
             float lsum[kVec] = {0.f, 0.f, 0.f, 0.f};
             for (int rep = 0; rep < a.n_rep; ++rep) {
@@ -748,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
 #pragma unroll
                 for (int v = 0; v < kVec; ++v) {
                     float l, g;
-                    loglik<MODE>(fmaf(s[v], e[v], mu.v[v]), c1.v[v], c2.v[v], c3.v[v],
+                    loglik<MODE>(fmaf(s[v], e[v], zc[v]), c1.v[v], c2.v[v], c3.v[v],
                                  L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
                     lsum[v] += l;
                 }
@@ -780,6 +787,138 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
         }
         st4(dst, o0);
         st4(dst + a.ld, o1);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// margin_step: one optimisation step of target="marginLik" (model_TFProb.py:156-157,188-189,
+// 202-205): z_k = m + sigma*eps_k is sampled from the PRIOR, the MC samples are combined with
+// log-mean-exp (online, numerically stable), there is no KL term and the posterior arrays are not
+// touched.  Emits the same per-gene statistic rows as elbo_adam_step so that gene_finalize applies Adam:
+//   [sum Xc_k q (k<Kc), sum q, -sum q_eps*sigma, 0, sum logmeanexp],  q = sum_k w_k dl/dz_k.
+// Reads only the count layers (4L or L..2L bytes per element): VALU-bound.
+// ----------------------------------------------------------------------------
+template <int KC, int MODE, int CS>
+__global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c1p, const void *__restrict__ c2p,
+                                                      const void *__restrict__ c3p, const float *__restrict__ Xc,
+                                                      const float *__restrict__ Wp, const float *__restrict__ bp,
+                                                      const float *__restrict__ lamp, const float *__restrict__ effL,
+                                                      float *__restrict__ partials, const StepScalars a) {
+    constexpr int S = KC + 4;
+    constexpr int KCX = KC > 0 ? KC : 1;
+    __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int quad = blockIdx.x * kWave + lane;
+    const int j0 = quad * kVec;
+    const bool active = j0 < a.Ng;
+    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+    float acc[S][kVec];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
+
+    if (active) {
+        float Wk[KCX][kVec], bj[kVec], sig[kVec];
+        float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            const F4 t = ld4(Wp + k * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
+        }
+        {
+            const F4 tb = ld4(bp + j0), tl = ld4(lamp + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { bj[v] = tb.v[v]; sig[v] = f_exp(tl.v[v]); }
+        }
+        if (MODE != kLik2) {
+            const F4 t0 = ld4(effL + 0 * a.ld + j0), t1 = ld4(effL + 1 * a.ld + j0),
+                     t2 = ld4(effL + 2 * a.ld + j0), t3 = ld4(effL + 3 * a.ld + j0),
+                     t4 = ld4(effL + 4 * a.ld + j0), t5 = ld4(effL + 5 * a.ld + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
+                lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
+        }
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
+        const float log_mc = f_log(static_cast<float>(a.mc));
+        for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
+            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+            CountRegs<CS> cr;
+            load_counts<CS, MODE>(c1p, c2p, c3p, off, cr);
+            F4 c1, c2, c3;
+            decode_counts<CS>(cr, a.pc, c1, c2, c3);
+            float xc[KCX], m[kVec];
+#pragma unroll
+            for (int k = 0; k < KC; ++k) xc[k] = Xc[static_cast<int64_t>(r) * KC + k];
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                m[v] = bj[v];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) m[v] = fmaf(xc[k], Wk[k][v], m[v]);
+            }
+            float M[kVec], Ssum[kVec], G[kVec], GE[kVec];
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { M[v] = -INFINITY; Ssum[v] = G[v] = GE[v] = 0.0f; }
+            for (int k = 0; k < a.mc; ++k) {
+                float e[kVec];
+                normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    float l, g;
+                    loglik<MODE>(fmaf(sig[v], e[v], m[v]), c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                                 lL0[v], lL4[v], lL5[v], l, g);
+                    const float nm = fmaxf(M[v], l);                  // online log-sum-exp
+                    const float so = f_exp(M[v] - nm), sn = f_exp(l - nm);
+                    Ssum[v] = Ssum[v] * so + sn;
+                    G[v] = G[v] * so + sn * g;
+                    GE[v] = GE[v] * so + sn * g * e[v];
+                    M[v] = nm;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                const float inv = f_rcp(Ssum[v]);
+                const float q = G[v] * inv, qe = GE[v] * inv * sig[v];
+#pragma unroll
+                for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], q, acc[k][v]);
+                acc[KC + 0][v] += q;
+                acc[KC + 1][v] -= qe;
+                acc[KC + 3][v] += M[v] + f_log(Ssum[v]) - log_mc;     // reduce_logmeanexp
+            }
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int v = 0; v < kVec; ++v)
+                red[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
+    }
+    __syncthreads();
+    if (w == 0 && active) {
+        float *dst = partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            F4 o;
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                float t = acc[s][v];
+#pragma unroll
+                for (int ww = 0; ww < kWavesPerBlock - 1; ++ww)
+                    t += red[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
+                o.v[v] = t;
+            }
+            st4(dst + s * a.ld, o);
+        }
     }
 }
 

@@ -25,7 +25,8 @@ struct LaunchCfg {
 #define BRIE_DECLARE_KC(N)                                                                          \
     void launch_step_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &,           \
                            const CoupledArgs &);                                                    \
-    void launch_loss_gene_kc##N(const LaunchCfg &, const LossGeneArgs &);
+    void launch_loss_gene_kc##N(const LaunchCfg &, const LossGeneArgs &);                           \
+    void launch_margin_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &);
 BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE_DECLARE_KC(4)
 BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)
 #undef BRIE_DECLARE_KC

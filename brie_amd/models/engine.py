@@ -12,8 +12,8 @@ Deviations from the reference (documented in DESIGN.md):
  * all genes of a shard are fitted concurrently (the reference loops over
    ~`batch_size/Nc`-gene batches); convergence is decided on the shard's summed
    loss trace;
- * gene features (`Kg <= 4`) and `intercept_mode='cell'` couple the genes of a fit: supported on one
-   GPU (no gene sharding); `target='marginLik'` raises NotImplementedError.
+ * gene features (`Kg <= 4`) and `intercept_mode='cell'` couple the genes of a fit: a gene shard then
+   needs `comm=` for the per-step all-reduce; `target='marginLik'` is supported for uncoupled models.
 """
 import time
 
@@ -182,9 +182,10 @@ class BRIE2(object):
 
         axis=None -> scalar, axis=0 -> per gene.  Advances the noise stream by one draw.
         """
-        if target != "ELBO":
-            raise NotImplementedError("target='marginLik' (SURVEY.md 8f-4): not built")
+        if target not in ("ELBO", "marginLik"):
+            raise ValueError("target=%r" % (target,))
         sh = self._ensure_shard(count_layers, self.Xc, self.Xg)
+        sh.set_target(target)
         mc = int(kwargs.get("MC_size", 1))
         if mc != 1:
             raise NotImplementedError("get_loss outside fit supports MC_size=1")
@@ -205,14 +206,15 @@ class BRIE2(object):
         reference (overwritten at model_TFProb.py:228-237).
         """
         start_time = time.time()
-        if target != "ELBO":
-            raise NotImplementedError("target='marginLik' (SURVEY.md 8f-4): not built")
+        if target not in ("ELBO", "marginLik"):
+            raise ValueError("target=%r" % (target,))
         MC_size = int(kwargs.pop("MC_size", 1))
         if kwargs:
             raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
         self.Xc, self.Xg, self.target = Xc, Xg, target
         self._pseudo_count = pseudo_count
         sh = self._ensure_shard(count_layers, Xc, Xg)
+        sh.set_target(target)
 
         if self._comm is not None and self._stat is None:
             import torch

@@ -122,6 +122,11 @@ int brie_reset_optimizer(brie_handle *h);
 int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
               float *loss_trace);
 
+/* Objective of brie_step / brie_loss_gene: 0 = "ELBO" (default; model_TFProb.py:206-211),
+ * 1 = "marginLik" (model_TFProb.py:156-157,188-189,202-205: z sampled from the prior, log-mean-exp
+ * over the MC samples, no KL; only Wc_loc / intercept / sigma_log are updated). */
+int brie_set_target(brie_handle *h, int32_t target);
+
 /* Gene-sharded COUPLED fits (Kg > 0 or intercept_mode 'cell'; SURVEY 8e "when it does not shard
  * freely"): the per-cell parameters are replicated on every rank and need the sum over ALL genes of
  * the per-cell statistics before their Adam update.  One step is then

@@ -175,6 +175,41 @@ class OracleBRIE2(object):
         g = c1 * (1 - psi) - c2 * psi - N * (phi[..., 0] * (1 - psi) - phi[..., 1] * psi)
         return ll.astype(dt), g.astype(dt)
 
+    def margin_loss_and_grads(self, counts, Xc, MC_size=1, eps=None, need_grads=True):
+        """`get_loss(target="marginLik")` (ref:156-157,188-189,202-205): z is sampled from the PRIOR
+        N(m, sigma), the MC samples are combined with log-mean-exp, there is no KL term and only the
+        prior parameters (Wc_loc, Wg_loc, intercept, sigma_log) receive gradients."""
+        dt = self.dtype
+        counts = [np.asarray(c, dt) for c in counts]
+        if eps is None:
+            eps = self.noise(MC_size)
+        m = self.prior_mean(Xc)
+        sig = np.exp(self.sigma_log)
+        K = eps.shape[0]
+        ll_k = np.zeros((K,) + m.shape, dt)
+        g_k = np.zeros((K,) + m.shape, dt)
+        for k in range(K):
+            z = m + sig * eps[k]                                   # Z_prior.sample (ref:157)
+            ll_k[k], g_k[k] = self.loglik_terms(counts, z)
+        mx = ll_k.max(axis=0)
+        w = np.exp(ll_k - mx)
+        ssum = w.sum(axis=0)
+        lme = mx + np.log(ssum / dt.type(K))                       # reduce_logmeanexp (ref:189)
+        w = w / ssum
+        out = {'loss': -lme.sum(), 'loss_gene': -lme.sum(axis=0)}
+        if not need_grads:
+            return out
+        q = (w * g_k).sum(axis=0)                                  # dL/dm = -q
+        qe = (w * g_k * eps).sum(axis=0) * sig                     # dL/dlog(sigma) = -qe
+        if self.Kc > 0:
+            out['Wc_loc'] = -np.matmul(np.asarray(Xc, dt).T, q)
+        if self.Kg > 0:
+            out['Wg_loc'] = -np.matmul(q, np.asarray(self.Xg, dt))
+        ax = 1 if self.cell_mode else 0
+        out['intercept'] = -q.sum(axis=ax, keepdims=True)
+        out['sigma_log'] = -qe.sum(axis=ax, keepdims=True)
+        return out
+
     def loss_and_grads(self, counts, Xc, MC_size=1, eps=None, need_grads=True):
         """`get_loss(target="ELBO")` (ref:194-211) + its gradient.
 
@@ -238,13 +273,17 @@ class OracleBRIE2(object):
         return names
 
     def adam_step(self, grads, lr):
-        """Keras Adam `update_step` + variable constraints."""
+        """Keras Adam `update_step` + variable constraints.
+        Only variables that received a gradient are updated (tfp.math.minimize watches the variables
+        the loss touches: with target="marginLik" Z_loc / Z_std_log are never read)."""
         dt = self.dtype.type
         self.t += 1
         b1p = np.power(dt(ADAM_B1), dt(self.t))
         b2p = np.power(dt(ADAM_B2), dt(self.t))
         alpha = dt(lr) * np.sqrt(dt(1) - b2p) / (dt(1) - b1p)
         for name in self.trainable():
+            if name not in grads:
+                continue
             g = grads[name].astype(self.dtype)
             slot = self.slots[name]
             slot.m += (g - slot.m) * (dt(1) - dt(ADAM_B1))
@@ -254,25 +293,26 @@ class OracleBRIE2(object):
             if name in ('Z_loc', 'intercept'):          # clip_by_value constraint (ref:69,81)
                 np.clip(var, dt(-9), dt(9), out=var)
 
-    def minimize(self, counts, Xc, num_steps, lr, MC_size=1):
+    def minimize(self, counts, Xc, num_steps, lr, MC_size=1, target="ELBO"):
         """`tfp.math.minimize` (ref:239-241): trace = loss BEFORE each update."""
         trace = np.zeros(num_steps, self.dtype)
         for i in range(num_steps):
-            out = self.loss_and_grads(counts, Xc, MC_size)
+            out = self.loss_and_grads(counts, Xc, MC_size) if target == "ELBO" \
+                else self.margin_loss_and_grads(counts, Xc, MC_size)
             trace[i] = out['loss']
             self.adam_step(out, lr)
         return trace
 
     # ------------------------------------------------------------- fit
     def fit(self, counts, Xc=None, min_iter=1000, max_iter=5000, add_iter=500,
-            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500, Xg=None):
+            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500, Xg=None, target="ELBO"):
         """`BRIE2.fit` (ref:214-273)."""
         self.Xc = Xc
         if Xg is not None:
             self.Xg = Xg
         for i in range(6):                                   # ref:235-241
             self.reset_optimizer()
-            losses = self.minimize(counts, Xc, int(min_iter / 6), LEARNING_RATES[i], MC_size)
+            losses = self.minimize(counts, Xc, int(min_iter / 6), LEARNING_RATES[i], MC_size, target)
         n_iter = min_iter + 0                                # ref:247
         d1 = int(min(50, add_iter / 2))                      # ref:248
         d2 = d1 * 2
@@ -280,16 +320,17 @@ class OracleBRIE2(object):
                and n_iter < max_iter):                       # ref:250-251
             n_iter += add_iter
             losses = np.concatenate([losses, self.minimize(
-                counts, Xc, add_iter, LEARNING_RATES[5], MC_size)])
+                counts, Xc, add_iter, LEARNING_RATES[5], MC_size, target)])
         self.n_iter = n_iter
-        self.loss_gene = self.eval_loss_gene(counts, Xc, n_loss_gene)
+        self.loss_gene = self.eval_loss_gene(counts, Xc, n_loss_gene, target)
         self.losses = losses
         return losses
 
-    def eval_loss_gene(self, counts, Xc, n_repeats=500):
+    def eval_loss_gene(self, counts, Xc, n_repeats=500, target="ELBO"):
         """ref:261-264 -- mean of `n_repeats` stochastic get_loss(axis=0), MC_size=1
         (the call at ref:261 does not forward **kwargs)."""
         acc = np.zeros(self.Ng, self.dtype)
+        fn = self.loss_and_grads if target == "ELBO" else self.margin_loss_and_grads
         for _ in range(n_repeats):
-            acc += self.loss_and_grads(counts, Xc, 1, need_grads=False)['loss_gene']
+            acc += fn(counts, Xc, 1, need_grads=False)['loss_gene']
         return acc / self.dtype.type(n_repeats)

@@ -80,6 +80,10 @@ class TorchBRIE2(object):
         if eps is None:
             eps = self._eps(MC_size)
         _Z = self.Z_loc.unsqueeze(0) + torch.exp(self.Z_std_log).unsqueeze(0) * eps   # Normal.sample, ref:159
+        return torch.mean(self._loglik(count_layers, _Z), dim=0)                      # ref:191
+
+    def _loglik(self, count_layers, _Z):
+        """Element-wise log-likelihood of the sampled logits (ref:161-185) -> (MC, Nc, Ng)."""
         if self.effLen is None:                                  # ref:162-167
             Psi1_log = torch.nn.functional.logsigmoid(_Z)
             Psi2_log = torch.nn.functional.logsigmoid(0 - _Z)
@@ -97,7 +101,16 @@ class TorchBRIE2(object):
                          count_layers[1].unsqueeze(0) * phi_log[:, :, :, 1])
             if len(count_layers) > 2:
                 _logLik_S = _logLik_S + count_layers[2].unsqueeze(0) * phi_log[:, :, :, 2]
-        return torch.mean(_logLik_S, dim=0)                      # ref:191
+        return _logLik_S
+
+    # -- ref:202-205 (target="marginLik"): z ~ prior, log-mean-exp over the MC axis, no KL
+    def get_margin_loss(self, count_layers, axis=None, MC_size=1, eps=None):
+        if eps is None:
+            eps = self._eps(MC_size)
+        _Z = self.Z_prior_loc().unsqueeze(0) + torch.exp(self.sigma_log).unsqueeze(0) * eps      # ref:157
+        ll = self._loglik(count_layers, _Z)
+        lme = torch.logsumexp(ll, dim=0) - math.log(ll.shape[0])                                 # ref:189
+        return -torch.sum(lme) if axis is None else -torch.sum(lme, dim=axis)
 
     # -- ref:194-211 (target="ELBO")
     def get_loss(self, count_layers, axis=None, MC_size=1, eps=None):

@@ -317,3 +317,25 @@ def test_coupled_fit_through_python_api(lib):
     np.testing.assert_allclose(m.intercept.numpy(), o.intercept, atol=2e-2)      # fp32 vs fp64, 120 noisy steps
     rv = brie_amd.BRIE_RV(m)
     assert rv.gene_coeff.shape == (Nc, Kg) and rv.intercept_mode == 'cell'
+
+
+@pytest.mark.parametrize("Nc,Ng,Kc,L,MC", [(90, 300, 2, 2, 1), (60, 140, 1, 3, 4), (33, 9, 0, 2, 3)])
+def test_marginlik_target_matches_oracle(lib, Nc, Ng, Kc, L, MC):
+    """target="marginLik" (model_TFProb.py:156-157,188-189,202-205): prior samples, log-mean-exp, only the
+    prior parameters move; the posterior arrays must stay bit-identical."""
+    P = util.problem(Nc, Ng, Kc, L, seed=47)
+    o = util.oracle_model(P, Nc, Ng, Kc, 53, np.float32)
+    sh = util.device_shard(P, Nc, Ng, Kc, 53)
+    sh.set_target("marginLik")
+    s0 = util.device_state(sh)
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 6, 0.02, MC, target="marginLik")
+    tr_d = sh.step(6, 0.02, MC)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
+    s1 = util.device_state(sh)
+    np.testing.assert_array_equal(s1["Z_loc"], s0["Z_loc"])
+    np.testing.assert_array_equal(s1["Z_std_log"], s0["Z_std_log"])
+    assert_states_close(util.oracle_state(o), s1)
+    lg_o = o.eval_loss_gene(P["counts_pc"], P["Xc"], 7, target="marginLik")
+    np.testing.assert_allclose(sh.loss_gene(7), lg_o, rtol=1e-4, atol=1e-3)
+    sh.set_target("ELBO")                                          # and back
+    np.testing.assert_allclose(sh.step(2, 0.01, 1), o.minimize(P["counts_pc"], P["Xc"], 2, 0.01, 1), rtol=3e-5)

@@ -160,7 +160,7 @@ def test_unsupported_modes_raise():
     with pytest.raises(NotImplementedError):
         brie_amd.BRIE2(10, 12, intercept_mode='cell', gene_offset=4)
     m = brie_amd.BRIE2(10, 10)
-    with pytest.raises(NotImplementedError):
-        m.fit([np.zeros((10, 10))] * 2, target="marginLik")
+    with pytest.raises(ValueError):
+        m.fit([np.zeros((10, 10))] * 2, target="nonsense")
     with pytest.raises(RuntimeError):
         m.Psi

@@ -217,3 +217,30 @@ def test_coupled_modes_gradients_match_autograd(mode, Kg, L):
         np.testing.assert_allclose(out[name], g.numpy(), rtol=1e-10, atol=1e-10, err_msg=name)
     tr = o.minimize(cnt, P["Xc"], 5, 0.01, 1)
     assert np.all(np.isfinite(tr)) and np.abs(o.intercept).max() <= 9
+
+
+@pytest.mark.parametrize("L,Kc,MC,mode,Kg", [(2, 2, 1, "gene", 0), (3, 1, 4, "gene", 0), (2, 1, 3, "cell", 2)])
+def test_marginlik_gradients_match_autograd(L, Kc, MC, mode, Kg):
+    """target="marginLik" (model_TFProb.py:156-157,188-189,202-205)."""
+    Nc, Ng = 25, 16
+    P = make_problem(Nc, Ng, Kc=Kc, L=L, seed=8, depth=4.0)
+    Xg = np.random.default_rng(2).standard_normal((Ng, Kg))
+    cnt = add_pseudo_count(P["counts"])
+    o = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=3, dtype=np.float64, Kg=Kg, intercept_mode=mode)
+    o.Xg = Xg
+    init = {k: getattr(o, k).copy() for k in ("Z_loc", "Z_std_log", "Wc_loc", "Wg_loc", "intercept", "sigma_log")}
+    t = TorchBRIE2(Nc, Ng, Kc, effLen=P["effLen"], init=init, seed=3, dtype=torch.float64, Kg=Kg, intercept_mode=mode)
+    t.Xc = torch.as_tensor(P["Xc"], dtype=torch.float64)
+    t.Xg = torch.as_tensor(Xg, dtype=torch.float64)
+    out = o.margin_loss_and_grads(cnt, P["Xc"], MC_size=MC)
+    loss = t.get_margin_loss([torch.as_tensor(c, dtype=torch.float64) for c in cnt], None, MC)
+    vs = [v for v in t.variables() if v is not t.Z_loc and v is not t.Z_std_log]
+    grads = torch.autograd.grad(loss, vs)
+    assert abs(float(loss.detach()) - out["loss"]) < 1e-9 * max(1, abs(out["loss"]))
+    names = [n for n in o.trainable() if n not in ("Z_loc", "Z_std_log")]
+    for name, g in zip(names, grads):
+        np.testing.assert_allclose(out[name], g.numpy(), rtol=1e-9, atol=1e-9, err_msg=name)
+    z0 = o.Z_loc.copy()
+    tr = o.minimize(cnt, P["Xc"], 8, 0.02, MC, target="marginLik")
+    np.testing.assert_array_equal(o.Z_loc, z0)                   # the posterior is not part of this objective
+    assert np.all(np.isfinite(tr)) and tr[-1] < tr[0] + 1e-6 * abs(tr[0])

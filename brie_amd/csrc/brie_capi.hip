@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -38,6 +39,43 @@ int fail(int code, const char *fmt, ...) {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// rocBLAS, bound at run time (dlopen) and only for wide cell designs (Kc > 8): the two plain fp32
+// GEMMs  M = Xc . Wc_loc  and  G = Xc^T . r  run on the matrix cores (v_mfma_f32_*_f32) through the
+// vendor library; everything else in this library is hand-written HIP and does not link rocBLAS.
+// ---------------------------------------------------------------------------------------------------
+struct RocblasApi {
+    void *lib = nullptr;
+    int (*create)(void **) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*set_atomics)(void *, int) = nullptr;
+    int (*sgemm_sb)(void *, int, int, int, int, int, const float *, const float *, int, int64_t, const float *, int,
+                    int64_t, const float *, float *, int, int64_t, int) = nullptr;
+};
+constexpr int kRocblasOpN = 111, kRocblasOpT = 112;
+
+RocblasApi *rocblas_api() {
+    static RocblasApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.create = reinterpret_cast<decltype(api.create)>(dlsym(api.lib, "rocblas_create_handle"));
+            api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(api.lib, "rocblas_destroy_handle"));
+            api.set_stream = reinterpret_cast<decltype(api.set_stream)>(dlsym(api.lib, "rocblas_set_stream"));
+            api.set_atomics = reinterpret_cast<decltype(api.set_atomics)>(dlsym(api.lib, "rocblas_set_atomics_mode"));
+            api.sgemm_sb = reinterpret_cast<decltype(api.sgemm_sb)>(dlsym(api.lib, "rocblas_sgemm_strided_batched"));
+            if (!api.create || !api.destroy || !api.set_stream || !api.set_atomics || !api.sgemm_sb) api.lib = nullptr;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
 
 struct brie_handle {
     brie_problem p{};
@@ -72,6 +110,12 @@ struct brie_handle {
     bool have_xg = false;
     float *rowstat_ext = nullptr;   // caller-owned (6, Nc) buffer used instead of rowstat (multi-GPU all-reduce)
     int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
+    // wide cell designs (Kc > BRIE_MAX_KC): Xc.W and Xc^T.r through fp32 MFMA GEMMs
+    bool wide = false;
+    int kernel_kc = 0;              // KC of the kernel instantiation (0 for wide designs)
+    void *blas = nullptr;           // rocblas_handle
+    float *Mbuf = nullptr, *Rbuf = nullptr;   // (Nc, ld) tiled: Xc.Wc_loc, residual r
+    float *Gbuf = nullptr;          // (Kc, ld): Xc^T . r
     bool step_open = false;         // between brie_step_begin and brie_step_end
     brie::CellFinalizeArgs pending_cf{};
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
@@ -147,6 +191,7 @@ int check_ready(const brie_handle *h) {
 
 void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
                  const brie::StepScalars &a, const brie::CoupledArgs &cp) {
+    if (h->wide) { brie::launch_step_wide(c, q, a); return; }
     switch (h->p.Kc) {
 #define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a, cp); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
@@ -156,7 +201,7 @@ void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::Ste
 }
 void launch_margin(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
                    const brie::StepScalars &a) {
-    switch (h->p.Kc) {
+    switch (h->kernel_kc) {
 #define BRIE_CASE(N) case N: brie::launch_margin_kc##N(c, q, a); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
         default: brie::launch_margin_kc8(c, q, a); break;
@@ -164,7 +209,7 @@ void launch_margin(const brie_handle *h, const brie::LaunchCfg &c, const brie::S
     }
 }
 void launch_loss_gene(const brie_handle *h, const brie::LaunchCfg &c, const brie::LossGeneArgs &a) {
-    switch (h->p.Kc) {
+    switch (h->kernel_kc) {
 #define BRIE_CASE(N) case N: brie::launch_loss_gene_kc##N(c, a); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
         default: brie::launch_loss_gene_kc8(c, a); break;
@@ -292,8 +337,11 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_INVALID, "abi_version %d != %d", p->abi_version, BRIE_AMD_ABI_VERSION);
     if (p->Nc <= 0 || p->Ng <= 0 || p->Nc > INT32_MAX || p->Ng > INT32_MAX - 1024)
         return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
-    if (p->Kc < 0 || p->Kc > BRIE_MAX_KC)
-        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC);
+    if (p->Kc < 0 || p->Kc > BRIE_MAX_KC_WIDE)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_WIDE);
+    if (p->Kc > BRIE_MAX_KC && (p->Kg > 0 || p->intercept_mode == 1))
+        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d > %d (wide design) together with gene features / cell intercepts "
+                    "is not built", p->Kc, BRIE_MAX_KC);
     if (p->Kg < 0 || p->Kg > BRIE_MAX_KG)
         return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
@@ -324,7 +372,9 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         if (h->tiled) { h->row_stride = brie::kGenesPerBlock; h->gb_stride = p->Nc * brie::kGenesPerBlock; }
         else { h->row_stride = h->ld; h->gb_stride = brie::kGenesPerBlock; }
     }
-    h->S = p->Kc + 4;
+    h->wide = p->Kc > BRIE_MAX_KC;
+    h->kernel_kc = h->wide ? 0 : p->Kc;
+    h->S = h->kernel_kc + 4;
     h->mode = !p->has_efflen ? brie::kLik2 : (p->n_layers == 3 ? brie::kLikEff3 : brie::kLikEff2);
     int rc = set_device(h);
     if (rc != BRIE_OK) { delete h; return rc; }
@@ -342,6 +392,15 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->lam, vec); A(h->m_lam, vec); A(h->v_lam, vec);
     A(h->effL, vec * 6);
     A(h->gene_tmp, vec);
+    if (h->wide) {
+        RocblasApi *rb = rocblas_api();
+        if (!rb) { brie_destroy(h); return fail(BRIE_ERR_HIP, "Kc=%d needs librocblas.so (not found)", p->Kc); }
+        if (rb->create(&h->blas) != 0 || rb->set_stream(h->blas, h->stream) != 0 || rb->set_atomics(h->blas, 0) != 0) {
+            brie_destroy(h);
+            return fail(BRIE_ERR_HIP, "rocblas_create_handle failed");
+        }
+        A(h->Mbuf, mat); A(h->Rbuf, mat); A(h->Gbuf, vec * p->Kc);
+    }
     h->cell_mode = p->intercept_mode == 1;
     h->coupled = p->Kg > 0 || h->cell_mode;
     if (h->coupled) {
@@ -375,12 +434,13 @@ int brie_destroy(brie_handle *h) {
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
-                     h->m_clam, h->v_clam, h->row_partials, h->rowstat};
+                     h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gbuf};
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
     for (void *q : h->cu)
         if (q) hipFree(q);
+    if (h->blas && rocblas_api()) rocblas_api()->destroy(h->blas);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -558,7 +618,7 @@ int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk) {
 int brie_set_target(brie_handle *h, int32_t target) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (target != 0 && target != 1) return fail(BRIE_ERR_INVALID, "target %d (0 = ELBO, 1 = marginLik)", target);
-    if (target == 1 && h->coupled)
+    if (target == 1 && (h->coupled || h->wide))
         return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts is not built");
     h->target = target;
     return BRIE_OK;
@@ -581,17 +641,39 @@ int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
 int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
     const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
-    return h->p.Nc * h->p.Ng * (48 + per_count * static_cast<int64_t>(h->p.n_layers));
+    const int64_t gemm_streams = h->wide ? 16 : 0;       // M written+read, r written+read (4 B each way)
+    return h->p.Nc * h->p.Ng * (48 + per_count * static_cast<int64_t>(h->p.n_layers) + gemm_streams);
 }
 
 int64_t brie_step_algorithmic_bytes(const brie_handle *h) {
     if (!h) return 0;
-    return h->p.Nc * h->p.Ng * (48 + 4 * static_cast<int64_t>(h->p.n_layers));
+    return h->p.Nc * h->p.Ng * (48 + 4 * static_cast<int64_t>(h->p.n_layers));     // SURVEY 8d fp32 model
 }
 
 }  // extern "C"
 
 namespace {
+
+// Wide designs.  All cell x gene buffers are gene-block tiles [g][Nc][256] (row-major Nc x 256, i.e.
+// column-major 256 x Nc with ld 256), W / G are (Kc, ld) row-major = column-major (ld x Kc):
+//   M_g (256 x Nc) = W_g (256 x Kc, lda = ld) . Xc^T (Kc x Nc, ldb = Kc)          -> gemm_prior_mean
+//   G_g (256 x Kc, ldc = ld) = R_g (256 x Nc, lda = 256) . Xc (Nc x Kc) = op_T(Xc^T) -> gemm_design_grad
+int gemm_prior_mean(brie_handle *h) {
+    const float one = 1.0f, zero = 0.0f;
+    const int rc = rocblas_api()->sgemm_sb(h->blas, kRocblasOpN, kRocblasOpN, brie::kGenesPerBlock,
+                                           static_cast<int>(h->p.Nc), h->p.Kc, &one, h->W, static_cast<int>(h->ld),
+                                           brie::kGenesPerBlock, h->Xc, h->p.Kc, 0, &zero, h->Mbuf,
+                                           brie::kGenesPerBlock, h->gb_stride, h->gene_blocks);
+    return rc == 0 ? BRIE_OK : fail(BRIE_ERR_HIP, "rocblas_sgemm_strided_batched (Xc.W) status %d", rc);
+}
+int gemm_design_grad(brie_handle *h) {
+    const float one = 1.0f, zero = 0.0f;
+    const int rc = rocblas_api()->sgemm_sb(h->blas, kRocblasOpN, kRocblasOpT, brie::kGenesPerBlock, h->p.Kc,
+                                           static_cast<int>(h->p.Nc), &one, h->Rbuf, brie::kGenesPerBlock,
+                                           h->gb_stride, h->Xc, h->p.Kc, 0, &zero, h->Gbuf, static_cast<int>(h->ld),
+                                           brie::kGenesPerBlock, h->gene_blocks);
+    return rc == 0 ? BRIE_OK : fail(BRIE_ERR_HIP, "rocblas_sgemm_strided_batched (Xc^T.r) status %d", rc);
+}
 
 // split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell
 // statistics `rowstat`, which a gene-sharded coupled fit all-reduces across ranks before brie_step_end.
@@ -603,8 +685,10 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (split == 0 && h->coupled && h->p.reserved != 0)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: use brie_step_begin / "
                     "all-reduce brie_rowstat_buffer / brie_step_end");
-    if (h->target == 1 && h->coupled)
-        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts is not built");
+    if (h->target == 1 && (h->coupled || h->wide))
+        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts / Kc > %d is not built",
+                    BRIE_MAX_KC);
+    if (h->wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
@@ -640,6 +724,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     a.pc = h->pc;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
+    cfg.mbuf = h->Mbuf; cfg.rbuf = h->Rbuf;
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
     cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0;
@@ -654,7 +739,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
     f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
-    f.Ng = a.Ng; f.Kc = h->p.Kc; f.n_chunks = h->n_chunks;
+    f.Ng = a.Ng; f.Kc = h->kernel_kc; f.n_chunks = h->n_chunks;
     f.train_b = h->cell_mode ? 0 : h->p.train_intercept;        // cell mode: the (1,Ng) vectors are not parameters
     f.train_lam = h->cell_mode ? 0 : h->p.train_sigma;
 
@@ -666,11 +751,18 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         a.alpha = alpha; f.alpha = alpha; cf.alpha = alpha;
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
+        if (h->wide && (rc = gemm_prior_mean(h)) != BRIE_OK) return rc;          // M = Xc . Wc_loc (MFMA)
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         if (h->target == 1) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
+        if (h->wide) {                                                           // G = Xc^T . r (MFMA), Adam on Wc_loc
+            if ((rc = gemm_design_grad(h)) != BRIE_OK) return rc;
+            const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
+            hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W,
+                               h->Gbuf, nW, alpha);
+        }
         if (h->coupled)
             hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
                                dim3(brie::kBlock), 0, h->stream, cf);
@@ -762,6 +854,12 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.pc = h->pc;
     a.coupled = h->coupled ? 1 : 0;
     a.margin = h->target == 1 ? 1 : 0;
+    a.mbuf = nullptr;
+    if (h->wide) {
+        if (h->target == 1) return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with Kc > %d is not built", BRIE_MAX_KC);
+        if ((rc = gemm_prior_mean(h)) != BRIE_OK) return rc;
+        a.mbuf = h->Mbuf;
+    }
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;
     a.cp.Kg = h->p.Kg; a.cp.cell_mode = h->cell_mode ? 1 : 0;
     a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;

@@ -307,8 +307,8 @@ __device__ __forceinline__ void decode_counts(const CountRegs<CS> &C, float pc, 
     }
 }
 
-// the vectors one lane holds for one cell row
-template <int CS> struct RowRegs { CountRegs<CS> cnt; F4 mu, rho, mm, vm, mr, vr; };
+// the vectors one lane holds for one cell row (mp: Xc.Wc_loc from the GEMM, wide designs only)
+template <int CS> struct RowRegs { CountRegs<CS> cnt; F4 mu, rho, mm, vm, mr, vr, mp; };
 
 constexpr float kOneMinusB1 = 1.0f - 0.9f;      // as Keras computes it in fp32
 constexpr float kOneMinusB2 = 1.0f - 0.999f;
@@ -323,14 +323,20 @@ constexpr float kAdamEps = 1e-7f;
 // one straight-line basic block, which is what lets the next row's loads stay
 // in flight across it); MC == 0: run-time count a.mc.
 // ----------------------------------------------------------------------------
-template <int KC, int MODE, int MC, int CS, bool CPL>
+// WIDE (only with KC == 0): wide cell designs (Kc > 8).  The prior-mean term Xc.Wc_loc is computed
+// by an fp32 MFMA GEMM (rocBLAS) into `mbuf` before the launch and read here as one more 16-B
+// stream; the residual r = (mu - m)/sigma^2 is written to `rbuf` and Xc^T.r is a second GEMM after
+// the launch (wide_design in brie_capi.hip).  Costs 8 extra bytes per element, no Kc-sized register state.
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
-    const StepScalars a, const CoupledArgs cp) {
+    const StepScalars a, const CoupledArgs cp, const float *__restrict__ mbuf = nullptr,
+    float *__restrict__ rbuf = nullptr) {
+    static_assert(!WIDE || KC == 0, "the wide-design variant carries no in-kernel Xc.W");
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
@@ -404,6 +410,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.clam = cp.clam[r];
             }
             load_counts<CS, MODE>(c1p, c2p, c3p, off, R.cnt);
+            if constexpr (WIDE) R.mp = ld4s(mbuf + off);
             R.mu = ld4s(mu_p + off);
             R.rho = ld4s(rho_p + off);
             R.mm = ld4s(mmu_p + off);
@@ -449,6 +456,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 float m = cell ? rs.cb : bj[v];
+                if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc from the GEMM
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
                 if constexpr (CPL) {
@@ -478,6 +486,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
                 R.mu.v[v] = nmu;
                 R.rho.v[v] -= (R.mr.v[v] * a.alpha) * f_rcp(f_sqrt(R.vr.v[v]) + kAdamEps);
+                if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for the Xc^T.r GEMM
                 // per-gene sufficient statistics
 #pragma unroll
                 for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
@@ -493,6 +502,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 st4s(vmu_p + off, R.vm);
                 st4s(mrho_p + off, R.mr);
                 st4s(vrho_p + off, R.vr);
+                if constexpr (WIDE) st4s(rbuf + off, R.mp);
             }
             if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
 #pragma unroll
@@ -656,6 +666,7 @@ struct LossGeneArgs {
     float pc;
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
+    const float *mbuf;      // wide designs: Xc.Wc_loc from the GEMM (KC == 0 instantiation), else null
     CoupledArgs cp;
 };
 
@@ -733,6 +744,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
                 s[v] = f_exp(rho.v[v]);
                 zc[v] = mu.v[v];
                 float m = cell ? cbr : bj[v];
+                if (a.mbuf) m += a.mbuf[off + v];
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(a.Xc[static_cast<int64_t>(r) * KC + k], Wk[k][v], m);
 #pragma unroll
@@ -969,6 +981,16 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
         float x = a.clam[i], m = a.m_clam[i], v = a.v_clam[i];
         adam_scalar(x, m, v, t, a.alpha);
         a.clam[i] = x; a.m_clam[i] = m; a.v_clam[i] = v;
+    }
+}
+
+// wide designs: Adam for Wc_loc from G = Xc^T . r (GEMM output), dL/dW = -G
+__global__ void wide_w_adam(float *W, float *mW, float *vW, const float *G, int64_t n, float alpha) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float x = W[i], m = mW[i], v = vW[i];
+        adam_scalar(x, m, v, -G[i], alpha);
+        W[i] = x; mW[i] = m; vW[i] = v;
     }
 }
 

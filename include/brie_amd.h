@@ -75,7 +75,7 @@ typedef struct brie_problem {
     int64_t Ng;               /* genes in this shard */
     int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
                                  keys the noise stream so results do not depend on sharding */
-    int32_t Kc;               /* cell features (0..BRIE_MAX_KC) */
+    int32_t Kc;               /* cell features (0..BRIE_MAX_KC_WIDE) */
     int32_t Kg;               /* gene features (0..BRIE_MAX_KG); > 0 couples the genes of a shard */
     int32_t n_layers;         /* 2 or 3 count layers */
     int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
@@ -88,7 +88,8 @@ typedef struct brie_problem {
     uint64_t seed;            /* key of the Philox4x32-10 noise stream */
 } brie_problem;
 
-#define BRIE_MAX_KC 8
+#define BRIE_MAX_KC 8         /* cell features fused into the streaming kernel (Xc row in SGPRs) */
+#define BRIE_MAX_KC_WIDE 64   /* wider designs: Xc.W and Xc^T.r as fp32 MFMA GEMMs (rocBLAS, loaded at run time) */
 #define BRIE_MAX_KG 4
 
 typedef struct brie_handle brie_handle;

@@ -37,6 +37,7 @@ def test_capi_exports_every_declared_symbol(built_lib):
 def test_capi_struct_layout_matches_header():
     import ctypes
     from brie_amd import _capi
+    assert _capi.MAX_KC == 64 and _capi.MAX_KG == 4
     assert ctypes.sizeof(_capi.BrieProblem) == 72
     assert _capi.BrieProblem.seed.offset == 64 and _capi.BrieProblem.Kc.offset == 32
 

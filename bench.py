@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="strong: the config's genes are sharded over ranks (BASELINE configs[3]); "
                          "weak: every rank fits the whole config")
+    ap.add_argument("--kc", type=int, default=None, help="override the config's number of cell covariates (experiments)")
     ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--count-storage", default="auto", choices=["auto", "f32"],
                     help="auto: integer counts <= 255 are kept as u8 in HBM (bit-identical results); f32: as uploaded")
@@ -132,6 +133,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = dict(CONFIGS[args.config])
+    if args.kc is not None:
+        cfg["Kc"] = args.kc
+        cfg["desc"] += " [Kc overridden to %d]" % args.kc
     Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
     if args.scaling == "strong":
         g0, g1 = gene_shard(Ng, rank, world)
@@ -225,7 +229,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
                 "%s_%s" % (args.config, sh.count_storage))
-            if pmc and world == 1 and args.mc == 1:
+            if pmc and world == 1 and args.mc == 1 and args.kc is None:
                 traffic = pmc["hbm_bytes_per_launch"]
         except (OSError, ValueError):
             pass

@@ -20,7 +20,7 @@ MAX_KC = 64          # 0..8 fused in the streaming kernel, 9..64 through the MFM
 MAX_KG = 4
 
 EXPORTS = [
-    "brie_create", "brie_destroy", "brie_upload", "brie_add_pseudo_count", "brie_init_state",
+    "brie_create", "brie_destroy", "brie_upload", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
     "brie_step_end", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
@@ -62,6 +62,7 @@ def load_library(path=None):
     lib.brie_create.argtypes = [ctypes.POINTER(BrieProblem), ctypes.POINTER(vp)]
     lib.brie_destroy.argtypes = [vp]
     lib.brie_upload.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
+    lib.brie_upload_sparse.argtypes = [vp, ctypes.c_int, i32, vp, vp, vp, i64, i64, i64]
     lib.brie_add_pseudo_count.argtypes = [vp, f32]
     lib.brie_init_state.argtypes = [vp, f32, f32]
     lib.brie_reset_optimizer.argtypes = [vp]
@@ -171,6 +172,21 @@ class Shard(object):
             pass
 
     def upload(self, which, x):
+        if hasattr(x, "tocsc") and hasattr(x, "indptr") is False:
+            x = x.tocsc()
+        if hasattr(x, "indptr") and hasattr(x, "indices"):           # scipy CSC / CSR: densified on the device
+            fmt = 1 if x.format == "csr" else 0
+            if x.format not in ("csc", "csr"):
+                x = x.tocsc()
+            indptr = np.ascontiguousarray(x.indptr, np.int64)
+            indices = np.ascontiguousarray(x.indices, np.int32)
+            data = np.ascontiguousarray(x.data, np.float32)
+            _check(self.lib, self.lib.brie_upload_sparse(
+                self._h, which, fmt, indptr.ctypes.data_as(ctypes.c_void_p), indices.ctypes.data_as(ctypes.c_void_p),
+                data.ctypes.data_as(ctypes.c_void_p), int(x.nnz), x.shape[0], x.shape[1]))
+            return
+        if hasattr(x, "tocsc"):                                       # other scipy sparse formats
+            return self.upload(which, x.tocsc())
         ptr, rows, cols, ld, keep = _matrix_pointer(x)
         _check(self.lib, self.lib.brie_upload(self._h, which, ptr, rows, cols, ld))
         del keep

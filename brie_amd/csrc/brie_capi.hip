@@ -520,6 +520,51 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     return BRIE_OK;
 }
 
+int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t *indptr, const int32_t *indices,
+                       const float *data, int64_t nnz, int64_t rows, int64_t cols) {
+    if (!h || !indptr || (nnz > 0 && (!indices || !data))) return fail(BRIE_ERR_INVALID, "null argument");
+    if (which < BRIE_COUNT1 || which > BRIE_COUNT3 || which - BRIE_COUNT1 >= h->p.n_layers)
+        return fail(BRIE_ERR_INVALID, "brie_upload_sparse takes a count layer (got array %d)", which);
+    if (format != 0 && format != 1) return fail(BRIE_ERR_INVALID, "format %d (0 = CSC, 1 = CSR)", format);
+    if (rows != h->p.Nc || cols != h->p.Ng)
+        return fail(BRIE_ERR_INVALID, "layer must be (%lld, %lld), got (%lld, %lld)", (long long)h->p.Nc,
+                    (long long)h->p.Ng, (long long)rows, (long long)cols);
+    if (nnz < 0) return fail(BRIE_ERR_INVALID, "nnz=%lld", (long long)nnz);
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "sparse upload needs the tiled layout");
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->cs != brie::kCountF32 || h->compact_tried) {
+        if ((rc = expand_counts(h)) != BRIE_OK) return rc;
+        h->compact_tried = false;
+        const char *cst = getenv("BRIE_COUNT_STORAGE");
+        h->allow_compact = !(cst && strcmp(cst, "f32") == 0);
+    }
+    const int64_t n_major = format == 1 ? rows : cols;
+    int64_t *d_ptr = nullptr;
+    int32_t *d_idx = nullptr;
+    float *d_val = nullptr;
+    auto cleanup = [&]() { hipFree(d_ptr); hipFree(d_idx); hipFree(d_val); };
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_ptr), (n_major + 1) * sizeof(int64_t));
+    if (e == hipSuccess && nnz > 0) e = hipMalloc(reinterpret_cast<void **>(&d_idx), nnz * sizeof(int32_t));
+    if (e == hipSuccess && nnz > 0) e = hipMalloc(reinterpret_cast<void **>(&d_val), nnz * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, indptr, (n_major + 1) * sizeof(int64_t), hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_idx, indices, nnz * sizeof(int32_t), hipMemcpyDefault, h->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_val, data, nnz * sizeof(float), hipMemcpyDefault, h->stream);
+    float *dst = h->c[which - BRIE_COUNT1];
+    if (e == hipSuccess) e = hipMemsetAsync(dst, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream);
+    if (e == hipSuccess && nnz > 0) {
+        hipLaunchKernelGGL(brie::scatter_sparse, dim3(static_cast<unsigned>(n_major)), dim3(128), 0, h->stream, d_ptr,
+                           d_idx, d_val, dst, n_major, format, h->row_stride, h->gb_stride);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "sparse upload: %s", hipGetErrorString(e));
+    h->have_c[which - BRIE_COUNT1] = true;
+    return BRIE_OK;
+}
+
 int brie_add_pseudo_count(brie_handle *h, float pc) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (!h->have_c[0] || !h->have_c[1]) return fail(BRIE_ERR_STATE, "count layers 1 and 2 not uploaded");

@@ -1081,6 +1081,20 @@ __global__ void pseudo_count(float *c1, float *c2, int64_t n4, float pc) {
     }
 }
 
+// Densify a compressed sparse layer on the device (the reference calls .toarray() on the host,
+// model_wrap.py:108-111 / model_TFProb.py:135-137).  major = gene (CSC) or cell (CSR); one block per
+// major index, duplicates are summed like scipy's toarray().  dst is the zeroed tiled fp32 layer.
+__global__ void scatter_sparse(const int64_t *indptr, const int32_t *indices, const float *data, float *dst,
+                               int64_t n_major, int csr, int64_t row_stride, int64_t gb_stride) {
+    const int64_t major = blockIdx.x;
+    if (major >= n_major) return;
+    for (int64_t p = indptr[major] + threadIdx.x; p < indptr[major + 1]; p += blockDim.x) {
+        const int64_t r = csr ? major : indices[p];
+        const int64_t j = csr ? indices[p] : major;
+        atomicAdd(dst + (j / kGenesPerBlock) * gb_stride + r * row_stride + (j % kGenesPerBlock), data[p]);
+    }
+}
+
 // flag bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255
 __global__ void count_range_check(const float *c, int64_t n4, int *flag) {
     int bad = 0;

@@ -38,10 +38,9 @@ def _wrap(a):
 
 
 def _dense_f32(x):
-    """logLik_MC densifies sparse layers (model_TFProb.py:135-137)."""
-    if hasattr(x, "toarray"):
-        x = x.toarray()
-    if hasattr(x, "data_ptr"):
+    """logLik_MC densifies sparse layers on the host (model_TFProb.py:135-137); here scipy sparse
+    layers are handed to the library as they are and densified on the device (brie_upload_sparse)."""
+    if hasattr(x, "tocsc") or hasattr(x, "data_ptr"):
         return x
     return np.ascontiguousarray(x, dtype=np.float32)
 

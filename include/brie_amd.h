@@ -103,6 +103,13 @@ int brie_destroy(brie_handle *h);
 int brie_upload(brie_handle *h, int which, const float *src,
                 int64_t rows, int64_t cols, int64_t ld);
 
+/* A count layer given as scipy-style compressed sparse (format 0 = CSC: indptr per gene, indices =
+ * cells; 1 = CSR: indptr per cell, indices = genes; int64 indptr, int32 indices, fp32 data; host or
+ * device pointers).  Densified ON THE DEVICE (duplicates summed) -- the reference densifies on the
+ * host with .toarray() (model_wrap.py:108-111, model_TFProb.py:135-137). */
+int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t *indptr,
+                       const int32_t *indices, const float *data, int64_t nnz, int64_t rows, int64_t cols);
+
 /* model_wrap.py:113-117: where count1+count2 > 0 add `pseudo_count` to BOTH
  * unique layers -- applied to the device copy, caller arrays are untouched. */
 int brie_add_pseudo_count(brie_handle *h, float pseudo_count);

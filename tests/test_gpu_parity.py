@@ -354,3 +354,31 @@ def test_wide_cell_design_matches_oracle(lib, Kc, L, MC):
     assert_states_close(util.oracle_state(o), util.device_state(sh), bulk=5e-5)
     np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
     assert sh.step_storage_bytes() > sh.step_algorithmic_bytes() - Nc * Ng * 4 * L     # + 16 B/element of GEMM streams
+
+
+def test_sparse_layers_densified_on_device(lib):
+    """CSC / CSR / COO count layers (model_wrap.py:108-111 densifies on the host) incl. duplicate entries."""
+    import scipy.sparse as sp
+    from brie_amd import _capi
+    Nc, Ng, Kc = 70, 530, 1
+    P = util.problem(Nc, Ng, Kc, 2, seed=61)
+    dense = util.device_shard(P, Nc, Ng, Kc, 67)
+    for conv in (sp.csc_matrix, sp.csr_matrix, sp.coo_matrix):
+        Q = dict(P, counts=[conv(c) for c in P["counts"]])
+        sh = util.device_shard(Q, Nc, Ng, Kc, 67)
+        np.testing.assert_array_equal(sh.read(_capi.COUNT1), P["counts_pc"][0])
+        np.testing.assert_array_equal(sh.step(3, 0.01, 1), util.device_shard(P, Nc, Ng, Kc, 67).step(3, 0.01, 1))
+    # duplicates are summed like scipy's toarray()
+    rows, cols, vals = np.array([0, 0, 5, 5]), np.array([3, 3, 7, 7]), np.array([1, 2, 4, 4], np.float32)
+    dup = sp.csc_matrix((vals, (rows, cols)), shape=(Nc, Ng))
+    dup.has_canonical_format = False
+    raw = sp.csc_matrix((Nc, Ng), dtype=np.float32)
+    raw.indptr, raw.indices, raw.data = np.zeros(Ng + 1, np.int32), np.array([0, 0, 5, 5], np.int32), vals
+    raw.indptr[4:] = 2
+    raw.indptr[8:] = 4
+    sh = _capi.Shard(Nc, Ng, 0)
+    sh.upload(_capi.COUNT1, raw)
+    sh.upload(_capi.COUNT2, np.zeros((Nc, Ng), np.float32))
+    got = sh.read(_capi.COUNT1)
+    assert got[0, 3] == 3 and got[5, 7] == 8 and got.sum() == 11
+    dense.close()

@@ -157,9 +157,10 @@ void configure_tiling(brie_handle *h) {
     if (rpc <= 0) {
         // A function of Nc ONLY (never of the shard's gene count): the per-gene fp32 partial sums are
         // then formed in the same order however the genes are sharded, so a gene's trajectory is
-        // bit-identical in a 1-GPU fit and in any gene shard.  Aim for >= 256 cell chunks.
+        // bit-identical in a 1-GPU fit and in any gene shard.  Aim for >= 128 cell chunks (measured best:
+        // 256 rows at Nc = 50k, 64 rows at Nc = 10k; profiles/r01_rows_per_chunk.log).
         rpc = 256;
-        while (rpc > 16 && (Nc + rpc - 1) / rpc < 256) rpc /= 2;
+        while (rpc > 16 && (Nc + rpc - 1) / rpc < 128) rpc /= 2;
     }
     h->rows_per_chunk = rpc;
     h->n_chunks = static_cast<int>((Nc + rpc - 1) / rpc);

@@ -123,3 +123,19 @@ def test_cli_quant_end_to_end_on_gpu(lib, tmp_path):
     strong = np.abs(truth) > 0.7
     if strong.sum() >= 3:
         assert np.corrcoef(df['group_ceoff'].values[strong], truth[strong])[0, 1] > 0.7
+
+
+def test_fitBRIE_emulated_reference_batches_on_gpu(lib):
+    """emulate_batches=True reproduces the reference's sequential gene batches (model_wrap.py:241-260): each
+    batch has its own fit and loss trace; per-gene results equal the concurrent fit up to fp32 summation order."""
+    import brie_amd
+    Nc, Ng = 40, 36
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=83)
+    mk = lambda: FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    kw = dict(Xc=P["Xc"], min_iter=120, max_iter=120, n_loss_gene=10, verbose=False, seed=3)
+    whole = brie_amd.fitBRIE(mk(), **kw)
+    batched = brie_amd.fitBRIE(mk(), batch_size=Nc * 12, emulate_batches=True, **kw)
+    assert len(batched.losses) == 3 * len(whole.losses) and batched.Ng == Ng
+    np.testing.assert_allclose(batched.Psi, whole.Psi, atol=1e-5)
+    np.testing.assert_allclose(batched.loss_gene, whole.loss_gene, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(batched.losses.reshape(3, -1).sum(0), whole.losses, rtol=1e-5)

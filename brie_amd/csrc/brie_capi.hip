@@ -931,19 +931,28 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
     if (rc != BRIE_OK) return rc;
     if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
-    if (which == BRIE_PSI || which == BRIE_Z_STD || which == BRIE_PSI95CI) {
+    if (which == BRIE_PSI || which == BRIE_Z_STD || which == BRIE_PSI95CI || which == BRIE_Z_LOC ||
+        which == BRIE_Z_STD_LOG) {
         if (rows != Nc || cols != Ng)
             return fail(BRIE_ERR_INVALID, "array %d must be (%lld, %lld)", which, (long long)Nc, (long long)Ng);
+        // kernel writes the array row-major and contiguous, then ONE copy crosses PCIe
+        const int mode = which == BRIE_Z_LOC ? 3 : (which == BRIE_Z_STD_LOG ? 4 : which - BRIE_PSI);
         float *tmp = nullptr;
-        const int64_t n4 = Nc * h->ld / 4;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * h->ld * sizeof(float)));
-        hipLaunchKernelGGL(brie::psi_epilogue, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->mu, h->rho, tmp, n4,
-                           which - BRIE_PSI);
-        rc = copy_cellgene(h, tmp, nullptr, dst, ld);
-        hipError_t e = hipStreamSynchronize(h->stream);
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * Ng * sizeof(float)));
+        hipLaunchKernelGGL(brie::export_rowmajor, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * Nc * brie::kWave)),
+                           dim3(256), 0, h->stream, h->mu, h->rho, tmp, static_cast<int>(Nc), static_cast<int>(Ng),
+                           h->gene_blocks, h->row_stride, h->gb_stride, mode);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) {
+            if (ld == cols)
+                e = hipMemcpyAsync(dst, tmp, static_cast<size_t>(Nc) * Ng * sizeof(float), hipMemcpyDefault, h->stream);
+            else
+                e = hipMemcpy2DAsync(dst, ld * sizeof(float), tmp, Ng * sizeof(float), Ng * sizeof(float), Nc,
+                                     hipMemcpyDefault, h->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         hipFree(tmp);
-        if (rc != BRIE_OK) return rc;
-        if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read derived array: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read array %d: %s", which, hipGetErrorString(e));
         return BRIE_OK;
     }
     if (which == BRIE_SIGMA) {

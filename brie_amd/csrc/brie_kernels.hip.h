@@ -1173,6 +1173,41 @@ __global__ void psi_epilogue(const float *mu, const float *rho, float *out, int6
     }
 }
 
+// Read-back kernel: state / derived array -> ROW-MAJOR (Nc, Ng) contiguous buffer (one coalesced 1-KiB
+// store per wave), so the D2H leg is a single contiguous copy.
+// mode 0 Psi, 1 Z_std, 2 Psi 95% CI width, 3 Z_loc, 4 Z_std_log
+__global__ void export_rowmajor(const float *mu, const float *rho, float *out, int Nc, int Ng, int gene_blocks,
+                                int64_t row_stride, int64_t gb_stride, int mode) {
+    constexpr float kZ975 = 1.959963984540054f;     // ndtri(0.975)
+    const int64_t total = static_cast<int64_t>(gene_blocks) * Nc * kWave;
+    const bool vec_ok = (Ng % kVec) == 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int lane = static_cast<int>(i % kWave);
+        const int r = static_cast<int>((i / kWave) % Nc);
+        const int g = static_cast<int>(i / (static_cast<int64_t>(kWave) * Nc));
+        const int j0 = (g * kWave + lane) * kVec;
+        if (j0 >= Ng) continue;
+        const int64_t off = g * gb_stride + r * row_stride + lane * kVec;
+        const F4 m = ld4(mu + off), q = ld4(rho + off);
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            if (mode == 0) o.v[v] = sigmoid_acc(m.v[v]);
+            else if (mode == 1) o.v[v] = expf(q.v[v]);
+            else if (mode == 2) {
+                const float s = expf(q.v[v]);
+                o.v[v] = sigmoid_acc(m.v[v] + kZ975 * s) - sigmoid_acc(m.v[v] - kZ975 * s);
+            } else if (mode == 3) o.v[v] = m.v[v];
+            else o.v[v] = q.v[v];
+        }
+        float *dst = out + static_cast<int64_t>(r) * Ng + j0;
+        if (vec_ok) st4(dst, o);
+        else
+            for (int v = 0; v < kVec && j0 + v < Ng; ++v) dst[v] = o.v[v];
+    }
+}
+
 __global__ void exp_vec(const float *src, float *dst, int n) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n) dst[j] = expf(src[j]);

@@ -22,7 +22,7 @@ MAX_KG = 4
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
-    "brie_step_end", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
+    "brie_step_end", "brie_set_gene_mask", "brie_read_loss_window", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
     "brie_get_count_storage", "brie_calibrate_stream", "brie_last_error", "brie_abi_version",
@@ -71,6 +71,8 @@ def load_library(path=None):
     lib.brie_rowstat_buffer.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(i64)]
     lib.brie_set_rowstat_buffer.argtypes = [vp, vp]
     lib.brie_step_end.argtypes = [vp, ctypes.POINTER(f32)]
+    lib.brie_set_gene_mask.argtypes = [vp, vp]
+    lib.brie_read_loss_window.argtypes = [vp, i32, vp]
     lib.brie_set_target.argtypes = [vp, i32]
     lib.brie_loss_gene.argtypes = [vp, i32, vp]
     lib.brie_read.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
@@ -225,6 +227,22 @@ class Shard(object):
             allreduce_inplace(stat_tensor)          # blocks until the reduced values are visible
             _check(self.lib, self.lib.brie_step_end(self._h, ctypes.byref(loss)))
             out[i] = loss.value
+        return out
+
+    def set_gene_mask(self, active=None):
+        """Per-gene train mask (bool (Ng,)); None = all genes active."""
+        if active is None:
+            _check(self.lib, self.lib.brie_set_gene_mask(self._h, None))
+            return
+        a = np.ascontiguousarray(np.asarray(active).astype(np.uint8))
+        if a.shape != (self.Ng,):
+            raise ValueError("mask must have shape (%d,)" % self.Ng)
+        _check(self.lib, self.lib.brie_set_gene_mask(self._h, a.ctypes.data_as(ctypes.c_void_p)))
+
+    def read_loss_window(self, n_last):
+        """(n_last, Ng) per-gene losses of the last steps, oldest first."""
+        out = np.empty((int(n_last), self.Ng), np.float32)
+        _check(self.lib, self.lib.brie_read_loss_window(self._h, int(n_last), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
     def set_target(self, target):

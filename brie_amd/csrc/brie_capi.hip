@@ -119,6 +119,10 @@ struct brie_handle {
     bool step_open = false;         // between brie_step_begin and brie_step_end
     brie::CellFinalizeArgs pending_cf{};
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
+    float *gene_active = nullptr;   // (ld) per-gene train mask (per-batch convergence), default all ones
+    int32_t *block_active = nullptr;   // (gene_blocks)
+    float *ring_kl = nullptr, *ring_ll = nullptr;   // (kLossRing, ld) per-gene loss terms of the last steps
+    int64_t ring_pos = 0;           // optimisation steps taken so far
     float *partials = nullptr;
     size_t partials_elems = 0;
     double *loss_parts = nullptr;
@@ -393,6 +397,9 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->lam, vec); A(h->m_lam, vec); A(h->v_lam, vec);
     A(h->effL, vec * 6);
     A(h->gene_tmp, vec);
+    A(h->gene_active, vec);
+    A(h->ring_kl, vec * brie::kLossRing);
+    A(h->ring_ll, vec * brie::kLossRing);
     if (h->wide) {
         RocblasApi *rb = rocblas_api();
         if (!rb) { brie_destroy(h); return fail(BRIE_ERR_HIP, "Kc=%d needs librocblas.so (not found)", p->Kc); }
@@ -414,6 +421,11 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     }
 #undef A
     configure_tiling(h);
+    {
+        e = hipMalloc(reinterpret_cast<void **>(&h->block_active), h->gene_blocks * sizeof(int32_t));
+        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+        if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { brie_destroy(h); return rc; }
+    }
     if (h->coupled) {
         float *rp = nullptr;
         if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * brie::kRowStats * p->Nc, h->stream)) != BRIE_OK) {
@@ -435,10 +447,12 @@ int brie_destroy(brie_handle *h) {
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
-                     h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gbuf};
+                     h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gbuf, h->gene_active,
+                     h->ring_kl, h->ring_ll};
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
+    if (h->block_active) hipFree(h->block_active);
     for (void *q : h->cu)
         if (q) hipFree(q);
     if (h->blas && rocblas_api()) rocblas_api()->destroy(h->blas);
@@ -661,6 +675,44 @@ int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk) {
     return BRIE_OK;
 }
 
+int brie_set_gene_mask(brie_handle *h, const uint8_t *active) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    if (active && h->coupled)
+        return fail(BRIE_ERR_UNSUPPORTED, "per-gene freezing is meaningless for coupled fits (one joint problem)");
+    std::vector<float> mask(static_cast<size_t>(h->ld), 0.0f);
+    std::vector<int32_t> blocks(static_cast<size_t>(h->gene_blocks), 0);
+    for (int64_t j = 0; j < h->p.Ng; ++j) {
+        const bool on = active ? active[j] != 0 : true;
+        mask[j] = on ? 1.0f : 0.0f;
+        if (on) blocks[j / brie::kGenesPerBlock] = 1;
+    }
+    HIP_TRY(hipMemcpyAsync(h->gene_active, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->block_active, blocks.data(), blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BRIE_OK;
+}
+
+int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out) {
+    if (!h || !out) return fail(BRIE_ERR_INVALID, "null argument");
+    if (n_last < 1 || n_last > brie::kLossRing || n_last > h->ring_pos)
+        return fail(BRIE_ERR_INVALID, "n_last=%d (ring holds %d steps, %lld taken)", n_last, brie::kLossRing,
+                    (long long)h->ring_pos);
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    float *tmp = nullptr;
+    const size_t n = static_cast<size_t>(n_last) * h->p.Ng;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), n * sizeof(float)));
+    hipLaunchKernelGGL(brie::loss_window, dim3(h->fin_blocks, n_last), dim3(brie::kBlock), 0, h->stream, h->ring_kl,
+                       h->ring_ll, tmp, h->ld, static_cast<int>(h->p.Ng), n_last, h->ring_pos);
+    hipError_t e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "loss window: %s", hipGetErrorString(e));
+    return BRIE_OK;
+}
+
 int brie_set_target(brie_handle *h, int32_t target) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (target != 0 && target != 1) return fail(BRIE_ERR_INVALID, "target %d (0 = ELBO, 1 = marginLik)", target);
@@ -769,6 +821,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     a.pc = h->pc;
+    a.gene_active = h->gene_active; a.block_active = h->block_active;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
     cfg.mbuf = h->Mbuf; cfg.rbuf = h->Rbuf;
     brie::CoupledArgs cp{};
@@ -785,6 +838,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     brie::FinalizeArgs f{};
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
     f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
+    f.gene_active = h->gene_active; f.ring_kl = h->ring_kl; f.ring_ll = h->ring_ll;
     f.Ng = a.Ng; f.Kc = h->kernel_kc; f.n_chunks = h->n_chunks;
     f.train_b = h->cell_mode ? 0 : h->p.train_intercept;        // cell mode: the (1,Ng) vectors are not parameters
     f.train_lam = h->cell_mode ? 0 : h->p.train_sigma;
@@ -797,6 +851,9 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         a.alpha = alpha; f.alpha = alpha; cf.alpha = alpha;
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
+        f.ring_slot = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
+        f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
+        h->ring_pos += 1;
         if (h->wide && (rc = gemm_prior_mean(h)) != BRIE_OK) return rc;          // M = Xc . Wc_loc (MFMA)
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         if (h->target == 1) launch_margin(h, cfg, q, a);
@@ -807,7 +864,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             if ((rc = gemm_design_grad(h)) != BRIE_OK) return rc;
             const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
             hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W,
-                               h->Gbuf, nW, alpha);
+                               h->Gbuf, nW, alpha, h->gene_active, h->ld);
         }
         if (h->coupled)
             hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),

@@ -214,6 +214,11 @@ struct StepScalars {
     float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
     float inv_mc;
     float pc;                               // pseudo-count applied on the fly to compact (u8) counts
+    // Per-batch convergence (the reference stops each ~batch_size/Nc-gene batch on its own,
+    // model_wrap.py:241-260 + model_TFProb.py:247-258): frozen genes keep their state, gene blocks
+    // with no active gene are skipped entirely.
+    const float *gene_active;               // (ld) 1 = train, 0 = frozen
+    const int32_t *block_active;            // (gene_blocks) any active gene in the 256-gene block
 };
 
 // Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
@@ -348,6 +353,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+    if (a.block_active[blockIdx.x] == 0) return;         // whole gene block frozen (workgroup-uniform)
 
     float acc[S][kVec];
 #pragma unroll
@@ -400,6 +406,12 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
+        bool on[kVec];
+        {
+            const F4 t = ld4(a.gene_active + j0);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) on[v] = t.v[v] != 0.0f;
+        }
 
         auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX], RowScalars &rs) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
@@ -477,15 +489,20 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 }
                 const float g_mu = rr - gbar[v] * a.inv_mc;
                 const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
-                // Keras Adam
-                R.mm.v[v] += (g_mu - R.mm.v[v]) * kOneMinusB1;
-                R.vm.v[v] += (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
-                R.mr.v[v] += (g_rho - R.mr.v[v]) * kOneMinusB1;
-                R.vr.v[v] += (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
-                float nmu = R.mu.v[v] - (R.mm.v[v] * a.alpha) * f_rcp(f_sqrt(R.vm.v[v]) + kAdamEps);
+                // Keras Adam (a frozen gene keeps state and moments)
+                const float n_mm = R.mm.v[v] + (g_mu - R.mm.v[v]) * kOneMinusB1;
+                const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
+                const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
+                const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
+                float nmu = R.mu.v[v] - (n_mm * a.alpha) * f_rcp(f_sqrt(n_vm) + kAdamEps);
                 nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
-                R.mu.v[v] = nmu;
-                R.rho.v[v] -= (R.mr.v[v] * a.alpha) * f_rcp(f_sqrt(R.vr.v[v]) + kAdamEps);
+                const float nrho = R.rho.v[v] - (n_mr * a.alpha) * f_rcp(f_sqrt(n_vr) + kAdamEps);
+                R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
+                R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
+                R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
+                R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
+                R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
+                R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
                 if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for the Xc^T.r GEMM
                 // per-gene sufficient statistics
 #pragma unroll
@@ -586,10 +603,14 @@ struct FinalizeArgs {
     float *b, *m_b, *v_b;       // (ld)
     float *lam, *m_lam, *v_lam; // (ld)
     double *loss_parts;         // (n_blocks, 2): sum KL, sum ll for this step
+    const float *gene_active;   // (ld) 1 = train, 0 = frozen (per-batch convergence)
+    float *ring_kl, *ring_ll;   // (kLossRing, ld) per-gene loss terms of the last steps
     int64_t ld;
     int32_t Ng, Kc, n_chunks, train_b, train_lam;
+    int32_t ring_slot, ring_prev;
     float alpha;
 };
+constexpr int kLossRing = 128;  // >= d2 = 2*min(50, add_iter/2) of model_TFProb.py:248-249
 
 __device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float g, float alpha) {
     m += (g - m) * kOneMinusB1;
@@ -604,7 +625,15 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
     const int s = blockIdx.y;
     const int S = a.Kc + 4;
     double t = 0.0;
-    if (j < a.Ng) {
+    if (j < a.Ng && a.gene_active[j] == 0.0f) {
+        // frozen gene: parameters untouched, its last loss terms are carried forward
+        if (s >= a.Kc + 2) {
+            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
+            const float last = ring[static_cast<int64_t>(a.ring_prev) * a.ld + j];
+            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = last;
+            t = static_cast<double>(last);
+        }
+    } else if (j < a.Ng) {
         const float *p = a.partials + static_cast<int64_t>(s) * a.ld + j;
         const int64_t stride = static_cast<int64_t>(S) * a.ld;
         int c = 0;
@@ -634,6 +663,9 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
                 adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
                 a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
             }
+        } else {
+            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
+            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = static_cast<float>(t);
         }
     }
     if (s < a.Kc + 2) return;                      // uniform per block: only the KL / ll rows reduce further
@@ -985,13 +1017,25 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
 }
 
 // wide designs: Adam for Wc_loc from G = Xc^T . r (GEMM output), dL/dW = -G
-__global__ void wide_w_adam(float *W, float *mW, float *vW, const float *G, int64_t n, float alpha) {
+__global__ void wide_w_adam(float *W, float *mW, float *vW, const float *G, int64_t n, float alpha,
+                            const float *gene_active, int64_t ld) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if (gene_active[i % ld] == 0.0f) continue;
         float x = W[i], m = mW[i], v = vW[i];
         adam_scalar(x, m, v, -G[i], alpha);
         W[i] = x; mW[i] = m; vW[i] = v;
     }
+}
+
+// out[k][j] = KL - ll of gene j at the k-th of the last `n_last` steps (chronological)
+__global__ void loss_window(const float *ring_kl, const float *ring_ll, float *out, int64_t ld, int Ng, int n_last,
+                            int64_t pos) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.y;
+    if (j >= Ng || k >= n_last) return;
+    const int64_t slot = (pos - n_last + k) % kLossRing;
+    out[static_cast<int64_t>(k) * Ng + j] = ring_kl[slot * ld + j] - ring_ll[slot * ld + j];
 }
 
 // out[j] = sum_c KL - (sum_c LL) / n_rep

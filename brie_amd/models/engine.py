@@ -198,11 +198,16 @@ class BRIE2(object):
     # ------------------------------------------------------------------ fit (model_TFProb.py:214-273)
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
-            n_loss_gene=500, pseudo_count=None, trace_reduce=None, **kwargs):
+            n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
         reference (overwritten at model_TFProb.py:228-237).
+
+        conv_batch_genes=None: one model, one convergence decision on the summed loss trace
+        (model_TFProb.py:247-258).  conv_batch_genes=n (set by fitBRIE to ceil(batch_size/Nc)): every
+        batch of n consecutive genes is one of the reference's sequential fits (model_wrap.py:241-260)
+        and stops on its own windowed loss; stopped batches are frozen on the device.
         """
         start_time = time.time()
         if target not in ("ELBO", "marginLik"):
@@ -235,7 +240,28 @@ class BRIE2(object):
         n_iter = min_iter + 0                                        # model_TFProb.py:247-258
         d1 = int(min(50, add_iter / 2))
         d2 = d1 * 2
-        while (len(losses) >= d2 and d1 > 0 and
+        if conv_batch_genes and not self._coupled and target == "ELBO":
+            starts = np.arange(0, self.Ng, int(conv_batch_genes))
+            sizes = np.diff(np.append(starts, self.Ng))
+            batch_on = np.ones(len(starts), bool)
+            self.n_iter_batch = np.full(len(starts), n_iter)
+            while n_iter < max_iter and len(losses) >= d2 and 0 < d2 <= 128:
+                win = np.add.reduceat(sh.read_loss_window(d2).astype(np.float64), starts, axis=1).astype(np.float32)
+                batch_on &= (win[:d1].mean(0) - win[d1:].mean(0)) > epsilon_conv      # per batch, model_TFProb.py:250
+                n_on = int(batch_on.sum())
+                if trace_reduce is not None:                         # gene shards: stop when no rank has work left
+                    n_on = int(round(float(np.asarray(trace_reduce(np.array([float(n_on)])))[0])))
+                if n_on == 0:
+                    break
+                sh.set_gene_mask(np.repeat(batch_on, sizes))
+                n_iter += add_iter
+                self.n_iter_batch[batch_on] = n_iter
+                losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])
+            sh.set_gene_mask(None)
+            conv_batch_genes = True
+        else:
+            conv_batch_genes = False
+        while (not conv_batch_genes and len(losses) >= d2 and d1 > 0 and
                losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv and n_iter < max_iter):
             n_iter += add_iter
             losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])

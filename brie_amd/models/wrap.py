@@ -199,6 +199,9 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
         # the loss trace is summed over ranks so every rank takes the same convergence decision
         keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
 
+    if separable and not emulate_batches and 'conv_batch_genes' not in keyargs:
+        # all genes are fitted concurrently; each reference-sized batch still stops on its own loss window
+        keyargs = dict(keyargs, conv_batch_genes=int(np.ceil(batch_size / Nc)))
     if separable and emulate_batches:                                 # model_wrap.py:242-260
         _n_gene = int(np.ceil(batch_size / Nc))
         _n_gene = max(4, (_n_gene + 3) // 4 * 4)                      # noise stream is keyed per gene quad

@@ -130,6 +130,16 @@ int brie_reset_optimizer(brie_handle *h);
 int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
               float *loss_trace);
 
+/* Per-batch convergence.  The reference fits ~batch_size/Nc genes at a time and lets every batch stop on
+ * its own windowed loss (model_wrap.py:241-260 + model_TFProb.py:247-258).  All genes are fitted
+ * concurrently here, so the host reads the per-gene losses of the last steps, decides per batch and
+ * freezes the genes of finished batches: a frozen gene keeps state, moments and its last loss; a
+ * 256-gene block with no active gene is skipped by the kernels.
+ * brie_set_gene_mask: active[Ng] bytes (1 = train, 0 = frozen), NULL = all active.
+ * brie_read_loss_window: out[n_last][Ng] = per-gene loss (KL - ll) of the last n_last <= 128 steps. */
+int brie_set_gene_mask(brie_handle *h, const uint8_t *active);
+int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out);
+
 /* Objective of brie_step / brie_loss_gene: 0 = "ELBO" (default; model_TFProb.py:206-211),
  * 1 = "marginLik" (model_TFProb.py:156-157,188-189,202-205: z sampled from the prior, log-mean-exp
  * over the MC samples, no KL; only Wc_loc / intercept / sigma_log are updated). */

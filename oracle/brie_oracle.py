@@ -71,6 +71,8 @@ class OracleBRIE2(object):
         self.Wg_loc = np.array(init.get('Wg_loc', np.zeros((self.Nc, self.Kg))), dt).reshape(self.Nc, self.Kg)   # ref:85
         self.intercept = np.array(init['intercept'], dt).reshape(self.par_shape)    # ref:67-71
         self.sigma_log = np.array(init['sigma_log'], dt).reshape(self.par_shape)    # ref:73-78
+        self.gene_active = np.ones(self.Ng, bool)       # per-batch convergence: frozen genes stop updating
+        self.lg_hist = []                               # per-gene losses of the last steps
         self.reset_optimizer()
 
     # ------------------------------------------------------------------ init
@@ -286,12 +288,17 @@ class OracleBRIE2(object):
                 continue
             g = grads[name].astype(self.dtype)
             slot = self.slots[name]
+            var = getattr(self, name)
+            old = (slot.m.copy(), slot.v.copy(), var.copy())
             slot.m += (g - slot.m) * (dt(1) - dt(ADAM_B1))
             slot.v += (g * g - slot.v) * (dt(1) - dt(ADAM_B2))
-            var = getattr(self, name)
             var -= (slot.m * alpha) / (np.sqrt(slot.v) + dt(ADAM_EPS))
             if name in ('Z_loc', 'intercept'):          # clip_by_value constraint (ref:69,81)
                 np.clip(var, dt(-9), dt(9), out=var)
+            if var.shape[-1] == self.Ng and not self.gene_active.all():
+                # genes of a finished batch keep state and moments (the reference stopped that fit)
+                for arr, o in zip((slot.m, slot.v, var), old):
+                    arr[..., ~self.gene_active] = o[..., ~self.gene_active]
 
     def minimize(self, counts, Xc, num_steps, lr, MC_size=1, target="ELBO"):
         """`tfp.math.minimize` (ref:239-241): trace = loss BEFORE each update."""
@@ -300,13 +307,22 @@ class OracleBRIE2(object):
             out = self.loss_and_grads(counts, Xc, MC_size) if target == "ELBO" \
                 else self.margin_loss_and_grads(counts, Xc, MC_size)
             trace[i] = out['loss']
+            lg = np.asarray(out['loss_gene'], np.float64)
+            if self.lg_hist and not self.gene_active.all():       # frozen genes carry their last loss forward
+                lg = np.where(self.gene_active, lg, self.lg_hist[-1])
+                trace[i] = lg.sum()
+            self.lg_hist = (self.lg_hist + [lg])[-128:]
             self.adam_step(out, lr)
         return trace
 
     # ------------------------------------------------------------- fit
     def fit(self, counts, Xc=None, min_iter=1000, max_iter=5000, add_iter=500,
-            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500, Xg=None, target="ELBO"):
-        """`BRIE2.fit` (ref:214-273)."""
+            epsilon_conv=1e-2, MC_size=1, n_loss_gene=500, Xg=None, target="ELBO", conv_batch_genes=None):
+        """`BRIE2.fit` (ref:214-273).
+
+        conv_batch_genes=None: one model, one convergence decision on the summed trace (ref:247-258).
+        conv_batch_genes=n: the fitBRIE situation (model_wrap.py:241-260) -- every batch of n consecutive
+        genes is its own reference fit and stops on its own windowed loss; a stopped batch is frozen."""
         self.Xc = Xc
         if Xg is not None:
             self.Xg = Xg
@@ -316,7 +332,22 @@ class OracleBRIE2(object):
         n_iter = min_iter + 0                                # ref:247
         d1 = int(min(50, add_iter / 2))                      # ref:248
         d2 = d1 * 2
-        while (losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv
+        if conv_batch_genes:
+            starts = np.arange(0, self.Ng, int(conv_batch_genes))
+            batch_on = np.ones(len(starts), bool)
+            self.n_iter_batch = np.full(len(starts), n_iter)
+            while n_iter < max_iter and len(self.lg_hist) >= d2 and d1 > 0:
+                win = np.add.reduceat(np.asarray(self.lg_hist[-d2:]), starts, axis=1).astype(np.float32)
+                batch_on &= (win[:d1].mean(0) - win[d1:].mean(0)) > epsilon_conv      # ref:250, per batch
+                if not batch_on.any():
+                    break
+                self.gene_active = np.repeat(batch_on, np.diff(np.append(starts, self.Ng)))
+                n_iter += add_iter
+                self.n_iter_batch[batch_on] = n_iter
+                losses = np.concatenate([losses, self.minimize(
+                    counts, Xc, add_iter, LEARNING_RATES[5], MC_size, target)])
+            self.gene_active = np.ones(self.Ng, bool)
+        while (not conv_batch_genes and losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv
                and n_iter < max_iter):                       # ref:250-251
             n_iter += add_iter
             losses = np.concatenate([losses, self.minimize(

@@ -47,7 +47,7 @@ class OracleBackedBRIE2(object):
 
     def fit(self, count_layers, Xc=None, Xg=None, min_iter=1000, max_iter=5000, add_iter=500,
             epsilon_conv=1e-2, verbose=True, n_loss_gene=500, pseudo_count=None, MC_size=1,
-            trace_reduce=None, **kw):
+            trace_reduce=None, conv_batch_genes=None, **kw):
         self.Xc, self.Xg = Xc, Xg
         data = [np.asarray(c.toarray() if hasattr(c, "toarray") else c, np.float32) for c in count_layers]
         if self._o.effLen is None:
@@ -56,7 +56,8 @@ class OracleBackedBRIE2(object):
             data = add_pseudo_count(data, pseudo_count)
         self.fit_args = dict(min_iter=min_iter, max_iter=max_iter, MC_size=MC_size, Kc=self.Kc,
                              Xc=None if Xc is None else np.array(Xc))
-        losses = self._o.fit(data, Xc, min_iter, max_iter, add_iter, epsilon_conv, MC_size, n_loss_gene, Xg=Xg)
+        losses = self._o.fit(data, Xc, min_iter, max_iter, add_iter, epsilon_conv, MC_size, n_loss_gene, Xg=Xg,
+                             conv_batch_genes=conv_batch_genes)
         if trace_reduce is not None:
             losses = trace_reduce(losses)
         self.losses, self.loss_gene = _w(losses), _w(self._o.loss_gene)

@@ -382,3 +382,39 @@ def test_sparse_layers_densified_on_device(lib):
     got = sh.read(_capi.COUNT1)
     assert got[0, 3] == 3 and got[5, 7] == 8 and got.sum() == 11
     dense.close()
+
+
+def test_frozen_genes_and_loss_window(lib):
+    """Per-batch convergence machinery: a gene mask freezes state, moments and per-gene parameters of the
+    masked genes (their last loss is carried forward), active genes are unaffected; fully frozen 256-gene
+    blocks are skipped.  Checked against the oracle with the same mask."""
+    from brie_amd import _capi
+    Nc, Ng, Kc = 60, 600, 1                      # 3 gene blocks; block 1 gets fully frozen
+    P = util.problem(Nc, Ng, Kc, 2, seed=71)
+    o = util.oracle_model(P, Nc, Ng, Kc, 73, np.float32)
+    sh = util.device_shard(P, Nc, Ng, Kc, 73)
+    o.minimize(P["counts_pc"], P["Xc"], 4, 0.01, 1)
+    sh.step(4, 0.01, 1)
+    win = sh.read_loss_window(4)
+    np.testing.assert_allclose(win, np.asarray(o.lg_hist[-4:]), rtol=2e-5, atol=1e-3)
+    mask = np.ones(Ng, bool)
+    mask[256:512] = False                        # a whole block
+    mask[10:30] = False                          # part of block 0 (crosses lane quads)
+    mask[597] = False
+    before = util.device_state(sh)
+    o.gene_active = mask.copy()
+    sh.set_gene_mask(mask)
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 5, 0.01, 1)
+    tr_d = sh.step(5, 0.01, 1)
+    after = util.device_state(sh)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
+    for k in ("Z_loc", "Z_std_log", "Wc_loc", "intercept", "sigma_log"):
+        np.testing.assert_array_equal(after[k][:, ~mask], before[k][:, ~mask])          # frozen: bit-identical
+        assert np.abs(after[k][:, mask] - before[k][:, mask]).max() > 0
+    assert_states_close(util.oracle_state(o), after)
+    win = sh.read_loss_window(6)
+    np.testing.assert_array_equal(win[1:, ~mask], np.repeat(win[:1, ~mask], 5, axis=0))   # carried forward
+    sh.set_gene_mask(None)
+    o.gene_active[:] = True
+    np.testing.assert_allclose(sh.step(2, 0.01, 1), o.minimize(P["counts_pc"], P["Xc"], 2, 0.01, 1), rtol=3e-5)
+    assert_states_close(util.oracle_state(o), util.device_state(sh))

@@ -165,3 +165,24 @@ def test_unsupported_modes_raise():
         m.fit([np.zeros((10, 10))] * 2, target="nonsense")
     with pytest.raises(RuntimeError):
         m.Psi
+
+
+def test_per_batch_convergence_equals_sequential_reference_batches(patched_wrap):
+    """fitBRIE fits all genes concurrently but lets every reference-sized batch stop on its own loss window
+    (conv_batch_genes); this must reproduce the sequential per-batch fits of model_wrap.py:241-260."""
+    Nc, Ng = 30, 24
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=14, depth=6.0)
+    mk = lambda: FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    kw = dict(Xc=P["Xc"], batch_size=Nc * 8, min_iter=120, max_iter=200, add_iter=10, epsilon_conv=0.1,
+              n_loss_gene=3, verbose=False)
+    seq = patched_wrap.fitBRIE(mk(), emulate_batches=True, **kw)
+    seq_models = list(OracleBackedBRIE2.instances)
+    OracleBackedBRIE2.instances = []
+    con = patched_wrap.fitBRIE(mk(), **kw)
+    (model,) = OracleBackedBRIE2.instances
+    n_seq = [m._o.n_iter for m in seq_models]
+    assert len(set(n_seq)) > 1, "test data should make the batches stop at different times: %s" % n_seq
+    np.testing.assert_array_equal(model._o.n_iter_batch, n_seq)
+    np.testing.assert_allclose(con.Psi, seq.Psi, atol=1e-5)
+    np.testing.assert_allclose(con.cell_coeff, seq.cell_coeff, atol=1e-5)
+    np.testing.assert_allclose(con.sigma, seq.sigma, atol=1e-5)

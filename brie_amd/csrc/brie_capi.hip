@@ -123,6 +123,15 @@ struct brie_handle {
     int32_t *block_active = nullptr;   // (gene_blocks)
     float *ring_kl = nullptr, *ring_ll = nullptr;   // (kLossRing, ld) per-gene loss terms of the last steps
     int64_t ring_pos = 0;           // optimisation steps taken so far
+    // packing of active gene quads (per-batch convergence): position -> original quad
+    int32_t *quad_ids = nullptr;    // device (ld / 4)
+    std::vector<int32_t> perm;      // host mirror; empty or identity when not packed
+    std::vector<float> mask_host;   // gene mask in ORIGINAL gene order (ld entries)
+    bool packed = false;
+    bool allow_pack = true;         // BRIE_PACK_ACTIVE=0 keeps frozen genes in place (A/B, tests)
+    void *pack_scratch = nullptr;   // one matrix-sized scratch buffer for the gathers (swaps with live arrays)
+    size_t pack_scratch_bytes = 0;
+    float *row_scratch = nullptr;   // scratch for per-gene row sets
     float *partials = nullptr;
     size_t partials_elems = 0;
     double *loss_parts = nullptr;
@@ -270,6 +279,95 @@ int expand_counts(brie_handle *h) {
     h->pc = 0.0f;
     h->allow_compact = false;                     // values are no longer integers
     return BRIE_OK;
+}
+
+// ---- packing of active quads ------------------------------------------------------------------
+// apply_quad_gather: every gene-indexed array of the shard is re-ordered so that position p holds what
+// was at position from[p].  Matrices go through one scratch buffer (pointer swap), vectors likewise.
+int apply_quad_gather(brie_handle *h, const std::vector<int32_t> &from) {
+    const int nq = static_cast<int>(h->ld / 4);
+    const int Nc = static_cast<int>(h->p.Nc);
+    int32_t *d_from = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_from), nq * sizeof(int32_t)));
+    hipError_t e = hipMemcpyAsync(d_from, from.data(), nq * sizeof(int32_t), hipMemcpyHostToDevice, h->stream);
+    // two scratch buffers: one cell x gene matrix (it swaps roles with the live arrays, so it must have
+    // exactly their size) and one for the largest per-gene row set (the loss rings / Wc_loc)
+    const size_t mat_bytes = static_cast<size_t>(Nc) * h->ld * sizeof(float);
+    const size_t row_bytes = static_cast<size_t>(brie::kLossRing > h->p.Kc ? brie::kLossRing : h->p.Kc) * h->ld * sizeof(float);
+    if (e == hipSuccess && !h->pack_scratch) {
+        e = hipMalloc(&h->pack_scratch, mat_bytes);
+        if (e == hipSuccess) h->pack_scratch_bytes = mat_bytes;
+    }
+    if (e == hipSuccess && !h->row_scratch) e = hipMalloc(reinterpret_cast<void **>(&h->row_scratch), row_bytes);
+    if (e != hipSuccess) { hipFree(d_from); return fail(BRIE_ERR_HIP, "pack: %s", hipGetErrorString(e)); }
+    const dim3 grid(grid_1d(static_cast<int64_t>(nq) * Nc)), block(256);
+    // cell x gene matrices: the live pointer and the scratch pointer swap roles after each gather
+    auto move_f32 = [&](float *&arr) {
+        if (!arr) return;
+        hipLaunchKernelGGL(brie::gather_quads_tiled<float4>, grid, block, 0, h->stream,
+                           reinterpret_cast<const float4 *>(arr), reinterpret_cast<float4 *>(h->pack_scratch), d_from, nq, Nc);
+        float *old = arr;
+        arr = static_cast<float *>(h->pack_scratch);
+        h->pack_scratch = old;
+    };
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        if (h->cs == brie::kCountF32) { move_f32(h->c[l]); continue; }
+        // compact layers are smaller than the scratch: gather into it, then copy back in place
+        const size_t bytes = static_cast<size_t>(Nc) * h->ld * (h->cs == brie::kCountU16 ? 2 : 1);
+        if (h->cs == brie::kCountU16)
+            hipLaunchKernelGGL(brie::gather_quads_tiled<uint2>, grid, block, 0, h->stream,
+                               static_cast<const uint2 *>(h->cu[l]), static_cast<uint2 *>(h->pack_scratch), d_from, nq, Nc);
+        else
+            hipLaunchKernelGGL(brie::gather_quads_tiled<uint32_t>, grid, block, 0, h->stream,
+                               static_cast<const uint32_t *>(h->cu[l]), static_cast<uint32_t *>(h->pack_scratch), d_from,
+                               nq, Nc);
+        e = hipMemcpyAsync(h->cu[l], h->pack_scratch, bytes, hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) break;
+    }
+    if (e == hipSuccess) {
+        move_f32(h->mu); move_f32(h->rho); move_f32(h->m_mu); move_f32(h->v_mu); move_f32(h->m_rho); move_f32(h->v_rho);
+        // per-gene vectors (rows, ld): gather into the scratch, copy back
+        auto move_rows = [&](float *arr, int rows) {
+            if (!arr || rows == 0 || e != hipSuccess) return;
+            hipLaunchKernelGGL(brie::gather_quads_rows, dim3(grid_1d(static_cast<int64_t>(rows) * nq)), block, 0, h->stream,
+                               arr, h->row_scratch, d_from, nq, rows, h->ld);
+            e = hipMemcpyAsync(arr, h->row_scratch, static_cast<size_t>(rows) * h->ld * sizeof(float),
+                               hipMemcpyDeviceToDevice, h->stream);
+        };
+        move_rows(h->W, h->p.Kc); move_rows(h->m_W, h->p.Kc); move_rows(h->v_W, h->p.Kc);
+        move_rows(h->b, 1); move_rows(h->m_b, 1); move_rows(h->v_b, 1);
+        move_rows(h->lam, 1); move_rows(h->m_lam, 1); move_rows(h->v_lam, 1);
+        move_rows(h->effL, 6); move_rows(h->gene_active, 1);
+        move_rows(h->ring_kl, brie::kLossRing); move_rows(h->ring_ll, brie::kLossRing);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    hipFree(d_from);
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "pack: %s", hipGetErrorString(e));
+    return BRIE_OK;
+}
+
+int upload_quad_ids_and_blocks(brie_handle *h, const std::vector<float> &mask_by_position) {
+    std::vector<int32_t> blocks(static_cast<size_t>(h->gene_blocks), 0);
+    for (int64_t j = 0; j < h->ld; ++j)
+        if (mask_by_position[j] != 0.0f) blocks[j / brie::kGenesPerBlock] = 1;
+    HIP_TRY(hipMemcpyAsync(h->quad_ids, h->perm.data(), h->perm.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->block_active, blocks.data(), blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BRIE_OK;
+}
+
+// Back to the identity order (before anything that addresses genes by their original index).
+int ensure_identity(brie_handle *h) {
+    if (!h->packed) return BRIE_OK;
+    const int nq = static_cast<int>(h->ld / 4);
+    std::vector<int32_t> inv(nq);
+    for (int p = 0; p < nq; ++p) inv[h->perm[p]] = p;          // original quad q currently lives at inv[q]
+    int rc = apply_quad_gather(h, inv);
+    if (rc != BRIE_OK) return rc;
+    for (int p = 0; p < nq; ++p) h->perm[p] = p;
+    h->packed = false;
+    return upload_quad_ids_and_blocks(h, h->mask_host);     // identity quad ids, block flags of the unpacked mask
 }
 
 int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t *cols, int64_t *ldd) {
@@ -422,6 +520,12 @@ int brie_create(const brie_problem *p, brie_handle **out) {
 #undef A
     configure_tiling(h);
     {
+        const char *pk = getenv("BRIE_PACK_ACTIVE");
+        h->allow_pack = !(pk && strcmp(pk, "0") == 0) && h->tiled;
+        h->perm.resize(static_cast<size_t>(h->ld / 4));
+        for (size_t q = 0; q < h->perm.size(); ++q) h->perm[q] = static_cast<int32_t>(q);
+        e = hipMalloc(reinterpret_cast<void **>(&h->quad_ids), h->perm.size() * sizeof(int32_t));
+        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
         e = hipMalloc(reinterpret_cast<void **>(&h->block_active), h->gene_blocks * sizeof(int32_t));
         if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
         if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { brie_destroy(h); return rc; }
@@ -453,6 +557,9 @@ int brie_destroy(brie_handle *h) {
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
     if (h->block_active) hipFree(h->block_active);
+    if (h->quad_ids) hipFree(h->quad_ids);
+    if (h->pack_scratch) hipFree(h->pack_scratch);
+    if (h->row_scratch) hipFree(h->row_scratch);
     for (void *q : h->cu)
         if (q) hipFree(q);
     if (h->blas && rocblas_api()) rocblas_api()->destroy(h->blas);
@@ -466,6 +573,7 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     if (!h || (!src && rows * cols > 0)) return fail(BRIE_ERR_INVALID, "null argument");
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
     // `src` may live in HBM and may still be being produced on another stream (e.g. a torch tensor on
     // torch's stream); the handle's stream is non-blocking, so order the copy after ALL prior device work.
@@ -547,6 +655,7 @@ int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t 
     if (nnz < 0) return fail(BRIE_ERR_INVALID, "nnz=%lld", (long long)nnz);
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "sparse upload needs the tiled layout");
     HIP_TRY(hipDeviceSynchronize());
     if (h->cs != brie::kCountF32 || h->compact_tried) {
@@ -587,6 +696,7 @@ int brie_add_pseudo_count(brie_handle *h, float pc) {
         if (!h->have_c[l]) return fail(BRIE_ERR_STATE, "count layer %d not uploaded", l + 1);
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (h->cs != brie::kCountF32 && (rc = expand_counts(h)) != BRIE_OK) return rc;   // second pseudo-count: fp32
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     if (h->cs != brie::kCountF32) {           // integer counts: keep them compact, add `pc` in registers
@@ -634,6 +744,7 @@ int brie_init_state(brie_handle *h, float intercept, float sigma) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     const uint32_t slo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull), shi = static_cast<uint32_t>(h->p.seed >> 32);
     const uint32_t qoff = static_cast<uint32_t>(h->p.gene_offset / 4);
     const int Nc = static_cast<int>(h->p.Nc), Ng = static_cast<int>(h->p.Ng);
@@ -681,17 +792,38 @@ int brie_set_gene_mask(brie_handle *h, const uint8_t *active) {
     if (rc != BRIE_OK) return rc;
     if (active && h->coupled)
         return fail(BRIE_ERR_UNSUPPORTED, "per-gene freezing is meaningless for coupled fits (one joint problem)");
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;        // `active` is in original gene order
     std::vector<float> mask(static_cast<size_t>(h->ld), 0.0f);
-    std::vector<int32_t> blocks(static_cast<size_t>(h->gene_blocks), 0);
+    bool any_frozen = false;
     for (int64_t j = 0; j < h->p.Ng; ++j) {
         const bool on = active ? active[j] != 0 : true;
         mask[j] = on ? 1.0f : 0.0f;
-        if (on) blocks[j / brie::kGenesPerBlock] = 1;
+        any_frozen |= !on;
     }
     HIP_TRY(hipMemcpyAsync(h->gene_active, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIP_TRY(hipMemcpyAsync(h->block_active, blocks.data(), blocks.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    return BRIE_OK;
+    h->mask_host = mask;
+    if (any_frozen && h->allow_pack && !h->wide) {
+        // pack: quads with an active gene first (stable), fully frozen quads after them; whole 256-gene
+        // blocks at the tail then hold no active gene and are skipped by the kernels
+        const int nq = static_cast<int>(h->ld / 4);
+        std::vector<int32_t> order;
+        order.reserve(nq);
+        auto quad_on = [&](int q) { return mask[4 * q] + mask[4 * q + 1] + mask[4 * q + 2] + mask[4 * q + 3] > 0.0f; };
+        for (int q = 0; q < nq; ++q) if (quad_on(q)) order.push_back(q);
+        const size_t n_on = order.size();
+        for (int q = 0; q < nq; ++q) if (!quad_on(q)) order.push_back(q);
+        if (n_on < static_cast<size_t>(nq)) {
+            if ((rc = apply_quad_gather(h, order)) != BRIE_OK) return rc;
+            h->perm = order;
+            h->packed = true;
+            std::vector<float> by_pos(static_cast<size_t>(h->ld));
+            for (int p = 0; p < nq; ++p)
+                for (int v = 0; v < 4; ++v) by_pos[4 * p + v] = mask[4 * order[p] + v];
+            return upload_quad_ids_and_blocks(h, by_pos);
+        }
+    }
+    return upload_quad_ids_and_blocks(h, mask);
 }
 
 int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out) {
@@ -701,6 +833,7 @@ int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out) {
                     (long long)h->ring_pos);
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     float *tmp = nullptr;
     const size_t n = static_cast<size_t>(n_last) * h->p.Ng;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), n * sizeof(float)));
@@ -728,6 +861,7 @@ int brie_set_count_storage(brie_handle *h, int32_t mode) {
     if (mode == 1) {
         int rc = set_device(h);
         if (rc != BRIE_OK) return rc;
+        if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
         if ((rc = expand_counts(h)) != BRIE_OK) return rc;
     }
     h->allow_compact = mode == 0;
@@ -821,7 +955,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     a.pc = h->pc;
-    a.gene_active = h->gene_active; a.block_active = h->block_active;
+    a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
     cfg.mbuf = h->Mbuf; cfg.rbuf = h->Rbuf;
     brie::CoupledArgs cp{};
@@ -947,6 +1081,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     if (rc != BRIE_OK) return rc;
     if (n_repeats < 1 || !out) return fail(BRIE_ERR_INVALID, "n_repeats=%d out=%p", n_repeats, (void *)out);
     if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const bool u8 = h->cs != brie::kCountF32;
@@ -955,6 +1090,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.c2 = u8 ? static_cast<const void *>(h->cu[1]) : h->c[1];
     a.c3 = u8 ? static_cast<const void *>(h->cu[2]) : h->c[2];
     a.pc = h->pc;
+    a.quad_ids = h->quad_ids;
     a.coupled = h->coupled ? 1 : 0;
     a.margin = h->target == 1 ? 1 : 0;
     a.mbuf = nullptr;
@@ -986,6 +1122,7 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
     if (!h || !dst) return fail(BRIE_ERR_INVALID, "null argument");
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     if (which == BRIE_PSI || which == BRIE_Z_STD || which == BRIE_PSI95CI || which == BRIE_Z_LOC ||

@@ -219,6 +219,9 @@ struct StepScalars {
     // with no active gene are skipped entirely.
     const float *gene_active;               // (ld) 1 = train, 0 = frozen
     const int32_t *block_active;            // (gene_blocks) any active gene in the 256-gene block
+    // After freezing, the active gene quads are packed to the front (gather_quads); quad_ids[position]
+    // is the quad's original index, which keys the noise stream -- results do not depend on the packing.
+    const int32_t *quad_ids;
 };
 
 // Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
-        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         bool on[kVec];
         {
@@ -695,6 +698,7 @@ struct LossGeneArgs {
     int64_t ld, row_stride, gb_stride;
     int32_t Nc, Ng, rows_per_chunk, n_rep;
     uint32_t seed_lo, seed_hi, draw0, quad_offset;
+    const int32_t *quad_ids;
     float pc;
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
@@ -753,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             }
         }
         const bool cell = a.coupled && a.cp.cell_mode != 0;
-        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
@@ -891,7 +895,7 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
 #pragma unroll
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
-        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(quad);
+        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
         const float log_mc = f_log(static_cast<float>(a.mc));
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
@@ -1025,6 +1029,33 @@ __global__ void wide_w_adam(float *W, float *mW, float *vW, const float *G, int6
         float x = W[i], m = mW[i], v = vW[i];
         adam_scalar(x, m, v, -G[i], alpha);
         W[i] = x; mW[i] = m; vW[i] = v;
+    }
+}
+
+// Quad permutation of the gene axis (packing the active quads of a partly frozen shard to the front and
+// back): dst position p takes the quad at src position `from[p]`.  T = 16/8/4-byte quad of a tiled
+// cell x gene array (fp32 / u16 / u8 elements), or a float4 quad of (rows, ld) per-gene vectors.
+template <typename T>
+__global__ void gather_quads_tiled(const T *src, T *dst, const int32_t *from, int n_quads, int Nc) {
+    const int64_t total = static_cast<int64_t>(n_quads) * Nc;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int lane = static_cast<int>(i % kWave);
+        const int r = static_cast<int>((i / kWave) % Nc);
+        const int g = static_cast<int>(i / (static_cast<int64_t>(kWave) * Nc));
+        const int p = g * kWave + lane;                          // destination quad position
+        const int q = from[p];
+        const int64_t so = (static_cast<int64_t>(q / kWave) * Nc + r) * kWave + (q % kWave);
+        dst[i] = src[so];                                        // i == ((g*Nc + r)*64 + lane): tiled quad index
+    }
+}
+__global__ void gather_quads_rows(const float *src, float *dst, const int32_t *from, int n_quads, int rows, int64_t ld) {
+    const int64_t total = static_cast<int64_t>(rows) * n_quads;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int p = static_cast<int>(i % n_quads);
+        const int64_t row = i / n_quads;
+        st4(dst + row * ld + 4 * static_cast<int64_t>(p), ld4(src + row * ld + 4 * static_cast<int64_t>(from[p])));
     }
 }
 

@@ -418,3 +418,39 @@ def test_frozen_genes_and_loss_window(lib):
     o.gene_active[:] = True
     np.testing.assert_allclose(sh.step(2, 0.01, 1), o.minimize(P["counts_pc"], P["Xc"], 2, 0.01, 1), rtol=3e-5)
     assert_states_close(util.oracle_state(o), util.device_state(sh))
+
+
+def test_packing_active_quads_is_bit_identical(lib, monkeypatch):
+    """With frozen genes the active quads are packed to the front so that frozen 256-gene blocks are skipped
+    (gather of every gene-indexed array, quad_ids keep the noise stream): every result must be bit-identical
+    to leaving the genes in place (BRIE_PACK_ACTIVE=0)."""
+    from brie_amd import _capi
+    Nc, Ng, Kc = 50, 1100, 2                    # 5 gene blocks
+    P = util.problem(Nc, Ng, Kc, 3, seed=79)
+    rng = np.random.default_rng(3)
+    mask = rng.random(Ng) < 0.3                 # 30 % of the genes stay active, scattered
+    mask[900:] = False
+    outs = []
+    for pack in ("1", "0"):
+        monkeypatch.setenv("BRIE_PACK_ACTIVE", pack)
+        sh = util.device_shard(P, Nc, Ng, Kc, 83)
+        sh.step(3, 0.01, 1)
+        sh.set_gene_mask(mask)
+        tr = sh.step(4, 0.01, 3)
+        win = sh.read_loss_window(5)            # forces the identity order back
+        tr2 = sh.step(2, 0.01, 1)               # still masked, packed again? (mask persists, order restored)
+        sh.set_gene_mask(None)
+        tr3 = sh.step(2, 0.01, 1)
+        outs.append((util.device_state(sh), tr, win, tr2, tr3, sh.loss_gene(3), sh.read(_capi.PSI),
+                     sh.read(_capi.COUNT3)))
+        sh.close()
+    a, b = outs
+    for k in util.STATE_KEYS:
+        np.testing.assert_array_equal(a[0][k], b[0][k])
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-6)          # fp64 block sums of the trace run in another order
+    np.testing.assert_array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-6)
+    np.testing.assert_allclose(a[4], b[4], rtol=1e-6)
+    np.testing.assert_array_equal(a[5], b[5])
+    np.testing.assert_array_equal(a[6], b[6])
+    np.testing.assert_array_equal(a[7], P["counts_pc"][2])

@@ -64,14 +64,17 @@ def _dense32(m):
 
 
 def convert_to_count_data(Rmat_dict, effLen_tensor, cell_note, gene_note, fill_missing=True):
-    """io_utils.py:12-52."""
-    Rmat = {k: _dense32(v) for k, v in Rmat_dict.items()}
+    """io_utils.py:12-52.  Sparse matrices stay sparse (CSC, fp32): the layers are densified on the
+    device at upload (brie_upload_sparse), not on the host."""
+    import scipy.sparse as sp
+    Rmat = {k: (sp.csc_matrix(v, dtype=np.float32) if sp.issparse(v) else _dense32(v)) for k, v in Rmat_dict.items()}
     if fill_missing:
-        shape = next(iter(Rmat.values())).shape
+        first = next(iter(Rmat.values()))
         for key in ('0', '1', '2', '3'):
             if key not in Rmat:
                 print("key %s not exist in .mtx file, fill with zeros." % key)
-                Rmat[key] = np.zeros(shape, np.float32)
+                Rmat[key] = sp.csc_matrix(first.shape, dtype=np.float32) if sp.issparse(first) \
+                    else np.zeros(first.shape, np.float32)
     layers = {'isoform1': Rmat['1'], 'isoform2': Rmat['2'], 'ambiguous': Rmat['3'], 'poorQual': Rmat['0']}
     cell_note, gene_note = np.asarray(cell_note), np.asarray(gene_note)
     obs = pd.DataFrame(cell_note[1:, :], index=cell_note[1:, 0], columns=cell_note[0, :])

@@ -277,7 +277,7 @@ def main():
             # calibrate so the sample costs ~cpu_seconds
             eps_s, el = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, 1, 3, args.mc, threads=cores,
                                              warmup_steps=1)
-            n_steps = int(max(5, min(400, args.cpu_seconds * eps_s / (Nc * n_gene * nb))))
+            n_steps = int(max(5, min(2000, args.cpu_seconds * eps_s / (Nc * n_gene * nb))))
             eps_s, el = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, nb, n_steps, args.mc, threads=cores)
             out["cpu_baseline"] = {
                 "value": eps_s, "unit": "cell*gene*iterations/s", "cores": cores, "kind": "port",

@@ -10,7 +10,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -39,43 +38,6 @@ int fail(int code, const char *fmt, ...) {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace
-
-// ---------------------------------------------------------------------------------------------------
-// rocBLAS, bound at run time (dlopen) and only for wide cell designs (Kc > 8): the two plain fp32
-// GEMMs  M = Xc . Wc_loc  and  G = Xc^T . r  run on the matrix cores (v_mfma_f32_*_f32) through the
-// vendor library; everything else in this library is hand-written HIP and does not link rocBLAS.
-// ---------------------------------------------------------------------------------------------------
-struct RocblasApi {
-    void *lib = nullptr;
-    int (*create)(void **) = nullptr;
-    int (*destroy)(void *) = nullptr;
-    int (*set_stream)(void *, hipStream_t) = nullptr;
-    int (*set_atomics)(void *, int) = nullptr;
-    int (*sgemm_sb)(void *, int, int, int, int, int, const float *, const float *, int, int64_t, const float *, int,
-                    int64_t, const float *, float *, int, int64_t, int) = nullptr;
-};
-constexpr int kRocblasOpN = 111, kRocblasOpT = 112;
-
-RocblasApi *rocblas_api() {
-    static RocblasApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        for (const char *name : {"librocblas.so", "librocblas.so.5", "/opt/rocm/lib/librocblas.so"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (api.lib) break;
-        }
-        if (api.lib) {
-            api.create = reinterpret_cast<decltype(api.create)>(dlsym(api.lib, "rocblas_create_handle"));
-            api.destroy = reinterpret_cast<decltype(api.destroy)>(dlsym(api.lib, "rocblas_destroy_handle"));
-            api.set_stream = reinterpret_cast<decltype(api.set_stream)>(dlsym(api.lib, "rocblas_set_stream"));
-            api.set_atomics = reinterpret_cast<decltype(api.set_atomics)>(dlsym(api.lib, "rocblas_set_atomics_mode"));
-            api.sgemm_sb = reinterpret_cast<decltype(api.sgemm_sb)>(dlsym(api.lib, "rocblas_sgemm_strided_batched"));
-            if (!api.create || !api.destroy || !api.set_stream || !api.set_atomics || !api.sgemm_sb) api.lib = nullptr;
-        }
-    }
-    return api.lib ? &api : nullptr;
-}
 
 struct brie_handle {
     brie_problem p{};
@@ -110,12 +72,13 @@ struct brie_handle {
     bool have_xg = false;
     float *rowstat_ext = nullptr;   // caller-owned (6, Nc) buffer used instead of rowstat (multi-GPU all-reduce)
     int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
-    // wide cell designs (Kc > BRIE_MAX_KC): Xc.W and Xc^T.r through fp32 MFMA GEMMs
+    // wide cell designs (Kc > BRIE_MAX_KC): W tile in LDS for Xc.W, MFMA kernel for Xc^T.r
     bool wide = false;
     int kernel_kc = 0;              // KC of the kernel instantiation (0 for wide designs)
-    void *blas = nullptr;           // rocblas_handle
-    float *Mbuf = nullptr, *Rbuf = nullptr;   // (Nc, ld) tiled: Xc.Wc_loc, residual r
-    float *Gbuf = nullptr;          // (Kc, ld): Xc^T . r
+    float *Mbuf = nullptr;          // (Nc, ld) tiled: Xc.Wc_loc for loss_gene_eval (allocated on first use)
+    float *Rbuf = nullptr;          // (Nc, ld) tiled: residual r written by the step kernel
+    float *Gpart = nullptr;         // (n_gchunks, Kc, ld): per-chunk partial sums of Xc^T . r
+    int gchunk_rows = 1024, n_gchunks = 0;
     bool step_open = false;         // between brie_step_begin and brie_step_end
     brie::CellFinalizeArgs pending_cf{};
     float *gene_tmp = nullptr;      // (ld) scratch per-gene output
@@ -499,13 +462,10 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->ring_kl, vec * brie::kLossRing);
     A(h->ring_ll, vec * brie::kLossRing);
     if (h->wide) {
-        RocblasApi *rb = rocblas_api();
-        if (!rb) { brie_destroy(h); return fail(BRIE_ERR_HIP, "Kc=%d needs librocblas.so (not found)", p->Kc); }
-        if (rb->create(&h->blas) != 0 || rb->set_stream(h->blas, h->stream) != 0 || rb->set_atomics(h->blas, 0) != 0) {
-            brie_destroy(h);
-            return fail(BRIE_ERR_HIP, "rocblas_create_handle failed");
-        }
-        A(h->Mbuf, mat); A(h->Rbuf, mat); A(h->Gbuf, vec * p->Kc);
+        if (!h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout"); }
+        h->n_gchunks = static_cast<int>((p->Nc + h->gchunk_rows - 1) / h->gchunk_rows);
+        A(h->Rbuf, mat);
+        A(h->Gpart, vec * p->Kc * h->n_gchunks);
     }
     h->cell_mode = p->intercept_mode == 1;
     h->coupled = p->Kg > 0 || h->cell_mode;
@@ -551,7 +511,7 @@ int brie_destroy(brie_handle *h) {
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
-                     h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gbuf, h->gene_active,
+                     h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gpart, h->gene_active,
                      h->ring_kl, h->ring_ll};
     for (float *q : ptrs)
         if (q) hipFree(q);
@@ -562,7 +522,6 @@ int brie_destroy(brie_handle *h) {
     if (h->row_scratch) hipFree(h->row_scratch);
     for (void *q : h->cu)
         if (q) hipFree(q);
-    if (h->blas && rocblas_api()) rocblas_api()->destroy(h->blas);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
     if (h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -873,7 +832,7 @@ int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
 int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
     const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
-    const int64_t gemm_streams = h->wide ? 16 : 0;       // M written+read, r written+read (4 B each way)
+    const int64_t gemm_streams = h->wide ? 8 : 0;        // residual r written by the step, read by wide_design_grad
     return h->p.Nc * h->p.Ng * (48 + per_count * static_cast<int64_t>(h->p.n_layers) + gemm_streams);
 }
 
@@ -886,25 +845,33 @@ int64_t brie_step_algorithmic_bytes(const brie_handle *h) {
 
 namespace {
 
-// Wide designs.  All cell x gene buffers are gene-block tiles [g][Nc][256] (row-major Nc x 256, i.e.
-// column-major 256 x Nc with ld 256), W / G are (Kc, ld) row-major = column-major (ld x Kc):
-//   M_g (256 x Nc) = W_g (256 x Kc, lda = ld) . Xc^T (Kc x Nc, ldb = Kc)          -> gemm_prior_mean
-//   G_g (256 x Kc, ldc = ld) = R_g (256 x Nc, lda = 256) . Xc (Nc x Kc) = op_T(Xc^T) -> gemm_design_grad
-int gemm_prior_mean(brie_handle *h) {
-    const float one = 1.0f, zero = 0.0f;
-    const int rc = rocblas_api()->sgemm_sb(h->blas, kRocblasOpN, kRocblasOpN, brie::kGenesPerBlock,
-                                           static_cast<int>(h->p.Nc), h->p.Kc, &one, h->W, static_cast<int>(h->ld),
-                                           brie::kGenesPerBlock, h->Xc, h->p.Kc, 0, &zero, h->Mbuf,
-                                           brie::kGenesPerBlock, h->gb_stride, h->gene_blocks);
-    return rc == 0 ? BRIE_OK : fail(BRIE_ERR_HIP, "rocblas_sgemm_strided_batched (Xc.W) status %d", rc);
+// Wide designs (Kc = 9..64): G = Xc^T . r on the matrix cores, then Adam for Wc_loc.
+int wide_backward(brie_handle *h, float alpha) {
+    const dim3 grid(h->gene_blocks, h->n_gchunks), block(512);
+    if (h->p.Kc <= 32)
+        hipLaunchKernelGGL((brie::wide_design_grad<1>), grid, block, 0, h->stream, h->Xc, h->Rbuf, h->Gpart,
+                           static_cast<int>(h->p.Nc), h->p.Kc, h->ld, h->gb_stride, h->gchunk_rows);
+    else
+        hipLaunchKernelGGL((brie::wide_design_grad<2>), grid, block, 0, h->stream, h->Xc, h->Rbuf, h->Gpart,
+                           static_cast<int>(h->p.Nc), h->p.Kc, h->ld, h->gb_stride, h->gchunk_rows);
+    const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
+    hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
+                       h->n_gchunks, alpha, h->gene_active, h->ld);
+    HIP_TRY(hipGetLastError());
+    return BRIE_OK;
 }
-int gemm_design_grad(brie_handle *h) {
-    const float one = 1.0f, zero = 0.0f;
-    const int rc = rocblas_api()->sgemm_sb(h->blas, kRocblasOpN, kRocblasOpT, brie::kGenesPerBlock, h->p.Kc,
-                                           static_cast<int>(h->p.Nc), &one, h->Rbuf, brie::kGenesPerBlock,
-                                           h->gb_stride, h->Xc, h->p.Kc, 0, &zero, h->Gbuf, static_cast<int>(h->ld),
-                                           brie::kGenesPerBlock, h->gene_blocks);
-    return rc == 0 ? BRIE_OK : fail(BRIE_ERR_HIP, "rocblas_sgemm_strided_batched (Xc^T.r) status %d", rc);
+
+// Mbuf = Xc . Wc_loc for the forward-only loss_gene pass of a wide design
+int wide_forward_mean(brie_handle *h) {
+    if (!h->Mbuf) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
+    }
+    hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Xc,
+                       h->W, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->p.Kc, h->ld, h->row_stride,
+                       h->gb_stride, h->rows_per_chunk);
+    HIP_TRY(hipGetLastError());
+    return BRIE_OK;
 }
 
 // split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell
@@ -954,10 +921,11 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    a.kc_wide = h->wide ? h->p.Kc : 0;
     a.pc = h->pc;
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
-    cfg.mbuf = h->Mbuf; cfg.rbuf = h->Rbuf;
+    cfg.rbuf = h->Rbuf;
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
     cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0;
@@ -988,18 +956,12 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         f.ring_slot = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
-        if (h->wide && (rc = gemm_prior_mean(h)) != BRIE_OK) return rc;          // M = Xc . Wc_loc (MFMA)
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         if (h->target == 1) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
-        if (h->wide) {                                                           // G = Xc^T . r (MFMA), Adam on Wc_loc
-            if ((rc = gemm_design_grad(h)) != BRIE_OK) return rc;
-            const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
-            hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W,
-                               h->Gbuf, nW, alpha, h->gene_active, h->ld);
-        }
+        if (h->wide && (rc = wide_backward(h, alpha)) != BRIE_OK) return rc;     // G = Xc^T . r (MFMA), Adam on Wc_loc
         if (h->coupled)
             hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
                                dim3(brie::kBlock), 0, h->stream, cf);
@@ -1096,7 +1058,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.mbuf = nullptr;
     if (h->wide) {
         if (h->target == 1) return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with Kc > %d is not built", BRIE_MAX_KC);
-        if ((rc = gemm_prior_mean(h)) != BRIE_OK) return rc;
+        if ((rc = wide_forward_mean(h)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;

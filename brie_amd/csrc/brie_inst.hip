@@ -96,7 +96,7 @@ void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
 #define BRIE_WIDE(MC)                                                                                          \
     hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, false, true>), c.grid, dim3(kBlock), 0, c.stream, q.c1,   \
                        q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, \
-                       q.partials, a, cp, c.mbuf, c.rbuf)
+                       q.partials, a, cp, c.rbuf)
     if (a.mc == 1) BRIE_WIDE(1);
     else if (a.mc == 3) BRIE_WIDE(3);
     else BRIE_WIDE(0);

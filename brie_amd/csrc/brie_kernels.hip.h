@@ -210,6 +210,7 @@ struct StepScalars {
     int64_t row_stride, gb_stride;          // matrix element (r, gene block g, lane l, v) lives at
                                             //   g*gb_stride + r*row_stride + 4*l + v
     int32_t Nc, Ng, rows_per_chunk, mc;
+    int32_t kc_wide;                        // wide designs: run-time number of cell features (9..64)
     uint32_t seed_lo, seed_hi, draw, quad_offset;
     float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
     float inv_mc;
@@ -228,6 +229,7 @@ struct StepScalars {
 // and/or intercept_mode='cell' (per-cell intercept and sigma, model_TFProb.py:53-55).  Per-cell
 // parameters need sums over genes: each wave reduces its 256 genes and writes one value per
 // (gene block, statistic, cell); cell_finalize sums the gene blocks and applies Adam.
+constexpr int kWideKcMax = 64;              // cell features of the wide-design path (W tile of a gene block in LDS)
 constexpr int kKgMax = 4;                   // gene features supported
 constexpr int kRowStats = kKgMax + 2;       // sum_j r*Xg_k (k<4), sum_j r, sum_j (1 - d r - s^2/sigma^2)
 struct CoupledArgs {
@@ -331,10 +333,12 @@ constexpr float kAdamEps = 1e-7f;
 // one straight-line basic block, which is what lets the next row's loads stay
 // in flight across it); MC == 0: run-time count a.mc.
 // ----------------------------------------------------------------------------
-// WIDE (only with KC == 0): wide cell designs (Kc > 8).  The prior-mean term Xc.Wc_loc is computed
-// by an fp32 MFMA GEMM (rocBLAS) into `mbuf` before the launch and read here as one more 16-B
-// stream; the residual r = (mu - m)/sigma^2 is written to `rbuf` and Xc^T.r is a second GEMM after
-// the launch (wide_design in brie_capi.hip).  Costs 8 extra bytes per element, no Kc-sized register state.
+// WIDE (only with KC == 0): wide cell designs (Kc = 9..64), whose Kc x 4 weights + Kc x 4 accumulators per
+// lane no longer fit in registers.  Forward: the gene block's W tile (Kc x 256) sits in LDS, the cell's Xc
+// row is loaded once per wave (lane k holds feature k) and broadcast with v_readlane, m = b + sum_k x_k W_k
+// is Kc LDS reads + 4 Kc FMAs per lane.  Backward: the residual r = (mu - m)/sigma^2 is written to `rbuf`
+// (one extra 4-B/element stream) and G = Xc^T . r is reduced over cells on the matrix cores by
+// wide_design_grad (v_mfma_f32_32x32x2_f32), which reads it back once.
 template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
@@ -342,12 +346,12 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
-    const StepScalars a, const CoupledArgs cp, const float *__restrict__ mbuf = nullptr,
-    float *__restrict__ rbuf = nullptr) {
-    static_assert(!WIDE || KC == 0, "the wide-design variant carries no in-kernel Xc.W");
+    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
+    static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
+    __shared__ float wlds[WIDE ? kWideKcMax * kGenesPerBlock : 1];      // W tile of this gene block
 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -357,6 +361,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
     if (a.block_active[blockIdx.x] == 0) return;         // whole gene block frozen (workgroup-uniform)
+    if constexpr (WIDE) {
+        for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
+            wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
+        __syncthreads();
+    }
 
     float acc[S][kVec];
 #pragma unroll
@@ -364,9 +373,10 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
         for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
 
-    // coupled variant: every lane runs (the wave reduces over its 256 genes); lanes beyond Ng work on
-    // the zero padding of the gene block, contribute nothing and store nothing
-    if ((CPL || active) && row0 + w < row_end) {
+    // coupled / wide variants: every lane runs (the wave reduces over its 256 genes, resp. lane k carries
+    // feature k of the cell's design row for v_readlane); lanes beyond Ng work on the zero padding of the
+    // gene block, contribute nothing and store nothing
+    if ((CPL || WIDE || active) && row0 + w < row_end) {
         // per-gene parameters, live across the whole chunk
         float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
@@ -425,7 +435,8 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.clam = cp.clam[r];
             }
             load_counts<CS, MODE>(c1p, c2p, c3p, off, R.cnt);
-            if constexpr (WIDE) R.mp = ld4s(mbuf + off);
+            if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
+                R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
             R.mu = ld4s(mu_p + off);
             R.rho = ld4s(rho_p + off);
             R.mm = ld4s(mmu_p + off);
@@ -443,6 +454,18 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             float rstat[CPL ? kRowStats : 1] = {};
             F4 c1, c2, c3;
             decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
+            if constexpr (WIDE) {        // Xc . Wc_loc: broadcast x_k with v_readlane, W_k from LDS
+                const int xbits = __builtin_bit_cast(int, R.mp.v[0]);
+                float mp[kVec] = {0.f, 0.f, 0.f, 0.f};
+                for (int k = 0; k < a.kc_wide; ++k) {
+                    const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xbits, k));
+                    const F4 wk = ld4(wlds + k * kGenesPerBlock + lane * kVec);
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) mp[v] = fmaf(xk, wk.v[v], mp[v]);
+                }
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) R.mp.v[v] = mp[v];
+            }
             float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
                   ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
 #pragma unroll
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 float m = cell ? rs.cb : bj[v];
-                if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc from the GEMM
+                if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc (LDS tile)
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
                 if constexpr (CPL) {
@@ -506,7 +529,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
                 R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
                 R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
-                if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for the Xc^T.r GEMM
+                if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for wide_design_grad
                 // per-gene sufficient statistics
 #pragma unroll
                 for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
@@ -515,7 +538,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 acc[KC + 2][v] += kl;
                 acc[KC + 3][v] += ll[v] * a.inv_mc;
             }
-            if (!CPL || active) {
+            if ((!CPL && !WIDE) || active) {
                 st4s(mu_p + off, R.mu);
                 st4s(rho_p + off, R.rho);
                 st4s(mmu_p + off, R.mm);
@@ -1020,14 +1043,95 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
     }
 }
 
-// wide designs: Adam for Wc_loc from G = Xc^T . r (GEMM output), dL/dW = -G
-__global__ void wide_w_adam(float *W, float *mW, float *vW, const float *G, int64_t n, float alpha,
+// wide designs, forward only (loss_gene_eval reads it): Mbuf = Xc . Wc_loc, tiled like the state arrays
+__global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const float *W, float *Mbuf, int Nc, int Ng,
+                                                          int Kc, int64_t ld, int64_t row_stride, int64_t gb_stride,
+                                                          int rows_per_chunk) {
+    __shared__ float wlds[kWideKcMax * kGenesPerBlock];
+    for (int i = threadIdx.x; i < Kc * kGenesPerBlock; i += kBlock)
+        wlds[i] = W[static_cast<int64_t>(i / kGenesPerBlock) * ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = blockIdx.y * rows_per_chunk;
+    const int row_end = min(row0 + rows_per_chunk, Nc);
+    const int64_t mbase = static_cast<int64_t>(blockIdx.x) * gb_stride + lane * kVec;
+    for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
+        const int xbits = __builtin_bit_cast(int, lane < Kc ? Xc[static_cast<int64_t>(r) * Kc + lane] : 0.0f);
+        F4 m = {{0.f, 0.f, 0.f, 0.f}};
+        for (int k = 0; k < Kc; ++k) {
+            const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xbits, k));
+            const F4 wk = ld4(wlds + k * kGenesPerBlock + lane * kVec);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) m.v[v] = fmaf(xk, wk.v[v], m.v[v]);
+        }
+        st4(Mbuf + mbase + static_cast<int64_t>(r) * row_stride, m);
+    }
+}
+
+// wide designs, backward: G = Xc^T . r reduced over the cells of one chunk on the matrix cores.
+// One 512-thread workgroup = 8 waves = the 8 32-gene slices of a 256-gene block; per MFMA
+// (v_mfma_f32_32x32x2_f32, exact fp32 fma chain) a wave consumes 2 cells x 32 genes of r and
+// 32 features x 2 cells of Xc:  A[i = feature][k = cell], B[k = cell][j = gene],
+// D[i][j]: lane l, reg q -> j = l & 31, i = (q & 3) + 8 (q >> 2) + 4 (l >> 5).
+// Gpart: (n_chunks, Kc, ld) partial sums, reduced in fp64 by wide_w_adam.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>      // 1: Kc <= 32, 2: Kc <= 64
+__global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict__ Xc, const float *__restrict__ R,
+                                                        float *__restrict__ Gpart, int Nc, int Kc, int64_t ld,
+                                                        int64_t gb_stride, int rows_per_chunk) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x >> 6;                        // gene slice 0..7
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.y * rows_per_chunk;
+    const int row_end = min(row0 + rows_per_chunk, Nc);
+    const float *rp = R + static_cast<int64_t>(blockIdx.x) * gb_stride + w * 32 + l31;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][q] = 0.0f;
+    constexpr int U = 8;                                   // 8 cell pairs of loads in flight per wave
+    for (int r = row0; r < row_end; r += 2 * U) {
+        float bval[U], aval[U][NACC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int rr = r + 2 * u + half;
+            const bool ok = rr < row_end;
+            bval[u] = ok ? rp[static_cast<int64_t>(rr) * kGenesPerBlock] : 0.0f;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int feat = l31 + 32 * a;
+                aval[u][a] = (ok && feat < Kc) ? Xc[static_cast<int64_t>(rr) * Kc + feat] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval[u][a], bval[u], acc[a], 0, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int feat = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * a;
+            if (feat < Kc)
+                Gpart[(static_cast<int64_t>(blockIdx.y) * Kc + feat) * ld + blockIdx.x * kGenesPerBlock + w * 32 + l31] =
+                    acc[a][q];
+        }
+}
+
+// wide designs: Adam for Wc_loc, dL/dW = -G with G = sum over chunks of Gpart (fp64)
+__global__ void wide_w_adam(float *W, float *mW, float *vW, const float *Gpart, int64_t n, int n_chunks, float alpha,
                             const float *gene_active, int64_t ld) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         if (gene_active[i % ld] == 0.0f) continue;
+        double g = 0.0;
+        for (int c = 0; c < n_chunks; ++c) g += static_cast<double>(Gpart[static_cast<int64_t>(c) * n + i]);
         float x = W[i], m = mW[i], v = vW[i];
-        adam_scalar(x, m, v, -G[i], alpha);
+        adam_scalar(x, m, v, static_cast<float>(-g), alpha);
         W[i] = x; mW[i] = m; vW[i] = v;
     }
 }

@@ -20,8 +20,7 @@ struct LaunchCfg {
     dim3 grid;
     hipStream_t stream;
     int coupled;   // 1: gene features and/or per-cell intercept (CoupledArgs valid)
-    const float *mbuf = nullptr;   // wide designs (Kc > 8): Xc.Wc_loc from the GEMM ...
-    float *rbuf = nullptr;         // ... and the residual buffer for Xc^T.r
+    float *rbuf = nullptr;         // wide designs (Kc > 8): residual buffer read back by wide_design_grad
 };
 
 #define BRIE_DECLARE_KC(N)                                                                          \
@@ -32,7 +31,7 @@ struct LaunchCfg {
 BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE_DECLARE_KC(4)
 BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)
 #undef BRIE_DECLARE_KC
-// wide cell designs: KC == 0 kernels that read / write the GEMM buffers (defined in the kc0 unit)
+// wide cell designs: KC == 0 kernels with the W tile in LDS, writing the residual buffer (defined in the kc0 unit)
 void launch_step_wide(const LaunchCfg &, const StepPointers &, const StepScalars &);
 
 }  // namespace brie

@@ -89,7 +89,7 @@ typedef struct brie_problem {
 } brie_problem;
 
 #define BRIE_MAX_KC 8         /* cell features fused into the streaming kernel (Xc row in SGPRs) */
-#define BRIE_MAX_KC_WIDE 64   /* wider designs: Xc.W and Xc^T.r as fp32 MFMA GEMMs (rocBLAS, loaded at run time) */
+#define BRIE_MAX_KC_WIDE 64   /* wider designs: W tile in LDS for Xc.W, hand-written fp32 MFMA kernel for Xc^T.r */
 #define BRIE_MAX_KG 4
 
 typedef struct brie_handle brie_handle;

@@ -17,7 +17,7 @@
 //                    Keras Adam / clip constraints for Z_loc, Z_std_log (:69,81,237-241)
 //   gene_finalize    reduce_sum over cells (:208-211) + Adam for Wc_loc,
 //                    intercept, sigma_log
-//   loss_gene_eval   :261-264   psi_epilogue :88-106   init_state :12-31
+//   loss_gene_eval   :261-264   export_rowmajor :88-106   init_state :12-31
 //   pseudo_count     brie/models/model_wrap.py:113-117
 #pragma once
 #include <hip/hip_runtime.h>
@@ -1328,28 +1328,9 @@ __global__ void log_rows(float *effL, int64_t ld, int Ng) {
     for (int s = 0; s < 3; ++s) effL[(3 + s) * ld + j] = logf(effL[s * ld + j]);
 }
 
-// mode 0: Psi = sigmoid(mu); 1: Z_std = exp(rho); 2: CI95 = sig(mu+z s) - sig(mu-z s)
 __device__ __forceinline__ float sigmoid_acc(float x) {
     const float e = expf(-fabsf(x));
     return x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-}
-__global__ void psi_epilogue(const float *mu, const float *rho, float *out, int64_t n4, int mode) {
-    constexpr float kZ975 = 1.959963984540054f;     // ndtri(0.975)
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const F4 m = ld4(mu + 4 * i), r = ld4(rho + 4 * i);
-        F4 o;
-#pragma unroll
-        for (int v = 0; v < kVec; ++v) {
-            if (mode == 0) o.v[v] = sigmoid_acc(m.v[v]);
-            else if (mode == 1) o.v[v] = expf(r.v[v]);
-            else {
-                const float s = expf(r.v[v]);
-                o.v[v] = sigmoid_acc(m.v[v] + kZ975 * s) - sigmoid_acc(m.v[v] - kZ975 * s);
-            }
-        }
-        st4(out + 4 * i, o);
-    }
 }
 
 // Read-back kernel: state / derived array -> ROW-MAJOR (Nc, Ng) contiguous buffer (one coalesced 1-KiB

@@ -14,6 +14,9 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def lib():
-    """The HIP extension; GPU tests must fail loudly (not skip) if it is missing."""
+    """The HIP extension; GPU tests must fail loudly (not skip) if it cannot be had.
+    If the in-tree library is absent or older than its sources it is (re)built first (hipcc is in the image)."""
     from brie_amd import _capi
+    from brie_amd.build import compile_library
+    compile_library()
     return _capi.load_library()

@@ -244,3 +244,27 @@ def test_marginlik_gradients_match_autograd(L, Kc, MC, mode, Kg):
     tr = o.minimize(cnt, P["Xc"], 8, 0.02, MC, target="marginLik")
     np.testing.assert_array_equal(o.Z_loc, z0)                   # the posterior is not part of this objective
     assert np.all(np.isfinite(tr)) and tr[-1] < tr[0] + 1e-6 * abs(tr[0])
+
+
+def test_kl_and_quantiles_against_independent_libraries():
+    """Independent pins of two TFP formulas the oracle restates: Normal-Normal KL (vs torch.distributions)
+    and the logit-normal 2.5 % / 97.5 % quantiles (vs scipy.stats.norm.ppf + expit)."""
+    from scipy.stats import norm
+    rng = np.random.default_rng(12)
+    Nc, Ng, Kc = 9, 7, 2
+    init = dict(Z_loc=rng.standard_normal((Nc, Ng)), Z_std_log=rng.standard_normal((Nc, Ng)) * 0.7,
+                Wc_loc=rng.standard_normal((Kc, Ng)), intercept=rng.standard_normal((1, Ng)),
+                sigma_log=rng.standard_normal((1, Ng)) * 0.5)
+    Xc = rng.standard_normal((Nc, Kc))
+    o = OracleBRIE2(Nc, Ng, Kc, dtype=np.float64, init=init)
+    zero = [np.zeros((Nc, Ng))] * 2
+    out = o.loss_and_grads(zero, Xc, 1)                       # zero counts => loss is exactly sum KL
+    q = torch.distributions.Normal(torch.tensor(init["Z_loc"]), torch.tensor(np.exp(init["Z_std_log"])))
+    p = torch.distributions.Normal(torch.tensor(Xc @ init["Wc_loc"] + init["intercept"]),
+                                   torch.tensor(np.exp(init["sigma_log"])).expand(Nc, Ng))
+    kl = torch.distributions.kl_divergence(q, p).numpy()
+    np.testing.assert_allclose(out["loss"], kl.sum(), rtol=1e-12)
+    np.testing.assert_allclose(out["kl_gene"], kl.sum(0), rtol=1e-12)
+    s = np.exp(init["Z_std_log"])
+    width = expit(init["Z_loc"] + norm.ppf(0.975) * s) - expit(init["Z_loc"] + norm.ppf(0.025) * s)
+    np.testing.assert_allclose(o.Psi95CI, width, rtol=1e-10)

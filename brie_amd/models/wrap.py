@@ -1,15 +1,14 @@
 """Host orchestration around `BRIE2`: result object, LRT driver, AnnData front end.
 
-Same names, arguments, defaults and outputs as
-/root/reference/brie/models/model_wrap.py (`BRIE_RV` 15-75, `concate` 78-85,
-`fit_BRIE_matrix` 88-199, `fitBRIE` 202-314).  Differences, all because the
-whole gene shard is fitted concurrently on the GPU:
- * `batch_size` is accepted and ignored unless `emulate_batches=True`
-   (then genes are fitted in reference-sized sequential batches);
- * the pseudo-count is applied to the device copy of the counts, the caller's
-   arrays are left untouched (the reference mutates them in place, :115-117);
- * with torch.distributed initialised (one process per GPU) genes are sharded
-   over ranks and per-gene outputs are all-gathered (brie_amd/sharding.py).
+Same names, arguments, defaults and outputs as /root/reference/brie/models/model_wrap.py
+(`BRIE_RV` 15-75, `concate` 78-85, `fit_BRIE_matrix` 88-199, `fitBRIE` 202-314).  What is different,
+all because the whole gene shard is fitted concurrently on the GPU:
+ * genes are not fitted batch after batch; `batch_size` only defines the per-batch convergence groups
+   (`conv_batch_genes`), unless `emulate_batches=True` asks for the literal sequential batches;
+ * the pseudo-count is applied to the device copy of the counts, the caller's arrays are left untouched
+   (the reference mutates them in place, :115-117);
+ * with torch.distributed initialised (one process per GPU) genes are sharded over ranks and per-gene
+   outputs are all-gathered (brie_amd/sharding.py).
 """
 import numpy as np
 
@@ -18,203 +17,207 @@ from ..stats import elbo_gain_pval, fdr_bh
 
 verbosity = 3      # brie/settings.py:4
 
+#: result attribute <- model attribute (model_wrap.py:28-38)
+_RV_FIELDS = (("sigma", "sigma"), ("intercept", "intercept"), ("cell_coeff", "Wc_loc"), ("gene_coeff", "Wg_loc"),
+              ("Psi", "Psi"), ("Psi95CI", "Psi95CI"), ("Z_loc", "Z_loc"), ("Z_std", "Z_std"),
+              ("losses", "losses"), ("loss_gene", "loss_gene"))
+#: arrays joined along the gene axis by `concate` (model_wrap.py:63-69) and along axis 0 (:71-75)
+_GENE_AXIS1 = ("sigma", "intercept", "cell_coeff", "Psi", "Psi95CI", "Z_std", "Z_loc")
+_GENE_AXIS0 = ("fdr", "pval", "ELBO_gain")
 
-def _np(x):
+
+def _host(x):
     return np.asarray(x.numpy() if hasattr(x, "numpy") else x)
 
 
 class BRIE_RV(object):
-    """Return value object for a fitted BRIE2 model (model_wrap.py:15-48)."""
+    """Host snapshot of a fitted BRIE2 model (model_wrap.py:15-48)."""
 
     def __init__(self, model):
-        self.Nc, self.Ng, self.Kc, self.Kg = model.Nc, model.Ng, model.Kc, model.Kg
-        self.shape = (self.Nc, self.Ng)
-        self.Xc, self.Xg = model.Xc, model.Xg
-        self.sigma = _np(model.sigma)
-        self.intercept = _np(model.intercept)
-        self.cell_coeff = _np(model.Wc_loc)
-        self.gene_coeff = _np(model.Wg_loc)
-        self.Psi = _np(model.Psi)
-        self.Psi95CI = _np(model.Psi95CI)
-        self.Z_loc = _np(model.Z_loc)
-        self.Z_std = _np(model.Z_std)
-        self.losses = _np(model.losses)
-        self.loss_gene = _np(model.loss_gene)
-        self.intercept_mode = model.intercept_mode
+        for dim in ("Nc", "Ng", "Kc", "Kg", "Xc", "Xg", "intercept_mode"):
+            setattr(self, dim, getattr(model, dim))
+        for mine, theirs in _RV_FIELDS:
+            setattr(self, mine, _host(getattr(model, theirs)))
 
-    @property
-    def Wc_loc(self):
-        return self.cell_coeff
-
-    @property
-    def Wg_loc(self):
-        return self.gene_coeff
+    shape = property(lambda self: (self.Nc, self.Ng))
+    Wc_loc = property(lambda self: self.cell_coeff)
+    Wg_loc = property(lambda self: self.gene_coeff)
 
     def __str__(self):
         return "BRIE2 results for %d cells and %d genes" % (self.Nc, self.Ng)
 
-    def concate(self, new_RV, axis=1):
-        """Gene-axis concatenation (model_wrap.py:53-75)."""
+    def concate(self, other, axis=1):
+        """Append another result along the gene axis (model_wrap.py:53-75); loss traces are laid end to end."""
         if axis != 1:
             print("Warning: only suppoting gene level concate!")
             return None
-        self.Ng += new_RV.Ng
-        self.shape = (self.Nc, self.Ng)
-        self.losses = np.append(self.losses, new_RV.losses)
-        self.loss_gene = np.append(self.loss_gene, new_RV.loss_gene)
-        for key in ("sigma", "intercept", "cell_coeff", "Psi", "Psi95CI", "Z_std", "Z_loc"):
-            setattr(self, key, np.append(getattr(self, key), getattr(new_RV, key), axis=1))
-        if hasattr(new_RV, 'ELBO_gain'):
-            for key in ("fdr", "pval", "ELBO_gain"):
-                setattr(self, key, np.append(getattr(self, key), getattr(new_RV, key), axis=0))
+        self.Ng = self.Ng + other.Ng
+        for key in ("losses", "loss_gene"):
+            setattr(self, key, np.append(getattr(self, key), getattr(other, key)))
+        for key in _GENE_AXIS1:
+            setattr(self, key, np.append(getattr(self, key), getattr(other, key), axis=1))
+        if hasattr(other, 'ELBO_gain'):
+            for key in _GENE_AXIS0:
+                setattr(self, key, np.append(getattr(self, key), getattr(other, key), axis=0))
 
 
 def concate(BRIE_RV_list):
-    """Concatenate a list of BRIE results (model_wrap.py:78-85)."""
-    res_merge = BRIE_RV_list[0]
-    for _res in BRIE_RV_list[1:]:
-        res_merge.concate(_res)
-    return res_merge
+    """Fold a list of per-batch results into the first one (model_wrap.py:78-85)."""
+    merged = BRIE_RV_list[0]
+    for nxt in BRIE_RV_list[1:]:
+        merged.concate(nxt)
+    return merged
 
 
-def _n_genes(layer):
-    return layer.shape[1]
+def _design_for_base(Xc, LRT_index, base_mode, Nc):
+    """Features of the base model (model_wrap.py:130-136): all of them ('full'), or all but the tested ones."""
+    if base_mode.upper() == 'FULL':
+        return Xc.copy()
+    if LRT_index is not None and len(LRT_index) < Xc.shape[1]:
+        return np.delete(Xc, LRT_index, axis=1)
+    return np.ones((Nc, 0), np.float32)
 
 
 def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, intercept_mode='gene',
                     LRT_index=None, pseudo_count=0.01, sigma=None, base_mode='full',
                     tau_prior=[3, 27], seed=0, device=0, gene_offset=0, comm=None, **keyargs):
-    """Fit a BRIE model with cell features on count matrices (model_wrap.py:88-199).
+    """Fit a BRIE model with cell / gene features on count matrices (model_wrap.py:88-199).
 
-    data : list of 2 or 3 (Nc, Ng) matrices (ndarray, scipy sparse, or torch tensors in HBM)
-    Xc   : (Nc, Kc) float32 cell features;  Xg : (Ng, Kg) -- Kg must be 0
-    **keyargs : forwarded to BRIE2.fit (min_iter, max_iter, add_iter, epsilon_conv, MC_size, verbose)
+    data : list of 2 or 3 (Nc, Ng) matrices (ndarray, scipy sparse, or torch tensors already in HBM)
+    Xc   : (Nc, Kc) float32 cell features;  Xg : (Ng, Kg) float32 gene features
+    LRT_index : cell features to test by ELBO gain (None = all, [] = none)
+    **keyargs : forwarded to BRIE2.fit (min_iter, max_iter, add_iter, epsilon_conv, MC_size, verbose, ...)
     """
-    Nc, Ng = data[0].shape[0], _n_genes(data[0])
+    Nc, Ng = data[0].shape[0], data[0].shape[1]
     print("[BRIE2] adding pseudo_count:", pseudo_count)
-    if Xc is None:
-        Xc = np.ones((Nc, 0), np.float32)
-    if Xg is None:
-        Xg = np.ones((Ng, 0), np.float32)
-    Xc = np.asarray(Xc, np.float32)
+    Xc = np.ones((Nc, 0), np.float32) if Xc is None else np.asarray(Xc, np.float32)
+    Xg = np.ones((Ng, 0), np.float32) if Xg is None else Xg
+    full_base = base_mode.upper() == 'FULL'
+    Xc_base = _design_for_base(Xc, LRT_index, base_mode, Nc)
 
-    if base_mode.upper() == 'FULL':                                   # model_wrap.py:130-136
-        Xc_base = Xc.copy()
-    elif LRT_index is not None and len(LRT_index) < Xc.shape[1]:
-        Xc_base = np.delete(Xc, LRT_index, axis=1)
-    else:
-        Xc_base = np.ones((Nc, 0), np.float32)
-
-    def run(Xc_fit, fit_seed, mode=intercept_mode):
-        mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=Xc_fit.shape[1], Kg=Xg.shape[1], effLen=effLen,
-                    intercept=intercept, intercept_mode=mode, sigma=sigma,
-                    tau_prior=tau_prior, seed=fit_seed, device=device, gene_offset=gene_offset, comm=comm)
-        mdl.fit(data, Xc=Xc_fit, Xg=Xg, pseudo_count=pseudo_count, **keyargs)
+    def run(design, fit_seed, mode=intercept_mode):
+        mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=design.shape[1], Kg=Xg.shape[1], effLen=effLen, intercept=intercept,
+                    intercept_mode=mode, sigma=sigma, tau_prior=tau_prior, seed=fit_seed, device=device,
+                    gene_offset=gene_offset, comm=comm)
+        mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **keyargs)
         return mdl
 
-    model = run(Xc_base, seed)
-    brie_results = BRIE_RV(model)
-    model.close()
+    base = run(Xc_base, seed)
+    result = BRIE_RV(base)
+    base.close()
 
-    if LRT_index is None:                                             # model_wrap.py:149-153
-        LRT_index = np.arange(Xc.shape[1])
-    if len(LRT_index) == 0:
-        return brie_results
+    tested = np.arange(Xc.shape[1]) if LRT_index is None else LRT_index            # model_wrap.py:149-153
+    if len(tested) == 0:
+        return result
 
-    # ELBO gain in analogy to a likelihood ratio (model_wrap.py:155-187)
-    ELBO_gain = np.zeros((Ng, len(LRT_index)), dtype=np.float32)
-    for ii, idx in enumerate(LRT_index):
-        if base_mode.upper() == 'FULL':
-            if verbosity == 3:
-                print("[BRIE2] fitting null model without feature %d" % (idx))
-            Xc_test = np.delete(Xc, idx, 1)
+    # ELBO gain per tested feature, in analogy to a likelihood ratio (model_wrap.py:155-187):
+    # 'full' base: refit WITHOUT the feature, gain = loss(reduced) - loss(full);
+    # 'null' base: refit WITH the feature added, gain = loss(base) - loss(extended), its weight is kept.
+    gain = np.zeros((Ng, len(tested)), dtype=np.float32)
+    for col, feat in enumerate(tested):
+        if verbosity == 3:
+            print("[BRIE2] fitting null model without feature %d" % feat if full_base
+                  else "[BRIE2] fitting test model by add feature %d" % feat)
+        design = np.delete(Xc, feat, 1) if full_base else np.append(Xc_base, Xc[:, feat:(feat + 1)], axis=1)
+        # the reference builds these models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always with
+        # the 'gene' default, whatever the base model uses -- mirrored
+        other = run(design, seed + 1 + col, mode='gene')
+        other_loss = _host(other.loss_gene)
+        if full_base:
+            gain[:, col] = other_loss - result.loss_gene
         else:
-            if verbosity == 3:
-                print("[BRIE2] fitting test model by add feature %d" % (idx))
-            Xc_test = np.append(Xc_base, Xc[:, idx:(idx + 1)], axis=1)
-        # the reference builds the test models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always
-        # with the 'gene' default, whatever the base model uses -- mirrored
-        model_test = run(Xc_test, seed + 1 + ii, mode='gene')
-        test_loss_gene = _np(model_test.loss_gene)
-        if base_mode.upper() == 'FULL':
-            ELBO_gain[:, ii] = test_loss_gene - brie_results.loss_gene
-        else:
-            ELBO_gain[:, ii] = brie_results.loss_gene - test_loss_gene
-            brie_results.cell_coeff = np.append(brie_results.cell_coeff,
-                                                _np(model_test.Wc_loc)[-1:, :], axis=0)
-        model_test.close()
+            gain[:, col] = result.loss_gene - other_loss
+            result.cell_coeff = np.append(result.cell_coeff, _host(other.Wc_loc)[-1:, :], axis=0)
+        other.close()
 
-    brie_results.ELBO_gain = ELBO_gain                                # H1 vs null
-    brie_results.pval = elbo_gain_pval(ELBO_gain)                     # model_wrap.py:190
-    fdr = np.zeros(ELBO_gain.shape)
-    for i in range(fdr.shape[1]):
-        fdr[:, i] = fdr_bh(brie_results.pval[:, i])                   # model_wrap.py:193-195
-    brie_results.fdr = fdr
-    return brie_results
+    result.ELBO_gain = gain
+    result.pval = elbo_gain_pval(gain)                                             # chi2.sf(2 gain, 1), :190
+    result.fdr = np.stack([fdr_bh(result.pval[:, c]) for c in range(gain.shape[1])], axis=1)   # BH per feature, :193-195
+    return result
 
 
 def _gene_slice(x, g0, g1):
-    if hasattr(x, "tocsc"):
-        return x.tocsc()[:, g0:g1]
-    return x[:, g0:g1]
+    return x.tocsc()[:, g0:g1] if hasattr(x, "tocsc") else x[:, g0:g1]
+
+
+def _write_back(adata, res, Xc, Xg, put_layer, LRT_index, params):
+    """The AnnData keys of model_wrap.py:272-311."""
+    if Xc.shape[0] > 0:
+        adata.obsm['Xc'], adata.varm['cell_coeff'] = Xc, res.cell_coeff.T
+    if Xg.shape[1] > 0:
+        adata.varm['Xg'], adata.obsm['gene_coeff'] = Xg, res.gene_coeff
+    per_gene = res.intercept_mode == 'gene'
+    per_cell = res.intercept_mode == 'cell'
+    if per_gene:
+        adata.varm['intercept'] = res.intercept.T
+    if per_cell:
+        adata.obsm['intercept'], adata.obsm['sigma'] = res.intercept, res.sigma
+    else:                                            # 'gene' and every other spelling (e.g. the CLI's "None")
+        adata.varm['sigma'] = res.sigma.T
+    for key, attr in (('Psi', 'Psi'), ('Z_std', 'Z_std'), ('Psi_95CI', 'Psi95CI')):
+        put_layer(key, getattr(res, attr))
+    adata.uns['brie_losses'] = res.losses
+    adata.var['loss_gene'] = res.loss_gene
+    if LRT_index is None or len(LRT_index) >= 1:
+        for key in ('fdr', 'pval', 'ELBO_gain'):
+            adata.varm[key] = getattr(res, key)
+    adata.uns['brie_param'] = params
 
 
 def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_index=[],
             layer_keys=['isoform1', 'isoform2', 'ambiguous'], batch_size=500000,
             pseudo_count=0.01, sigma=None, base_mode='full', tau_prior=[3, 27],
             seed=0, device=0, emulate_batches=False, comm=None, gather_layers=True, **keyargs):
-    """Fit a BRIE model from an AnnData-like object (model_wrap.py:202-314).
+    """Fit a BRIE model from an AnnData-like object and write the results back (model_wrap.py:202-314).
 
-    `adata` needs `.shape`, `.layers`, `.varm`, `.obsm`, `.var`, `.uns`
-    (anndata.AnnData or any duck-typed stand-in).  Writes the same keys back.
-    New optional arguments: seed, device, emulate_batches, comm (a
-    `brie_amd.sharding.GeneComm`; one process per GPU, genes sharded over ranks).
+    `adata` needs `.shape`, `.layers`, `.varm`, `.obsm`, `.var`, `.uns` (anndata.AnnData,
+    brie_amd.io.CountData, or any duck-typed stand-in).  New optional arguments: seed, device,
+    emulate_batches, comm (a `brie_amd.sharding.GeneComm`: one process per GPU, genes sharded over
+    ranks), gather_layers.
     """
     Nc, Ng = adata.shape[0], adata.shape[1]
-    if Xc is None:
-        Xc = np.ones((Nc, 0), np.float32)
-    if Xg is None:
-        Xg = np.ones((Ng, 0), np.float32)
-    if LRT_index is None:
-        LRT_index = np.arange(Xc.shape[1])
+    Xc = np.ones((Nc, 0), np.float32) if Xc is None else Xc
+    Xg = np.ones((Ng, 0), np.float32) if Xg is None else Xg
+    LRT_index = np.arange(Xc.shape[1]) if LRT_index is None else LRT_index
     layer_keys = [k for k in layer_keys if k in adata.layers]
     has_eff = 'effLen' in adata.varm
-    separable = (Xg is None or Xg.shape[1] == 0) and intercept_mode.upper() != 'CELL'   # model_wrap.py:241
+    # genes are independent unless gene features or per-cell intercepts tie them together (model_wrap.py:241)
+    separable = Xg.shape[1] == 0 and intercept_mode.upper() != 'CELL'
 
     def fit_range(g0, g1, sub_seed):
         layers = [_gene_slice(adata.layers[k], g0, g1) for k in layer_keys]
-        eff = adata.varm['effLen'][g0:g1, :] if has_eff else None
-        return fit_BRIE_matrix(layers, Xc=Xc, Xg=Xg[g0:g1, :], effLen=eff, intercept=intercept,
-                               intercept_mode=intercept_mode, LRT_index=LRT_index,
-                               pseudo_count=pseudo_count, sigma=sigma, base_mode=base_mode,
-                               tau_prior=tau_prior, seed=sub_seed, device=device, gene_offset=g0,
+        return fit_BRIE_matrix(layers, Xc=Xc, Xg=Xg[g0:g1, :], effLen=adata.varm['effLen'][g0:g1, :] if has_eff else None,
+                               intercept=intercept, intercept_mode=intercept_mode, LRT_index=LRT_index,
+                               pseudo_count=pseudo_count, sigma=sigma, base_mode=base_mode, tau_prior=tau_prior,
+                               seed=sub_seed, device=device, gene_offset=g0,
                                comm=None if separable else comm, **keyargs)
 
     g_lo, g_hi = 0, Ng
-    if comm is not None and comm.world > 1:
-        # separable fits shard freely; coupled fits (Kg > 0 / cell mode) shard the genes too and
-        # all-reduce the per-cell statistics every step (brie_step_begin/_end)
+    sharded = comm is not None and comm.world > 1
+    if sharded:
+        # separable fits shard freely; coupled fits (Kg > 0 / cell mode) shard the genes too and all-reduce the
+        # per-cell statistics every step (brie_step_begin/_end).  The loss trace is summed over ranks so that
+        # every rank takes the same convergence decisions.
         from ..sharding import gene_shard
         g_lo, g_hi = gene_shard(Ng, comm.rank, comm.world)
-        # the loss trace is summed over ranks so every rank takes the same convergence decision
         keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
 
-    if separable and not emulate_batches and 'conv_batch_genes' not in keyargs:
-        # all genes are fitted concurrently; each reference-sized batch still stops on its own loss window
-        keyargs = dict(keyargs, conv_batch_genes=int(np.ceil(batch_size / Nc)))
-    if separable and emulate_batches:                                 # model_wrap.py:242-260
-        _n_gene = int(np.ceil(batch_size / Nc))
-        _n_gene = max(4, (_n_gene + 3) // 4 * 4)                      # noise stream is keyed per gene quad
-        res_list = []
-        for g0 in range(g_lo, g_hi, _n_gene):
-            res_list.append(fit_range(g0, min(g0 + _n_gene, g_hi), seed))
-            print("[BRIE2] %d out %d genes done" % (min(g0 + _n_gene, g_hi), Ng))
-        ResVal = concate(res_list)
+    n_batch_genes = int(np.ceil(batch_size / Nc))                     # model_wrap.py:242
+    if separable and emulate_batches:                                 # the literal loop of model_wrap.py:244-260
+        step = max(4, (n_batch_genes + 3) // 4 * 4)                   # the noise stream is keyed per gene quad
+        parts = []
+        for g0 in range(g_lo, g_hi, step):
+            parts.append(fit_range(g0, min(g0 + step, g_hi), seed))
+            print("[BRIE2] %d out %d genes done" % (min(g0 + step, g_hi), Ng))
+        ResVal = concate(parts)
     else:
+        if separable and 'conv_batch_genes' not in keyargs:
+            # all genes at once, but each reference-sized batch still stops on its own loss window
+            keyargs = dict(keyargs, conv_batch_genes=n_batch_genes)
         ResVal = fit_range(g_lo, g_hi, seed)
 
     ResVal.gene_range = (g_lo, g_hi)
-    if comm is not None and comm.world > 1:                           # RCCL all-gather of per-gene vectors
+    if sharded:                                                       # RCCL all-gather of the per-gene vectors
         if ResVal.sigma.shape[0] == 1:                                # (Nc,1) cell-mode vectors are replicated
             ResVal.sigma = comm.allgather_genes(ResVal.sigma, Ng)
             ResVal.intercept = comm.allgather_genes(ResVal.intercept, Ng)
@@ -226,45 +229,21 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
             ResVal.pval = elbo_gain_pval(ResVal.ELBO_gain)
             ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
 
-    # update adata (model_wrap.py:272-311).  Sharded fits: rank 0 receives the full cell x gene layers
-    # (gather_layers=True, one gather per layer at the very end); other ranks keep `<key>_shard`.
-    full = (g_lo, g_hi) == (0, Ng)
+    whole = (g_lo, g_hi) == (0, Ng)
 
     def put_layer(key, local):
-        if full:
+        """Cell x gene outputs: the full layer when this process holds all genes; otherwise `<key>_shard`
+        everywhere and, with gather_layers, the full layer on rank 0 (one gather per layer at the very end)."""
+        if whole:
             adata.layers[key] = local
             return
         adata.layers[key + '_shard'] = local
         if gather_layers:
-            whole = comm.gather_columns(local, Ng)
-            if whole is not None:
-                adata.layers[key] = whole
-    if Xc.shape[0] > 0:
-        adata.obsm['Xc'] = Xc
-        adata.varm['cell_coeff'] = ResVal.cell_coeff.T
-    if Xg.shape[1] > 0:
-        adata.varm['Xg'] = Xg
-        adata.obsm['gene_coeff'] = ResVal.gene_coeff
-    if ResVal.intercept_mode == 'gene':
-        adata.varm['intercept'] = ResVal.intercept.T
-        adata.varm['sigma'] = ResVal.sigma.T
-    elif ResVal.intercept_mode == 'cell':
-        adata.obsm['intercept'] = ResVal.intercept
-        adata.obsm['sigma'] = ResVal.sigma
-    else:
-        adata.varm['sigma'] = ResVal.sigma.T
-    put_layer('Psi', ResVal.Psi)
-    put_layer('Z_std', ResVal.Z_std)
-    put_layer('Psi_95CI', ResVal.Psi95CI)
-    adata.uns['brie_losses'] = ResVal.losses
-    adata.var['loss_gene'] = ResVal.loss_gene
-    if LRT_index is None or len(LRT_index) >= 1:
-        adata.varm['fdr'] = ResVal.fdr
-        adata.varm['pval'] = ResVal.pval
-        adata.varm['ELBO_gain'] = ResVal.ELBO_gain
-    adata.uns['brie_param'] = {
-        'LRT_index': LRT_index, 'base_mode': base_mode, 'intecept': intercept,
-        'intercept_mode': intercept_mode, 'sigma': sigma, 'pseudo_count': pseudo_count,
-        'layer_keys': layer_keys, 'gene_range': (g_lo, g_hi),
-    }
+            full = comm.gather_columns(local, Ng)
+            if full is not None:
+                adata.layers[key] = full
+
+    _write_back(adata, ResVal, Xc, Xg, put_layer, LRT_index, {
+        'LRT_index': LRT_index, 'base_mode': base_mode, 'intecept': intercept, 'intercept_mode': intercept_mode,
+        'sigma': sigma, 'pseudo_count': pseudo_count, 'layer_keys': layer_keys, 'gene_range': (g_lo, g_hi)})
     return ResVal

@@ -31,19 +31,11 @@ def filter_genes(data, min_counts=0, min_cells=0, min_counts_uniq=0, min_cells_u
     out.var['n_counts'] = n_tot[keep]
     out.var['n_counts_uniq'] = n_unq[keep]
     dropped = int(np.sum(~keep))
-    if dropped > 0:
-        terms = []
-        if min_cells > 0:
-            terms.append('%d cells with any count' % min_cells)
-        if min_counts > 0:
-            terms.append('%d total counts' % min_counts)
-        if min_cells_uniq > 0:
-            terms.append('%d cells with unique counts' % min_cells_uniq)
-        if min_counts_uniq > 0:
-            terms.append('%d unique counts' % min_counts_uniq)
-        if min_MIF_uniq > 0:
-            terms.append('%.4f minor isoform frequency' % min_MIF_uniq)
-        print('Filtered out %d genes with less than ' % dropped + " or ".join(terms))
+    if dropped:
+        rules = [("%d cells with any count", min_cells), ("%d total counts", min_counts),
+                 ("%d cells with unique counts", min_cells_uniq), ("%d unique counts", min_counts_uniq),
+                 ("%.4f minor isoform frequency", min_MIF_uniq)]
+        print("Filtered out %d genes with less than " % dropped + " or ".join(t % v for t, v in rules if v > 0))
     return out
 
 

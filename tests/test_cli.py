@@ -41,7 +41,7 @@ def test_filter_genes_and_match_against_reference_fragments():
 
 def test_parser_defaults_match_reference_cli():
     from brie_amd.cli.quant import build_parser, parse_lrt_index
-    o, _ = build_parser().parse_args(["-i", "x.npz"])
+    o = build_parser().parse_args(["-i", "x.npz"])
     # /root/reference/brie/bin/quant.py:138-187
     assert (o.MC_size, o.min_iter, o.max_iter, o.batch_size, o.pseudo_count, o.nproc) == (3, 5000, 20000, 500000, 0.01, 6)
     assert (o.min_count, o.min_uniq_count, o.min_cell, o.min_MIF) == (50, 10, 30, 0.001)

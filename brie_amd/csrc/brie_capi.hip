@@ -95,6 +95,7 @@ struct brie_handle {
     void *pack_scratch = nullptr;   // one matrix-sized scratch buffer for the gathers (swaps with live arrays)
     size_t pack_scratch_bytes = 0;
     float *row_scratch = nullptr;   // scratch for per-gene row sets
+    float *io_scratch = nullptr;    // (Nc, ld) staging buffer of brie_read, allocated on first use and kept
     float *partials = nullptr;
     size_t partials_elems = 0;
     double *loss_parts = nullptr;
@@ -333,6 +334,14 @@ int ensure_identity(brie_handle *h) {
     return upload_quad_ids_and_blocks(h, h->mask_host);     // identity quad ids, block flags of the unpacked mask
 }
 
+// matrix-sized staging buffer for read-backs (kept: BRIE_RV reads four matrices in a row)
+int io_buffer(brie_handle *h, float **out) {
+    if (!h->io_scratch)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->io_scratch), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+    *out = h->io_scratch;
+    return BRIE_OK;
+}
+
 int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t *cols, int64_t *ldd) {
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     switch (which) {
@@ -520,6 +529,7 @@ int brie_destroy(brie_handle *h) {
     if (h->quad_ids) hipFree(h->quad_ids);
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
+    if (h->io_scratch) hipFree(h->io_scratch);
     for (void *q : h->cu)
         if (q) hipFree(q);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
@@ -1094,7 +1104,7 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         // kernel writes the array row-major and contiguous, then ONE copy crosses PCIe
         const int mode = which == BRIE_Z_LOC ? 3 : (which == BRIE_Z_STD_LOG ? 4 : which - BRIE_PSI);
         float *tmp = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * Ng * sizeof(float)));
+        if ((rc = io_buffer(h, &tmp)) != BRIE_OK) return rc;
         hipLaunchKernelGGL(brie::export_rowmajor, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * Nc * brie::kWave)),
                            dim3(256), 0, h->stream, h->mu, h->rho, tmp, static_cast<int>(Nc), static_cast<int>(Ng),
                            h->gene_blocks, h->row_stride, h->gb_stride, mode);
@@ -1107,7 +1117,6 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
                                      hipMemcpyDefault, h->stream);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-        hipFree(tmp);
         if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read array %d: %s", which, hipGetErrorString(e));
         return BRIE_OK;
     }
@@ -1135,12 +1144,11 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
             return fail(BRIE_ERR_INVALID, "array %d is (%lld, %lld)", which, (long long)Nc, (long long)Ng);
         float *tmp = nullptr;
         const int64_t n4 = Nc * h->ld / 4;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(Nc) * h->ld * sizeof(float)));
+        if ((rc = io_buffer(h, &tmp)) != BRIE_OK) return rc;
         hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
                            tmp, n4, h->pc, l < 2 ? 1 : 0, h->cs);
         rc = copy_cellgene(h, tmp, nullptr, dst, ld);
         hipError_t e = hipStreamSynchronize(h->stream);
-        hipFree(tmp);
         if (rc != BRIE_OK) return rc;
         if (e != hipSuccess) return fail(BRIE_ERR_HIP, "read compact counts: %s", hipGetErrorString(e));
         return BRIE_OK;

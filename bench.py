@@ -184,6 +184,7 @@ def main():
     if Kc:
         sh.upload(_capi.XC, Xc)
     sample_layers = [layers[l][:, :min(ng, 64)].cpu().numpy() for l in range(L)] if rank == 0 else None
+    eff_host = eff_all[:min(ng, 64)].cpu().numpy() if (L == 3 and rank == 0) else None
     Xc_host = Xc.cpu().numpy()
     del layers
     torch.cuda.empty_cache()
@@ -286,6 +287,28 @@ def main():
                           % (nb, n_gene, Nc, n_steps, el),
                 "gpu_over_cpu": value / eps_s,
             }
+            # second, separately labelled baseline: the same algorithm as ONE fused
+            # C/OpenMP pass (oracle/brie_oracle.c) on all host cores -- what a tuned CPU kernel reaches
+            try:
+                from oracle.c_oracle import COracle
+                from oracle.brie_oracle import add_pseudo_count
+                co = COracle(add_pseudo_count(sample_layers), Xc_host, effLen=None if L == 2 else eff_host, seed=seed)
+                co.minimize(2, 0.005, args.mc)
+                t0 = time.perf_counter()
+                co.minimize(3, 0.005, args.mc)
+                per_step = (time.perf_counter() - t0) / 3
+                n_fused = int(max(3, min(500, 0.5 * args.cpu_seconds / per_step)))
+                t0 = time.perf_counter()
+                co.minimize(n_fused, 0.005, args.mc)
+                el = time.perf_counter() - t0
+                fused = n_fused * Nc * sample_layers[0].shape[1] / el
+                out["cpu_baseline_fused"] = {
+                    "value": fused, "unit": "cell*gene*iterations/s", "cores": co.threads(), "kind": "port-fused",
+                    "sample": "%d genes x %d cells x %d Adam steps, fused C/OpenMP restatement (oracle/brie_oracle.c), %.1f s"
+                              % (sample_layers[0].shape[1], Nc, n_fused, el),
+                    "gpu_over_cpu": value / fused}
+            except Exception as exc:                      # gcc / OpenMP missing: the eager baseline above stands
+                out["cpu_baseline_fused"] = {"error": repr(exc)}
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -45,6 +45,8 @@ philox.py             shared counter-based N(0,1) stream (Philox4x32-10 + Box-Mu
 brie_oracle.py        NumPy restatement with hand-derived gradients (fp32 / fp64)
 brie_oracle_torch.py  eager torch-CPU autograd restatement in the reference's
                       execution shape; also the `cpu_baseline` ("port") of bench.py
+brie_oracle.c         fused C / OpenMP restatement of the step (second implementation; "cpu_baseline_fused")
+c_oracle.py           gcc build + ctypes driver of brie_oracle.c
 host_stats.py         chi2 / Benjamini-Hochberg restatement for the LRT driver
 synth.py              seeded synthetic count generator (SURVEY.md 8d recipe)
 """

@@ -1,0 +1,73 @@
+"""ctypes driver of oracle/brie_oracle.c (fused C / OpenMP restatement).  TEST INFRASTRUCTURE ONLY."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "brie_oracle.c")
+LIB = os.path.join(HERE, "_build", "libbrie_oracle.so")
+
+
+def build(force=False):
+    """gcc -O3 -fopenmp -> oracle/_build/libbrie_oracle.so"""
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(LIB), exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", SRC, "-o", LIB, "-lm"], check=True)
+    return LIB
+
+
+class _Problem(ctypes.Structure):
+    _fields_ = [("Nc", ctypes.c_int32), ("Ng", ctypes.c_int32), ("Kc", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("has_efflen", ctypes.c_int32), ("mc", ctypes.c_int32), ("train_b", ctypes.c_int32),
+                ("train_lam", ctypes.c_int32), ("gene_offset", ctypes.c_int64), ("seed", ctypes.c_uint64)]
+
+
+class COracle(object):
+    """State + optimiser slots as float32 arrays, stepped by the C kernel; mirrors OracleBRIE2's fields."""
+
+    def __init__(self, counts, Xc, effLen=None, seed=0, gene_offset=0, intercept=None, sigma=None, init=None):
+        from .brie_oracle import OracleBRIE2
+        self.lib = ctypes.CDLL(build())
+        self.counts = [np.ascontiguousarray(c, np.float32) for c in counts]
+        self.Nc, self.Ng = self.counts[0].shape
+        self.Xc = np.ascontiguousarray(Xc if Xc is not None else np.zeros((self.Nc, 0)), np.float32)
+        self.Kc = self.Xc.shape[1]
+        self.effLen = None if effLen is None else np.ascontiguousarray(effLen, np.float32)
+        self.seed, self.gene_offset, self.draw, self.t = int(seed), int(gene_offset), 0, 0
+        self.train_b, self.train_lam = intercept is None, sigma is None
+        o = OracleBRIE2(self.Nc, self.Ng, self.Kc, effLen=effLen, intercept=intercept, sigma=sigma, seed=seed,
+                        gene_offset=gene_offset, dtype=np.float32, init=init)
+        f = lambda a: np.ascontiguousarray(a, np.float32)
+        self.Z_loc, self.Z_std_log, self.Wc_loc = f(o.Z_loc), f(o.Z_std_log), f(o.Wc_loc)
+        self.intercept, self.sigma_log = f(o.intercept).reshape(-1), f(o.sigma_log).reshape(-1)
+        self.reset_optimizer()
+
+    def reset_optimizer(self):
+        self.t = 0
+        self.slots = {k: (np.zeros_like(getattr(self, k)), np.zeros_like(getattr(self, k)))
+                      for k in ("Z_loc", "Z_std_log", "Wc_loc", "intercept", "sigma_log")}
+
+    def minimize(self, n_steps, lr, MC_size=1):
+        p = _Problem(self.Nc, self.Ng, self.Kc, len(self.counts), int(self.effLen is not None), int(MC_size),
+                     int(self.train_b), int(self.train_lam), self.gene_offset, self.seed)
+        trace = np.zeros(n_steps, np.float32)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+        c3 = self.counts[2] if len(self.counts) > 2 else None
+        s = self.slots
+        rc = self.lib.brie_oracle_steps(
+            ctypes.byref(p), ctypes.c_int32(n_steps), ctypes.c_float(lr), ctypes.c_int32(self.t),
+            ctypes.c_uint32(self.draw), ptr(self.counts[0]), ptr(self.counts[1]), ptr(c3), ptr(self.Xc), ptr(self.effLen),
+            ptr(self.Z_loc), ptr(self.Z_std_log), ptr(s["Z_loc"][0]), ptr(s["Z_loc"][1]), ptr(s["Z_std_log"][0]),
+            ptr(s["Z_std_log"][1]), ptr(self.Wc_loc), ptr(s["Wc_loc"][0]), ptr(s["Wc_loc"][1]), ptr(self.intercept),
+            ptr(s["intercept"][0]), ptr(s["intercept"][1]), ptr(self.sigma_log), ptr(s["sigma_log"][0]),
+            ptr(s["sigma_log"][1]), ptr(trace))
+        if rc != 0:
+            raise MemoryError("brie_oracle_steps")
+        self.t += n_steps
+        self.draw += n_steps
+        return trace
+
+    def threads(self):
+        return int(self.lib.brie_oracle_threads())

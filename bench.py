@@ -288,7 +288,7 @@ def main():
                 "gpu_over_cpu": value / eps_s,
             }
             # second, separately labelled baseline: the same algorithm as ONE fused
-            # C/OpenMP pass (oracle/brie_oracle.c) on all host cores -- what a tuned CPU kernel reaches
+            # C/OpenMP pass (oracle/brie_oracle.c) on all host cores
             try:
                 from oracle.c_oracle import COracle
                 from oracle.brie_oracle import add_pseudo_count
@@ -304,7 +304,8 @@ def main():
                 fused = n_fused * Nc * sample_layers[0].shape[1] / el
                 out["cpu_baseline_fused"] = {
                     "value": fused, "unit": "cell*gene*iterations/s", "cores": co.threads(), "kind": "port-fused",
-                    "sample": "%d genes x %d cells x %d Adam steps, fused C/OpenMP restatement (oracle/brie_oracle.c), %.1f s"
+                    "sample": "%d genes x %d cells x %d Adam steps, fused single-pass C/OpenMP restatement (oracle/brie_oracle.c; scalar libm, "
+                              "noise stream evaluated in double -- not vectorised), %.1f s"
                               % (sample_layers[0].shape[1], Nc, n_fused, el),
                     "gpu_over_cpu": value / fused}
             except Exception as exc:                      # gcc / OpenMP missing: the eager baseline above stands

@@ -57,6 +57,14 @@ def load_library(path=None):
         raise ImportError(
             "libbrie_amd.so not found at %s -- build it with `python -m brie_amd.build` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback." % path)
+    # One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).
+    # If torch is imported first, the dynamic loader binds libbrie_amd.so to that copy (SONAME match) and all
+    # is well; loaded the other way round the process ends up with TWO runtimes and the one that initialises
+    # second reports "no ROCm-capable device".  So: when torch is installed, load it before the library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(path)
     vp, i32, i64, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
     lib.brie_create.argtypes = [ctypes.POINTER(BrieProblem), ctypes.POINTER(vp)]

@@ -122,3 +122,42 @@ def test_max_size_config5_single_gpu(lib):
     np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:], o.Wc_loc, atol=2e-4)
     assert np.abs(zloc).max() <= 9.0 and np.all(np.isfinite(zloc))
     sh.close()
+
+
+def test_full_size_config3_staged_schedule_psi(lib):
+    """PSI delta at the headline size after a staged mini-schedule (6 learning-rate stages x 25 steps,
+    fresh Adam per stage, model_TFProb.py:234-241): one gene quad over all 50k cells vs the fp64 oracle."""
+    import torch
+    import bench
+    from brie_amd import _capi
+    from oracle.brie_oracle import OracleBRIE2, add_pseudo_count, LEARNING_RATES
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS["c3"]
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 777
+    Xc, layers = _generate(torch, dev, cfg, seed)
+    sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=seed)
+    for l in range(2):
+        sh.upload(_capi.COUNT1 + l, layers[l])
+    sh.add_pseudo_count(0.01)
+    sh.upload(_capi.XC, Xc)
+    sh.init_state()
+    g0 = 11112
+    cnt = add_pseudo_count([layers[l][:, g0:g0 + 4].cpu().numpy() for l in range(2)])
+    del layers
+    torch.cuda.empty_cache()
+    o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float64)
+    Xc_h = Xc.cpu().numpy()
+    for lr in LEARNING_RATES:
+        sh.reset_optimizer()
+        o.reset_optimizer()
+        sh.step(25, lr, 1, trace=False)
+        o.minimize(cnt, Xc_h, 25, lr, 1)
+    d = np.abs(sh.read(_capi.PSI)[:, g0:g0 + 4] - o.Psi)
+    print("C3 PSI delta after 150 staged steps: max %.3g p99 %.3g p99.9 %.3g"
+          % (d.max(), np.percentile(d, 99), np.percentile(d, 99.9)))
+    # bulk bound + outlier bound: Adam's g/(sqrt(v)+eps) turns an fp32 rounding of a near-zero gradient into an
+    # O(lr) move for isolated (cell, gene) entries, exactly as the fp32 CPU oracle does against fp64
+    assert np.percentile(d, 99) < 1e-4 and np.percentile(d, 99.9) < 3e-4 and d.max() < 5e-3
+    np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:g0 + 4], o.Wc_loc, atol=5e-4)
+    sh.close()

@@ -105,6 +105,9 @@ def main():
                          "weak: every rank fits the whole config")
     ap.add_argument("--kc", type=int, default=None, help="override the config's number of cell covariates (experiments)")
     ap.add_argument("--rows-per-chunk", type=int, default=0)
+    ap.add_argument("--emulate-shard-of", type=int, default=0,
+                    help="experiments: with --gpus 1, run only rank 0's gene shard of an N-way split (per-rank step "
+                         "time of the strong-scaling run without N GPUs); the line is labelled and is not a result")
     ap.add_argument("--count-storage", default="auto", choices=["auto", "f32"],
                     help="auto: integer counts <= 255 are kept as u8 in HBM (bit-identical results); f32: as uploaded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +145,11 @@ def main():
         cfg["Kc"] = args.kc
         cfg["desc"] += " [Kc overridden to %d]" % args.kc
     Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
-    if args.scaling == "strong":
+    if args.emulate_shard_of:
+        assert world == 1
+        g0, g1 = gene_shard(Ng, 0, args.emulate_shard_of)
+        cfg["desc"] += " [ONLY shard 0 of %d: per-rank dry run]" % args.emulate_shard_of
+    elif args.scaling == "strong":
         g0, g1 = gene_shard(Ng, rank, world)
     else:
         g0, g1 = 0, Ng
@@ -231,6 +238,8 @@ def main():
     assert np.isfinite(last).all(), last
     psi_dev = sh.read(_capi.PSI) if (rank == 0 and world == 1 and not args.no_psi_check) else None
     total_elems = Nc * (Ng if args.scaling == "strong" else Ng * world)
+    if args.emulate_shard_of:
+        total_elems = Nc * ng
     value = args.steps * total_elems / elapsed
 
     out = None

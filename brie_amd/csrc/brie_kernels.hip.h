@@ -507,11 +507,13 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 const float s2r = s[v] * s[v] * is2;                               // s^2 / sigma^2
                 const float dl = R.rho.v[v] - (cell ? rs.clam : lamj[v]);
                 const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;         // KL(q || prior)
-                if constexpr (CPL) {
+                if constexpr (CPL) {     // padding genes inside the last quad (Ng % 4 != 0) are not part of the cell's sums
+                    const bool real = j0 + v < a.Ng;
+                    const float rq = real ? rr : 0.0f;
 #pragma unroll
-                    for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rr, Xgk[k][v], rstat[k]);
-                    rstat[kKgMax] += rr;
-                    rstat[kKgMax + 1] += 1.0f - d * rr - s2r;
+                    for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rq, Xgk[k][v], rstat[k]);
+                    rstat[kKgMax] += rq;
+                    rstat[kKgMax + 1] += real ? 1.0f - d * rr - s2r : 0.0f;
                 }
                 const float g_mu = rr - gbar[v] * a.inv_mc;
                 const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;

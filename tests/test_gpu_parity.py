@@ -454,3 +454,49 @@ def test_packing_active_quads_is_bit_identical(lib, monkeypatch):
     np.testing.assert_array_equal(a[5], b[5])
     np.testing.assert_array_equal(a[6], b[6])
     np.testing.assert_array_equal(a[7], P["counts_pc"][2])
+
+
+def _random_cases(n, seed=20261001):
+    """Seeded sweep over shapes and model switches (the same list on every run)."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for i in range(n):
+        Nc = int(rng.choice([1, 2, 7, 63, 64, 65, 130, 257, 300, 515]))
+        Ng = int(rng.choice([1, 3, 4, 5, 255, 256, 257, 511, 700, 1025]))
+        L = int(rng.choice([2, 3]))
+        MC = int(rng.choice([1, 2, 3, 5]))
+        kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin"][i % 7]
+        Kc = int(rng.integers(9, 41)) if kind == "wide" else int(rng.integers(0, 9))
+        Kg = int(rng.integers(1, 5)) if kind == "xg" else 0
+        eff = bool(L == 3 or rng.random() < 0.3)
+        cases.append((i, kind, Nc, Ng, Kc, Kg, L, MC, eff))
+    return cases
+
+
+@pytest.mark.parametrize("i,kind,Nc,Ng,Kc,Kg,L,MC,eff", _random_cases(28))
+def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff):
+    """Every product switch of BRIE2.__init__/fit (model_TFProb.py:42-85,214-273) at awkward sizes: partly filled
+    gene blocks, fewer cells than one chunk, single cell / single gene, Kc across the fused/wide boundary."""
+    from brie_amd import _capi
+    P = util.problem(Nc, Ng, Kc, L, seed=1000 + i)
+    if not eff:
+        P["effLen"] = None
+    elif P["effLen"] is None:                       # two layers with effective lengths (model_TFProb.py:168-183)
+        P["effLen"] = np.random.default_rng(i).uniform(50, 400, (Ng, 6)).astype(np.float32)
+    if Kg:
+        P["Xg"] = np.random.default_rng(i + 77).standard_normal((Ng, Kg)).astype(np.float32)
+    mode = "cell" if kind == "cell" else "gene"
+    fixed = dict(intercept=0.25, sigma=1.5) if kind == "fixed" else {}
+    seed = 5000 + i
+    o = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode, **fixed)
+    sh = util.device_shard(P, Nc, Ng, Kc, seed, Kg=Kg, mode=mode, **fixed)
+    target = "marginLik" if kind == "margin" else "ELBO"
+    sh.set_target(target)
+    n = 4
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], n, 0.01, MC, target=target)
+    tr_d = sh.step(n, 0.01, MC)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=5e-5, atol=1e-3)
+    assert_states_close(util.oracle_state(o), util.device_state(sh))
+    d = np.abs(sh.read(_capi.PSI) - o.Psi)
+    assert d.max() < 1e-4
+    sh.close()

@@ -25,7 +25,8 @@ EXPORTS = [
     "brie_step_end", "brie_set_gene_mask", "brie_read_loss_window", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
-    "brie_get_count_storage", "brie_calibrate_stream", "brie_last_error", "brie_abi_version",
+    "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts",
+    "brie_last_error", "brie_abi_version",
 ]
 
 
@@ -91,6 +92,8 @@ def load_library(path=None):
     lib.brie_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.brie_set_tiling.argtypes = [vp, i32]
     lib.brie_calibrate_stream.argtypes = [i32, i32, i32, i64, i32, i32, ctypes.POINTER(ctypes.c_double)]
+    lib.brie_simulate_psi.argtypes = [i32, i64, i64, i64, ctypes.c_uint64, vp, vp, vp]
+    lib.brie_simulate_counts.argtypes = [i32, i64, i64, i64, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.brie_step_algorithmic_bytes.argtypes = [vp]
     lib.brie_step_algorithmic_bytes.restype = i64
     lib.brie_step_storage_bytes.argtypes = [vp]
@@ -153,6 +156,41 @@ def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=
     _check(lib, lib.brie_calibrate_stream(int(device), int(n_read), int(n_write), int(bytes_per_stream),
                                           int(iters), int(lds_bytes), ctypes.byref(out)))
     return out.value
+
+
+def _f32_matrix(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError("brie_amd: expected an array of shape %s, got %s" % (tuple(shape), a.shape))
+    return a
+
+
+def simulate_psi(mean_logit, sigma, seed=0, gene_offset=0, device=0):
+    """brie_simulate_psi: Psi = sigmoid(clip(mean_logit + sigma_j * N(0,1), -9, 9)) for host (Nc, Ng) arrays."""
+    lib = load_library()
+    mean_logit = _f32_matrix(mean_logit)
+    Nc, Ng = mean_logit.shape
+    sigma = _f32_matrix(np.broadcast_to(np.asarray(sigma, np.float32).reshape(-1), (Ng,)))
+    out = np.empty((Nc, Ng), np.float32)
+    _check(lib, lib.brie_simulate_psi(int(device), Nc, Ng, int(gene_offset), int(seed) & (2 ** 64 - 1),
+                                      mean_logit.ctypes.data, sigma.ctypes.data, out.ctypes.data))
+    return out
+
+
+def simulate_counts(psi, total, effLen=None, seed=0, gene_offset=0, device=0):
+    """brie_simulate_counts: Multinomial(total, phi) reads per (cell, gene); returns (c1, c2, c3 or None)."""
+    lib = load_library()
+    psi = _f32_matrix(psi)
+    Nc, Ng = psi.shape
+    total = _f32_matrix(total, (Nc, Ng))
+    eff = None if effLen is None else _f32_matrix(effLen, (Ng, 6))
+    out = [np.empty((Nc, Ng), np.float32) for _ in range(3 if eff is not None else 2)]
+    _check(lib, lib.brie_simulate_counts(int(device), Nc, Ng, int(gene_offset), int(seed) & (2 ** 64 - 1),
+                                         psi.ctypes.data, total.ctypes.data,
+                                         None if eff is None else eff.ctypes.data,
+                                         out[0].ctypes.data, out[1].ctypes.data,
+                                         None if eff is None else out[2].ctypes.data))
+    return out[0], out[1], (out[2] if eff is not None else None)
 
 
 class Shard(object):

@@ -5,6 +5,7 @@
 #define BRIE_HOST_TU 1
 #include "brie_launch.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1264,6 +1265,80 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     cleanup();
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "calibration: %s", hipGetErrorString(e));
     *gbps = static_cast<double>(n_read + n_write) * a.n4 * 16.0 * iters / (ms * 1e-3) / 1e9;
+    return BRIE_OK;
+}
+
+// ---- count simulator: stateless, row-major host or device arrays, processed in row slabs -------------
+namespace {
+struct SlabBuffers {
+    std::vector<void *> bufs;
+    ~SlabBuffers() { for (void *q : bufs) hipFree(q); }
+    float *get(size_t elems) {
+        void *q = nullptr;
+        if (elems == 0 || hipMalloc(&q, elems * sizeof(float)) != hipSuccess) return nullptr;
+        bufs.push_back(q);
+        return static_cast<float *>(q);
+    }
+};
+// elements per row slab staged through HBM (5 fp32 slabs live at once); BRIE_SIM_SLAB_ELEMS overrides (tests)
+int64_t sim_slab_elems() {
+    const char *e = getenv("BRIE_SIM_SLAB_ELEMS");
+    const int64_t v = e ? atoll(e) : 0;
+    return v > 0 ? v : (int64_t(1) << 27);
+}
+}  // namespace
+
+int brie_simulate_psi(int32_t device, int64_t Nc, int64_t Ng, int64_t gene_offset, uint64_t seed,
+                      const float *mean_logit, const float *sigma, float *psi_out) {
+    if (!mean_logit || !sigma || !psi_out) return fail(BRIE_ERR_INVALID, "null argument");
+    if (Nc <= 0 || Ng <= 0 || Nc > INT32_MAX || Ng > INT32_MAX || gene_offset < 0 || gene_offset % 4 != 0)
+        return fail(BRIE_ERR_INVALID, "bad shape / gene_offset (Nc=%lld Ng=%lld gene_offset=%lld)", (long long)Nc,
+                    (long long)Ng, (long long)gene_offset);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(Nc, sim_slab_elems() / Ng));
+    SlabBuffers sb;
+    float *d_mean = sb.get(slab * Ng), *d_out = sb.get(slab * Ng), *d_sig = sb.get(Ng);
+    if (!d_mean || !d_out || !d_sig) return fail(BRIE_ERR_HIP, "hipMalloc simulator slab");
+    HIP_TRY(hipMemcpy(d_sig, sigma, Ng * sizeof(float), hipMemcpyDefault));
+    for (int64_t r0 = 0; r0 < Nc; r0 += slab) {
+        const int64_t rows = std::min(slab, Nc - r0);
+        HIP_TRY(hipMemcpy(d_mean, mean_logit + r0 * Ng, rows * Ng * sizeof(float), hipMemcpyDefault));
+        hipLaunchKernelGGL(brie::sim_psi, dim3(grid_1d(rows * ((Ng + 3) / 4))), dim3(256), 0, nullptr, d_mean, d_sig, d_out,
+                           rows, Ng, r0, gene_offset, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(psi_out + r0 * Ng, d_out, rows * Ng * sizeof(float), hipMemcpyDefault));
+    }
+    return BRIE_OK;
+}
+
+int brie_simulate_counts(int32_t device, int64_t Nc, int64_t Ng, int64_t gene_offset, uint64_t seed, const float *psi,
+                         const float *total, const float *effLen, float *out1, float *out2, float *out3) {
+    if (!psi || !total || !out1 || !out2 || (effLen && !out3)) return fail(BRIE_ERR_INVALID, "null argument");
+    if (Nc <= 0 || Ng <= 0 || Nc > INT32_MAX || Ng > INT32_MAX || gene_offset < 0)
+        return fail(BRIE_ERR_INVALID, "bad shape / gene_offset (Nc=%lld Ng=%lld gene_offset=%lld)", (long long)Nc,
+                    (long long)Ng, (long long)gene_offset);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    const int64_t slab = std::max<int64_t>(1, std::min<int64_t>(Nc, sim_slab_elems() / Ng));
+    SlabBuffers sb;
+    float *d_psi = sb.get(slab * Ng), *d_tot = sb.get(slab * Ng), *d_o1 = sb.get(slab * Ng), *d_o2 = sb.get(slab * Ng);
+    float *d_o3 = effLen ? sb.get(slab * Ng) : nullptr, *d_eff = effLen ? sb.get(Ng * 6) : nullptr;
+    if (!d_psi || !d_tot || !d_o1 || !d_o2 || (effLen && (!d_o3 || !d_eff)))
+        return fail(BRIE_ERR_HIP, "hipMalloc simulator slab");
+    if (effLen) HIP_TRY(hipMemcpy(d_eff, effLen, Ng * 6 * sizeof(float), hipMemcpyDefault));
+    for (int64_t r0 = 0; r0 < Nc; r0 += slab) {
+        const int64_t rows = std::min(slab, Nc - r0);
+        const size_t bytes = static_cast<size_t>(rows) * Ng * sizeof(float);
+        HIP_TRY(hipMemcpy(d_psi, psi + r0 * Ng, bytes, hipMemcpyDefault));
+        HIP_TRY(hipMemcpy(d_tot, total + r0 * Ng, bytes, hipMemcpyDefault));
+        hipLaunchKernelGGL(brie::sim_counts, dim3(grid_1d(rows * Ng)), dim3(256), 0, nullptr, d_psi, d_tot, d_eff, d_o1, d_o2,
+                           d_o3, rows, Ng, r0, gene_offset, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpy(out1 + r0 * Ng, d_o1, bytes, hipMemcpyDefault));
+        HIP_TRY(hipMemcpy(out2 + r0 * Ng, d_o2, bytes, hipMemcpyDefault));
+        if (effLen) HIP_TRY(hipMemcpy(out3 + r0 * Ng, d_o3, bytes, hipMemcpyDefault));
+    }
     return BRIE_OK;
 }
 

@@ -1375,6 +1375,146 @@ __global__ void exp_vec(const float *src, float *dst, int n) {
     if (j < n) dst[j] = expf(src[j]);
 }
 
+// ----------------------------------------------------------------------------
+// Count simulator (brie/models/simulator.py:7-75): Psi from the fitted prior
+// (:22-41) and Multinomial(total, phi) reads with phi ~ [Psi, 1-Psi, 1] * effLen[:, [0,4,5]]
+// (:45-69).  The reference draws with TF's unseeded samplers; here every draw comes from the
+// shared Philox stream, addressed by (global gene, cell), so a simulation is reproducible
+// and independent of sharding.  The multinomial is two conditional binomials; a binomial
+// is sampled exactly, in fp64: sequential inversion when n*min(p,1-p) < 10, Hoermann's
+// transformed rejection with squeeze (BTRS, 1993) otherwise.  oracle/sim_oracle.c restates
+// the same arithmetic on the CPU; the tests demand bit-identical counts.
+// ----------------------------------------------------------------------------
+constexpr uint32_t kSimPsiDraw = 0xFFFFFFFEu;      // draw ids reserved next to kInitDraw
+constexpr uint32_t kSimBinomDraw1 = 0xFFFFFFFDu;
+constexpr uint32_t kSimBinomDraw2 = 0xFFFFFFFCu;
+
+struct SimRng {
+    uint32_t gene, cell, draw, k, s0, s1;
+    uint32_t w[4];
+    int left;
+    __device__ SimRng(uint32_t g, uint32_t c, uint32_t d, uint32_t lo, uint32_t hi)
+        : gene(g), cell(c), draw(d), k(0), s0(lo), s1(hi), left(0) {}
+    // 53-bit uniform in (0,1) from two Philox words
+    __device__ double next() {
+        if (left == 0) {
+            philox4x32_10(gene, cell, draw, k++, s0, s1, w);
+            left = 2;
+        }
+        const uint32_t hi = left == 2 ? w[0] : w[2], lo = left == 2 ? w[1] : w[3];
+        --left;
+        return (static_cast<double>(hi >> 5) * 67108864.0 + static_cast<double>(lo >> 6) + 0.5) * 0x1p-53;
+    }
+};
+
+__device__ inline double stirling_tail(double k) {
+    // log(k!) - [log(sqrt(2 pi)) + (k + 1/2) log(k + 1) - (k + 1)]
+    const double tab[10] = {0.08106146679532726, 0.04134069595540929, 0.02767792568499834, 0.02079067210376509,
+                            0.01664469118982119, 0.01387612882307075, 0.01189670994589177, 0.01041126526197209,
+                            0.009255462182712733, 0.008330563433362871};
+    if (k <= 9.0) return tab[static_cast<int>(k)];
+    const double kp1 = k + 1.0, kp1sq = kp1 * kp1;
+    return (1.0 / 12.0 - (1.0 / 360.0 - 1.0 / 1260.0 / kp1sq) / kp1sq) / kp1;
+}
+
+__device__ inline double sim_binomial(double n, double p, SimRng &g) {
+#pragma clang fp contract(off)
+    if (n <= 0.0 || p <= 0.0) return 0.0;
+    if (p >= 1.0) return n;
+    const bool flip = p > 0.5;
+    if (flip) p = 1.0 - p;
+    const double q = 1.0 - p;
+    double x;
+    if (n * p < 10.0) {                                   // inversion: walk the pmf from 0
+        const double qn = exp(n * log(q));
+        const double bound = fmin(n, n * p + 10.0 * sqrt(n * p * q + 1.0));
+        double px = qn, u = g.next();
+        x = 0.0;
+        while (u > px) {
+            x += 1.0;
+            if (x > bound) { x = 0.0; px = qn; u = g.next(); }
+            else { u -= px; px = ((n - x + 1.0) * p * px) / (x * q); }
+        }
+    } else {                                              // BTRS
+        const double spq = sqrt(n * p * q);
+        const double b = 1.15 + 2.53 * spq;
+        const double a = -0.0873 + 0.0248 * b + 0.01 * p;
+        const double c = n * p + 0.5;
+        const double vr = 0.92 - 4.2 / b;
+        const double alpha = (2.83 + 5.1 / b) * spq;
+        const double m = floor((n + 1.0) * p);
+        const double r = p / q;
+        for (;;) {
+            const double u = g.next() - 0.5;
+            double v = g.next();
+            const double us = 0.5 - fabs(u);
+            const double k = floor((2.0 * a / us + b) * u + c);
+            if (us >= 0.07 && v <= vr) { x = k; break; }
+            if (k < 0.0 || k > n) continue;
+            v = log(v * alpha / (a / (us * us) + b));
+            const double ub = (m + 0.5) * log((m + 1.0) / (r * (n - m + 1.0))) +
+                              (n + 1.0) * log((n - m + 1.0) / (n - k + 1.0)) +
+                              (k + 0.5) * log(r * (n - k + 1.0) / (k + 1.0)) +
+                              stirling_tail(m) + stirling_tail(n - m) - stirling_tail(k) - stirling_tail(n - k);
+            if (v <= ub) { x = k; break; }
+        }
+    }
+    return flip ? n - x : x;
+}
+
+// psi, total: (rows, Ng) row-major; effL: (Ng, 6) or null (two categories: c1 ~ Binomial(total, psi), c2 = rest)
+__global__ void sim_counts(const float *__restrict__ psi, const float *__restrict__ total,
+                           const float *__restrict__ effL, float *__restrict__ o1, float *__restrict__ o2,
+                           float *__restrict__ o3, int64_t rows, int64_t Ng, int64_t row0, int64_t gene_offset,
+                           uint32_t s0, uint32_t s1) {
+#pragma clang fp contract(off)
+    const int64_t n_el = rows * Ng;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n_el;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = i / Ng, j = i - r * Ng;
+        const uint32_t gene = static_cast<uint32_t>(gene_offset + j), cell = static_cast<uint32_t>(row0 + r);
+        const double n = floor(static_cast<double>(total[i]));
+        const double ps = static_cast<double>(psi[i]);
+        double p1 = ps, pc = 1.0;
+        if (effL) {
+            const double w1 = ps * static_cast<double>(effL[j * 6 + 0]);
+            const double w2 = (1.0 - ps) * static_cast<double>(effL[j * 6 + 4]);
+            const double w3 = static_cast<double>(effL[j * 6 + 5]);
+            p1 = w1 / (w1 + w2 + w3);
+            pc = (w2 + w3) > 0.0 ? w2 / (w2 + w3) : 0.0;
+        }
+        SimRng g1(gene, cell, kSimBinomDraw1, s0, s1);
+        const double c1 = sim_binomial(n, p1, g1);
+        double c2 = n - c1;
+        if (effL) {
+            SimRng g2(gene, cell, kSimBinomDraw2, s0, s1);
+            c2 = sim_binomial(n - c1, pc, g2);
+            o3[i] = static_cast<float>(n - c1 - c2);
+        }
+        o1[i] = static_cast<float>(c1);
+        o2[i] = static_cast<float>(c2);
+    }
+}
+
+// Psi = sigmoid(clip(mean + sigma_j * eps, -9, 9))  (simulator.py:31-41); sigma: (Ng); one thread per gene quad
+__global__ void sim_psi(const float *__restrict__ mean, const float *__restrict__ sigma, float *__restrict__ out,
+                        int64_t rows, int64_t Ng, int64_t row0, int64_t gene_offset, uint32_t s0, uint32_t s1) {
+    const int64_t nq = (Ng + 3) / 4, n_el = rows * nq;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n_el;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t r = i / nq, q = i - r * nq;
+        float e[4];
+        normal4(static_cast<uint32_t>(gene_offset / 4 + q), static_cast<uint32_t>(row0 + r), kSimPsiDraw, 0u, s0, s1, e);
+        for (int v = 0; v < 4; ++v) {
+            const int64_t j = q * 4 + v;
+            if (j >= Ng) break;
+            float z = fmaf(sigma[j], e[v], mean[r * Ng + j]);
+            z = fminf(fmaxf(z, -9.0f), 9.0f);
+            out[r * Ng + j] = sigmoid_acc(z);
+        }
+    }
+}
+
 #endif  // BRIE_HOST_TU
 
 // ----------------------------------------------------------------------------

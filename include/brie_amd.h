@@ -202,6 +202,20 @@ int brie_get_count_storage(const brie_handle *h);
 int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream,
                           int32_t iters, int32_t lds_bytes_per_block, double *gbps);
 
+/* Count simulator -- brie/models/simulator.py:7-75.  Stateless; every array is C-order (Nc, Ng) fp32 in host or
+ * device memory (copied through HBM in row slabs), genes are addressed globally (gene_offset) so a gene shard
+ * simulates exactly its columns of the whole matrix.  All draws come from the library's Philox stream keyed by
+ * `seed` (the reference uses TensorFlow's unseeded samplers), see DESIGN.md section 7.3.
+ *  brie_simulate_psi   : psi = sigmoid(clip(mean_logit + sigma_j * N(0,1), -9, 9))           (simulator.py:31-41)
+ *  brie_simulate_counts: (c1,c2,c3) ~ Multinomial(floor(total), phi), phi ~ [psi, 1-psi, 1] * effLen[:, [0,4,5]]
+ *                        (simulator.py:45-69); effLen == NULL: two categories, c1 ~ Binomial(total, psi), c2 the rest,
+ *                        out3 unused.  Exact sampling (inversion / BTRS) in fp64. */
+int brie_simulate_psi(int32_t device, int64_t Nc, int64_t Ng, int64_t gene_offset, uint64_t seed,
+                      const float *mean_logit, const float *sigma /* (Ng) */, float *psi_out);
+int brie_simulate_counts(int32_t device, int64_t Nc, int64_t Ng, int64_t gene_offset, uint64_t seed,
+                         const float *psi, const float *total, const float *effLen /* (Ng, 6) or NULL */,
+                         float *out1, float *out2, float *out3);
+
 const char *brie_last_error(void);
 int brie_abi_version(void);
 

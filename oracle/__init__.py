@@ -47,6 +47,8 @@ brie_oracle_torch.py  eager torch-CPU autograd restatement in the reference's
                       execution shape; also the `cpu_baseline` ("port") of bench.py
 brie_oracle.c         fused C / OpenMP restatement of the step (second implementation; "cpu_baseline_fused")
 c_oracle.py           gcc build + ctypes driver of brie_oracle.c
+sim_oracle.c / .py    count simulator (brie/models/simulator.py): exact binomial / multinomial sampling from the
+                      Philox stream; distribution pinned against scipy (tests/test_oracle_sim.py)
 host_stats.py         chi2 / Benjamini-Hochberg restatement for the LRT driver
 synth.py              seeded synthetic count generator (SURVEY.md 8d recipe)
 """

@@ -473,7 +473,7 @@ def _random_cases(n, seed=20261001):
     return cases
 
 
-@pytest.mark.parametrize("i,kind,Nc,Ng,Kc,Kg,L,MC,eff", _random_cases(28))
+@pytest.mark.parametrize("i,kind,Nc,Ng,Kc,Kg,L,MC,eff", _random_cases(56))
 def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff):
     """Every product switch of BRIE2.__init__/fit (model_TFProb.py:42-85,214-273) at awkward sizes: partly filled
     gene blocks, fewer cells than one chunk, single cell / single gene, Kc across the fused/wide boundary."""
@@ -499,4 +499,38 @@ def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff
     assert_states_close(util.oracle_state(o), util.device_state(sh))
     d = np.abs(sh.read(_capi.PSI) - o.Psi)
     assert d.max() < 1e-4
+    np.testing.assert_allclose(sh.read(_capi.PSI95CI), o.Psi95CI, atol=2e-4)
+    np.testing.assert_allclose(sh.read(_capi.Z_STD), o.Z_std, rtol=1e-3, atol=1e-6)
+    if kind not in ("wide",):                       # 3-draw per-gene loss on the updated state
+        lg_o = o.eval_loss_gene(P["counts_pc"], P["Xc"], 3, target=target)
+        np.testing.assert_allclose(sh.loss_gene(3), lg_o, rtol=2e-4, atol=2e-3)
     sh.close()
+
+
+@pytest.mark.parametrize("Nc,Ng,Kc,L,MC,cuts", [
+    (300, 1000, 3, 2, 1, (256, 512)),          # cuts on gene-block boundaries
+    (515, 700, 2, 3, 3, (4, 260, 696)),        # cuts inside blocks, a 4-gene shard at each end
+    (130, 1030, 12, 2, 2, (516,)),             # wide design (LDS tile + MFMA reduction)
+    (64, 37, 0, 2, 1, (8, 36)),                # last shard = the ragged tail (1 gene)
+])
+def test_gene_shards_bit_identical_to_whole_fit(lib, Nc, Ng, Kc, L, MC, cuts):
+    """genes are independent, so any contiguous split (boundaries multiples of 4 = one Philox quad)
+    must reproduce the whole fit bit for bit -- state, per-gene loss and the summed loss trace (fp64 sum)."""
+    P = util.problem(Nc, Ng, Kc, L, seed=77)
+    whole = util.device_shard(P, Nc, Ng, Kc, 8)
+    whole.step(6, 0.01, MC)
+    lg = whole.loss_gene(4)
+    a = util.device_state(whole)
+    edges = (0,) + tuple(cuts) + (Ng,)
+    for g0, g1 in zip(edges[:-1], edges[1:]):
+        Ps = dict(P, counts=[c[:, g0:g1].copy() for c in P["counts"]],
+                  effLen=None if P["effLen"] is None else P["effLen"][g0:g1].copy())
+        part = util.device_shard(Ps, Nc, g1 - g0, Kc, 8, gene_offset=g0)
+        part.step(6, 0.01, MC)
+        b = util.device_state(part)
+        for k in util.STATE_KEYS:
+            if a[k].size:
+                np.testing.assert_array_equal(a[k][:, g0:g1], b[k], err_msg="%s genes %d:%d" % (k, g0, g1))
+        np.testing.assert_array_equal(lg[g0:g1], part.loss_gene(4))
+        part.close()
+    whole.close()

@@ -179,16 +179,20 @@ class BRIE2(object):
     def get_loss(self, count_layers, target="ELBO", axis=None, **kwargs):
         """One stochastic evaluation of the ELBO loss (no parameter update).
 
-        axis=None -> scalar, axis=0 -> per gene.  Advances the noise stream by one draw.
+        axis=None -> scalar, axis=0 -> per gene.  Advances the noise stream by MC_size draws.
         """
         if target not in ("ELBO", "marginLik"):
             raise ValueError("target=%r" % (target,))
         sh = self._ensure_shard(count_layers, self.Xc, self.Xg)
         sh.set_target(target)
         mc = int(kwargs.get("MC_size", 1))
-        if mc != 1:
-            raise NotImplementedError("get_loss outside fit supports MC_size=1")
-        lg = sh.loss_gene(1)
+        if mc < 1:
+            raise ValueError("MC_size=%r" % (mc,))
+        if mc != 1 and target == "marginLik":
+            raise NotImplementedError("get_loss(target='marginLik') outside fit supports MC_size=1")
+        # ELBO: KL - mean_k ll(z_k) is linear in the samples, i.e. the mean of MC_size single-sample evaluations
+        # (one read of the data, MC_size draws in registers; the noise stream advances by MC_size draws)
+        lg = sh.loss_gene(mc)
         if axis is None:
             return _wrap(np.float32(lg.astype(np.float64).sum()))
         if axis == 0:

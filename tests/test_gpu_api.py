@@ -29,6 +29,15 @@ def test_BRIE2_fit_matches_oracle_fit(lib):
     np.testing.assert_allclose(m.intercept.numpy(), o.intercept, atol=2e-3)
     assert m.Z_std.shape == (Nc, Ng) and m.Psi95CI.shape == (Nc, Ng) and m.sigma.shape == (1, Ng)
     assert isinstance(m.Psi95CI, np.ndarray) and m.n_iter == 240
+    # get_loss (model_TFProb.py:194-211) on the fitted state: per gene and scalar, MC_size samples; both sides continue
+    # the same noise stream, so the stochastic values agree too
+    cnt = add_pseudo_count(P["counts"])
+    lg = m.get_loss(P["counts"], axis=0, MC_size=4)
+    np.testing.assert_allclose(lg.numpy(), o.eval_loss_gene(cnt, P["Xc"], 4), rtol=2e-3, atol=2e-2)
+    tot = m.get_loss(P["counts"], MC_size=2)
+    np.testing.assert_allclose(float(tot.numpy()), o.eval_loss_gene(cnt, P["Xc"], 2).sum(), rtol=1e-3)
+    with pytest.raises(ValueError):
+        m.get_loss(P["counts"], target="nonsense")
     m.close()
 
 

@@ -17,7 +17,7 @@ Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
 ABI_VERSION = 1
 MAX_KC = 64          # 0..8 in registers, 9..64 with the W tile in LDS + an MFMA kernel for Xc^T.r
-MAX_KG = 4
+MAX_KG = 64
 
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
@@ -259,10 +259,16 @@ class Shard(object):
         _check(self.lib, self.lib.brie_step(self._h, int(n_steps), float(lr), int(mc_size), None))
         return None
 
+    def rowstat_size(self):
+        """Number of floats of the per-cell statistics buffer of a coupled fit (brie_rowstat_buffer)."""
+        dev, n = ctypes.c_void_p(), ctypes.c_int64()
+        _check(self.lib, self.lib.brie_rowstat_buffer(self._h, ctypes.byref(dev), ctypes.byref(n)))
+        return int(n.value)
+
     def step_sharded(self, n_steps, lr, mc_size, allreduce_inplace, stat_tensor):
         """Coupled gene-sharded steps: begin -> all-reduce of the per-cell statistics -> end.
 
-        `stat_tensor`: a float32 device tensor of kRowStats*Nc elements registered as the statistics
+        `stat_tensor`: a float32 device tensor of rowstat_size() elements registered as the statistics
         buffer; `allreduce_inplace(t)` sums it over ranks (RCCL).  Returns the LOCAL loss trace."""
         _check(self.lib, self.lib.brie_set_rowstat_buffer(self._h, ctypes.c_void_p(stat_tensor.data_ptr())))
         out = np.empty(int(n_steps), np.float32)

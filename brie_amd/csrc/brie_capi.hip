@@ -64,12 +64,14 @@ struct brie_handle {
     float *effL = nullptr;          // (6, ld)
     // coupled modes: gene features (Kg > 0) and/or per-cell intercept / sigma (intercept_mode 'cell')
     bool coupled = false, cell_mode = false;
-    float *Xg = nullptr;            // (kKgMax, ld) transposed gene features
-    float *Wg = nullptr, *m_Wg = nullptr, *v_Wg = nullptr;           // (Nc, kKgMax)
+    int kgp = brie::kKgMax;         // pitch of a Wg_loc row / rows of Xg: 4 for Kg <= 4, else Kg rounded up to 4
+    bool gwide = false;             // Kg > 4: Xg tile in LDS (GW kernel variant)
+    float *Xg = nullptr;            // (kgp, ld) transposed gene features
+    float *Wg = nullptr, *m_Wg = nullptr, *v_Wg = nullptr;           // (Nc, kgp)
     float *cb = nullptr, *m_cb = nullptr, *v_cb = nullptr;           // (Nc)
     float *clam = nullptr, *m_clam = nullptr, *v_clam = nullptr;     // (Nc)
-    float *row_partials = nullptr;  // (gene_blocks, kRowStats, Nc)
-    float *rowstat = nullptr;       // (kRowStats, Nc)
+    float *row_partials = nullptr;  // (gene_blocks, (kgp + 2) * Nc), see brie::CoupledArgs
+    float *rowstat = nullptr;       // ((kgp + 2) * Nc)
     bool have_xg = false;
     float *rowstat_ext = nullptr;   // caller-owned (6, Nc) buffer used instead of rowstat (multi-GPU all-reduce)
     int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
@@ -362,7 +364,7 @@ int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t
             *dev = h->lam; *rows = 1; *cols = Ng; *ldd = h->ld; return BRIE_OK;
         case BRIE_WG_LOC:
             if (h->p.Kg == 0) { *dev = nullptr; *rows = Nc; *cols = 0; *ldd = 1; return BRIE_OK; }
-            *dev = h->Wg; *rows = Nc; *cols = h->p.Kg; *ldd = brie::kKgMax; return BRIE_OK;
+            *dev = h->Wg; *rows = Nc; *cols = h->p.Kg; *ldd = h->kgp; return BRIE_OK;
         default: return fail(BRIE_ERR_INVALID, "array id %d is not a stored matrix", which);
     }
 }
@@ -415,11 +417,12 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
     if (p->Kc < 0 || p->Kc > BRIE_MAX_KC_WIDE)
         return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_WIDE);
+    if (p->Kg > BRIE_MAX_KG_WIDE)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG_WIDE);
     if (p->Kc > BRIE_MAX_KC && (p->Kg > 0 || p->intercept_mode == 1))
         return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d > %d (wide design) together with gene features / cell intercepts "
                     "is not built", p->Kc, BRIE_MAX_KC);
-    if (p->Kg < 0 || p->Kg > BRIE_MAX_KG)
-        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG);
+    if (p->Kg < 0) return fail(BRIE_ERR_INVALID, "Kg=%d", p->Kg);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
         return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
     if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0 && p->reserved == 0)
@@ -481,11 +484,14 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     h->coupled = p->Kg > 0 || h->cell_mode;
     if (h->coupled) {
         const size_t nc = static_cast<size_t>(p->Nc);
-        A(h->Xg, vec * brie::kKgMax);
-        A(h->Wg, nc * brie::kKgMax); A(h->m_Wg, nc * brie::kKgMax); A(h->v_Wg, nc * brie::kKgMax);
+        h->gwide = p->Kg > brie::kKgMax;
+        h->kgp = h->gwide ? static_cast<int>(round_up(p->Kg, 4)) : brie::kKgMax;
+        if (h->gwide && !h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "Kg > 4 needs the tiled layout"); }
+        A(h->Xg, vec * h->kgp);
+        A(h->Wg, nc * h->kgp); A(h->m_Wg, nc * h->kgp); A(h->v_Wg, nc * h->kgp);
         A(h->cb, nc); A(h->m_cb, nc); A(h->v_cb, nc);
         A(h->clam, nc); A(h->m_clam, nc); A(h->v_clam, nc);
-        A(h->rowstat, nc * brie::kRowStats);
+        A(h->rowstat, nc * (h->kgp + 2));
     }
 #undef A
     configure_tiling(h);
@@ -502,7 +508,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     }
     if (h->coupled) {
         float *rp = nullptr;
-        if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * brie::kRowStats * p->Nc, h->stream)) != BRIE_OK) {
+        if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * (h->kgp + 2) * p->Nc, h->stream)) != BRIE_OK) {
             brie_destroy(h);
             return rc;
         }
@@ -573,7 +579,7 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
             return fail(BRIE_ERR_INVALID, "Xg must be (Ng=%lld, Kg=%d), got (%lld, %lld)", (long long)h->p.Ng, h->p.Kg,
                         (long long)rows, (long long)cols);
         if (h->p.Kg == 0) return BRIE_OK;
-        std::vector<float> tmp(static_cast<size_t>(rows) * cols), packed(static_cast<size_t>(brie::kKgMax) * h->ld, 0.0f);
+        std::vector<float> tmp(static_cast<size_t>(rows) * cols), packed(static_cast<size_t>(h->kgp) * h->ld, 0.0f);
         HIP_TRY(hipMemcpy2D(tmp.data(), cols * sizeof(float), src, ld * sizeof(float), cols * sizeof(float), rows,
                             hipMemcpyDefault));
         for (int64_t j = 0; j < rows; ++j)
@@ -699,8 +705,8 @@ int brie_reset_optimizer(brie_handle *h) {
     HIP_TRY(hipMemsetAsync(h->v_lam, 0, vec, h->stream));
     if (h->coupled) {
         const size_t nc = static_cast<size_t>(h->p.Nc) * sizeof(float);
-        HIP_TRY(hipMemsetAsync(h->m_Wg, 0, nc * brie::kKgMax, h->stream));
-        HIP_TRY(hipMemsetAsync(h->v_Wg, 0, nc * brie::kKgMax, h->stream));
+        HIP_TRY(hipMemsetAsync(h->m_Wg, 0, nc * h->kgp, h->stream));
+        HIP_TRY(hipMemsetAsync(h->v_Wg, 0, nc * h->kgp, h->stream));
         HIP_TRY(hipMemsetAsync(h->m_cb, 0, nc, h->stream));
         HIP_TRY(hipMemsetAsync(h->v_cb, 0, nc, h->stream));
         HIP_TRY(hipMemsetAsync(h->m_clam, 0, nc, h->stream));
@@ -735,7 +741,7 @@ int brie_init_state(brie_handle *h, float intercept, float sigma) {
     if (h->coupled) {       // per-cell parameters (shapes of model_TFProb.py:53-55)
         const bool rnd_cb = h->cell_mode && std::isnan(intercept);
         hipLaunchKernelGGL(brie::init_cell_params, dim3((Nc + 255) / 256), dim3(256), 0, h->stream, h->Wg, h->cb, Nc,
-                           h->p.Kg, rnd_cb ? 1 : 0, slo, shi);
+                           h->p.Kg, h->kgp, rnd_cb ? 1 : 0, slo, shi);
         if (h->cell_mode && !rnd_cb)
             hipLaunchKernelGGL(brie::fill_f32, dim3(grid_1d(Nc)), dim3(256), 0, h->stream, h->cb, static_cast<int64_t>(Nc),
                                intercept);
@@ -873,6 +879,24 @@ int wide_backward(brie_handle *h, float alpha) {
 }
 
 // Mbuf = Xc . Wc_loc for the forward-only loss_gene pass of a wide design
+int cell_finalize_blocks(const brie_handle *h) {
+    return static_cast<int>((static_cast<int64_t>(h->kgp + 2) * h->p.Nc + brie::kBlock - 1) / brie::kBlock);
+}
+
+// Kg > 4, forward only (loss_gene_eval reads it): Mbuf = Wg_loc . Xg^T -- the same (rows x K).(K x genes) product as
+// the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
+int gwide_forward_mean(brie_handle *h) {
+    if (!h->Mbuf) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
+    }
+    hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Wg,
+                       h->Xg, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->kgp, h->ld, h->row_stride,
+                       h->gb_stride, h->rows_per_chunk);
+    HIP_TRY(hipGetLastError());
+    return BRIE_OK;
+}
+
 int wide_forward_mean(brie_handle *h) {
     if (!h->Mbuf) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
@@ -939,13 +963,17 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     cfg.rbuf = h->Rbuf;
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
-    cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0;
+    cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0; cp.kgp = h->kgp;
+    // Xg tile (kgp x 256 fp32), re-used by the cross-wave fold of the (Kc + 4) per-gene statistics
+    cfg.gw_lds_bytes = h->gwide ? std::max(h->kgp, (brie::kWavesPerBlock - 1) * h->S) * brie::kGenesPerBlock *
+                                      static_cast<int>(sizeof(float)) : 0;
     brie::CellFinalizeArgs cf{};
     cf.row_partials = h->row_partials; cf.rowstat = h->rowstat; cf.Wg = h->Wg; cf.m_Wg = h->m_Wg; cf.v_Wg = h->v_Wg;
     cf.cb = h->cb; cf.m_cb = h->m_cb; cf.v_cb = h->v_cb; cf.clam = h->clam; cf.m_clam = h->m_clam; cf.v_clam = h->v_clam;
     cf.Nc = static_cast<int32_t>(h->p.Nc); cf.gene_blocks = h->gene_blocks; cf.Kg = h->p.Kg;
     cf.cell_mode = cp.cell_mode; cf.train_b = h->p.train_intercept; cf.train_lam = h->p.train_sigma;
     cf.phase = split ? 1 : 0;
+    cf.kgp = h->kgp;
     if (h->rowstat_ext) cf.rowstat = h->rowstat_ext;
 
     brie::FinalizeArgs f{};
@@ -974,8 +1002,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
         if (h->wide && (rc = wide_backward(h, alpha)) != BRIE_OK) return rc;     // G = Xc^T . r (MFMA), Adam on Wc_loc
         if (h->coupled)
-            hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
-                               dim3(brie::kBlock), 0, h->stream, cf);
+            hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, cf);
     }
     HIP_TRY(hipGetLastError());
     if (split) {
@@ -1013,7 +1040,7 @@ int brie_rowstat_buffer(brie_handle *h, float **dev, int64_t *n_floats) {
     if (!h || !dev || !n_floats) return fail(BRIE_ERR_INVALID, "null argument");
     if (!h->coupled) return fail(BRIE_ERR_STATE, "no per-cell statistics: Kg == 0 and intercept_mode 'gene'");
     *dev = h->rowstat_ext ? h->rowstat_ext : h->rowstat;
-    *n_floats = static_cast<int64_t>(brie::kRowStats) * h->p.Nc;
+    *n_floats = static_cast<int64_t>(h->kgp + 2) * h->p.Nc;
     return BRIE_OK;
 }
 
@@ -1034,8 +1061,7 @@ int brie_step_end(brie_handle *h, float *loss) {
     if (h->coupled) {
         brie::CellFinalizeArgs cf = h->pending_cf;
         cf.phase = 2;
-        hipLaunchKernelGGL(brie::cell_finalize, dim3((cf.Nc + brie::kBlock - 1) / brie::kBlock, brie::kRowStats),
-                           dim3(brie::kBlock), 0, h->stream, cf);
+        hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, cf);
         HIP_TRY(hipGetLastError());
     }
     if (loss) {
@@ -1072,8 +1098,12 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
         if ((rc = wide_forward_mean(h)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
+    if (h->gwide) {
+        if ((rc = gwide_forward_mean(h)) != BRIE_OK) return rc;
+        a.mbuf = h->Mbuf;
+    }
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;
-    a.cp.Kg = h->p.Kg; a.cp.cell_mode = h->cell_mode ? 1 : 0;
+    a.cp.Kg = h->p.Kg; a.cp.cell_mode = h->cell_mode ? 1 : 0; a.cp.kgp = h->kgp;
     a.mu = h->mu; a.rho = h->rho; a.Xc = h->Xc; a.W = h->W; a.b = h->b;
     a.lam = h->lam; a.effL = h->effL; a.partials = h->partials; a.ld = h->ld;
     a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;

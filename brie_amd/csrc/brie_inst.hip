@@ -19,9 +19,21 @@ void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a
                        q.partials, a, cp);
 }
 
+// Kg > 4: coupled variant with the gene block's Xg tile in dynamic LDS (up to 64 KiB on top of the static arrays)
+template <int MODE, int CS>
+void step_launch_gw(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    auto kern = elbo_adam_step<BRIE_KC, MODE, 0, CS, true, false, true>;
+    // per device and cheap; the coupled variants are not launch-bound
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
+    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), c.gw_lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
+                       q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr);
+}
+
 template <int MODE, int CS>
 void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     // coupled modes (gene features / per-cell intercept): one variant with run-time MC_size
+    if (c.coupled && c.gw_lds_bytes > 0) { step_launch_gw<MODE, CS>(c, q, a, cp); return; }
     if (c.coupled) { step_launch<MODE, 0, CS, true>(c, q, a, cp); return; }
     // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
     if (a.mc == 1) step_launch<MODE, 1, CS, false>(c, q, a, cp);

@@ -230,14 +230,17 @@ struct StepScalars {
 // parameters need sums over genes: each wave reduces its 256 genes and writes one value per
 // (gene block, statistic, cell); cell_finalize sums the gene blocks and applies Adam.
 constexpr int kWideKcMax = 64;              // cell features of the wide-design path (W tile of a gene block in LDS)
-constexpr int kKgMax = 4;                   // gene features supported
-constexpr int kRowStats = kKgMax + 2;       // sum_j r*Xg_k (k<4), sum_j r, sum_j (1 - d r - s^2/sigma^2)
+constexpr int kKgMax = 4;                   // gene features kept in registers (CPL variant)
+constexpr int kKgWideMax = 64;              // gene features of the GW variant (Xg tile of a gene block in LDS)
+// Per-cell statistics of one gene block, "row chunk" of (kgp + 2) * Nc floats, kgp = pitch of a Wg_loc row
+// (4 for Kg <= 4, else Kg rounded up to 4):  [Nc][kgp] sum_j r*Xg_k | [Nc] sum_j r | [Nc] sum_j (1 - d r - s^2/sigma^2)
+// -- the same layout as (Wg_loc gradient, cell intercept gradient, cell sigma_log gradient).
 struct CoupledArgs {
-    const float *Xg;        // (kKgMax, ld) gene features, transposed, zero rows beyond Kg
-    const float *Wg;        // (Nc, kKgMax) per-cell weights, zero columns beyond Kg
+    const float *Xg;        // (kgp, ld) gene features, transposed, zero rows beyond Kg
+    const float *Wg;        // (Nc, kgp) per-cell weights, zero columns beyond Kg
     const float *cb, *clam; // (Nc) per-cell intercept / log sigma (cell mode)
-    float *row_partials;    // (gene_blocks, kRowStats, Nc)
-    int32_t Kg, cell_mode;
+    float *row_partials;    // (gene_blocks, (kgp + 2) * Nc)
+    int32_t Kg, cell_mode, kgp;
 };
 struct RowScalars { float wg[kKgMax], cb, clam; };
 
@@ -245,6 +248,23 @@ __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off);
     return x;
+}
+
+// Sums 8 per-lane values over the wave with 10 shuffles (instead of 8 x 6): three exchange stages halve the
+// number of values a lane carries while summing lane pairs 32/16/8 apart, three plain butterfly stages finish.
+// Returns, in every lane, the wave total of t[lane >> 3].
+__device__ __forceinline__ float wave_sum8(const float (&t)[8], int lane) {
+    const bool h32 = (lane & 32) != 0, h16 = (lane & 16) != 0, h8 = (lane & 8) != 0;
+    float a[4], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = (h32 ? t[i + 4] : t[i]) + __shfl_xor(h32 ? t[i] : t[i + 4], 32);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) b[i] = (h16 ? a[i + 2] : a[i]) + __shfl_xor(h16 ? a[i] : a[i + 2], 16);
+    float c = (h8 ? b[1] : b[0]) + __shfl_xor(h8 ? b[0] : b[1], 8);
+    c += __shfl_xor(c, 4);
+    c += __shfl_xor(c, 2);
+    c += __shfl_xor(c, 1);
+    return c;
 }
 
 // Count storage.  kCountF32: the uploaded fp32 layers (pseudo-count already applied in place).
@@ -318,7 +338,7 @@ __device__ __forceinline__ void decode_counts(const CountRegs<CS> &C, float pc, 
 }
 
 // the vectors one lane holds for one cell row (mp: Xc.Wc_loc from the GEMM, wide designs only)
-template <int CS> struct RowRegs { CountRegs<CS> cnt; F4 mu, rho, mm, vm, mr, vr, mp; };
+template <int CS> struct RowRegs { CountRegs<CS> cnt; F4 mu, rho, mm, vm, mr, vr, mp; float wgl; };
 
 constexpr float kOneMinusB1 = 1.0f - 0.9f;      // as Keras computes it in fp32
 constexpr float kOneMinusB2 = 1.0f - 0.999f;
@@ -339,7 +359,7 @@ constexpr float kAdamEps = 1e-7f;
 // is Kc LDS reads + 4 Kc FMAs per lane.  Backward: the residual r = (mu - m)/sigma^2 is written to `rbuf`
 // (one extra 4-B/element stream) and G = Xc^T . r is reduced over cells on the matrix cores by
 // wide_design_grad (v_mfma_f32_32x32x2_f32), which reads it back once.
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false>
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
@@ -348,10 +368,14 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
     const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
     static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
+    static_assert(!GW || (CPL && !WIDE), "GW is the coupled variant for Kg > 4");
+    extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
-    __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
+    // GW: the cross-wave fold reuses the (dynamic) Xg tile once the row loop is over -- keeps 2 workgroups per CU
+    __shared__ float red_static[GW ? 1 : (kWavesPerBlock - 1) * S * kGenesPerBlock];
     __shared__ float wlds[WIDE ? kWideKcMax * kGenesPerBlock : 1];      // W tile of this gene block
+    float *red = GW ? xlds : red_static;
 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -364,6 +388,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     if constexpr (WIDE) {
         for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
             wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
+        __syncthreads();
+    }
+    if constexpr (GW) {
+        for (int i = threadIdx.x; i < cp.kgp * kGenesPerBlock; i += kBlock)
+            xlds[i] = cp.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
         __syncthreads();
     }
 
@@ -380,8 +409,8 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         // per-gene parameters, live across the whole chunk
         float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
-        float Xgk[CPL ? kKgMax : 1][kVec];
-        if constexpr (CPL) {
+        float Xgk[(CPL && !GW) ? kKgMax : 1][kVec];
+        if constexpr (CPL && !GW) {
 #pragma unroll
             for (int k = 0; k < kKgMax; ++k) {
                 const F4 t = ld4(cp.Xg + k * a.ld + j0);
@@ -429,8 +458,12 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX], RowScalars &rs) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             if constexpr (CPL) {
+                if constexpr (GW) {      // the cell's Wg_loc row: lane k holds feature k (one coalesced load)
+                    R.wgl = lane < cp.kgp ? cp.Wg[static_cast<int64_t>(r) * cp.kgp + lane] : 0.0f;
+                } else {
 #pragma unroll
-                for (int k = 0; k < kKgMax; ++k) rs.wg[k] = cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                    for (int k = 0; k < kKgMax; ++k) rs.wg[k] = cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                }
                 rs.cb = cp.cb[r];
                 rs.clam = cp.clam[r];
             }
@@ -451,7 +484,17 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             const bool cell = CPL && cp.cell_mode != 0;
             const float row_isig2 = CPL ? f_exp(-2.0f * rs.clam) : 0.0f;
-            float rstat[CPL ? kRowStats : 1] = {};
+            float rstat[CPL ? kKgMax + 2 : 1] = {};      // [k < 4] sum r Xg_k (register variant), [4] sum r, [5] sum (1 - d r - s2r)
+            float mg[kVec] = {0.f, 0.f, 0.f, 0.f}, rqv[kVec] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (GW) {          // Wg_loc . Xg^T: broadcast w_k with v_readlane, Xg_k from LDS
+                const int wbits = __builtin_bit_cast(int, R.wgl);
+                for (int k = 0; k < cp.Kg; ++k) {
+                    const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, k));
+                    const F4 xk = ld4(xlds + k * kGenesPerBlock + lane * kVec);
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) mg[v] = fmaf(wk, xk.v[v], mg[v]);
+                }
+            }
             F4 c1, c2, c3;
             decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
             if constexpr (WIDE) {        // Xc . Wc_loc: broadcast x_k with v_readlane, W_k from LDS
@@ -497,10 +540,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc (LDS tile)
 #pragma unroll
                 for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
-                if constexpr (CPL) {
+                if constexpr (CPL && !GW) {
 #pragma unroll
                     for (int k = 0; k < kKgMax; ++k) m = fmaf(rs.wg[k], Xgk[k][v], m);   // + Wg_loc . Xg^T
                 }
+                if constexpr (GW) m += mg[v];
                 const float is2 = cell ? row_isig2 : isig2[v];
                 const float d = R.mu.v[v] - m;
                 const float rr = d * is2;                                          // (mu - m) / sigma^2
@@ -510,8 +554,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 if constexpr (CPL) {     // padding genes inside the last quad (Ng % 4 != 0) are not part of the cell's sums
                     const bool real = j0 + v < a.Ng;
                     const float rq = real ? rr : 0.0f;
+                    rqv[v] = rq;
+                    if constexpr (!GW) {
 #pragma unroll
-                    for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rq, Xgk[k][v], rstat[k]);
+                        for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rq, Xgk[k][v], rstat[k]);
+                    }
                     rstat[kKgMax] += rq;
                     rstat[kKgMax + 1] += real ? 1.0f - d * rr - s2r : 0.0f;
                 }
@@ -550,11 +597,39 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 if constexpr (WIDE) st4s(rbuf + off, R.mp);
             }
             if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
+                float *chunk = cp.row_partials + static_cast<int64_t>(blockIdx.x) * (cp.kgp + 2) * a.Nc;
+                if constexpr (GW) {
+                    // sum_j r_j Xg[j, k] for 8 features at a time; lane l ends up with feature 8 (l & 7) + (l >> 3)
+                    float mine = 0.0f;
+                    for (int g = 0; g * 8 < cp.kgp; ++g) {
+                        float t[8];
 #pragma unroll
-                for (int q = 0; q < kRowStats; ++q) {
-                    const float t = wave_sum(active ? rstat[q] : 0.0f);
-                    if (lane == 0)
-                        cp.row_partials[(static_cast<int64_t>(blockIdx.x) * kRowStats + q) * a.Nc + r] = t;
+                        for (int i = 0; i < 8; ++i) {
+                            t[i] = 0.0f;
+                            if (g * 8 + i < cp.kgp) {
+                                const F4 xk = ld4(xlds + (g * 8 + i) * kGenesPerBlock + lane * kVec);
+#pragma unroll
+                                for (int v = 0; v < kVec; ++v) t[i] = fmaf(rqv[v], xk.v[v], t[i]);
+                            }
+                        }
+                        const float c = wave_sum8(t, lane);
+                        mine = (lane & 7) == g ? c : mine;
+                    }
+                    const int kf = 8 * (lane & 7) + (lane >> 3);
+                    if (kf < cp.kgp) chunk[static_cast<int64_t>(r) * cp.kgp + kf] = mine;
+                } else {
+                    float mine = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < kKgMax; ++q) {
+                        const float t = wave_sum(active ? rstat[q] : 0.0f);
+                        mine = lane == q ? t : mine;
+                    }
+                    if (lane < kKgMax) chunk[static_cast<int64_t>(r) * kKgMax + lane] = mine;
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const float t = wave_sum(active ? rstat[kKgMax + q] : 0.0f);
+                    if (lane == 0) chunk[static_cast<int64_t>(cp.kgp + q) * a.Nc + r] = t;
                 }
             }
         };
@@ -594,6 +669,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     }
 
     // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row
+    if constexpr (GW) __syncthreads();      // every wave is done reading the Xg tile the fold overwrites
     if (w > 0) {
 #pragma unroll
         for (int s = 0; s < S; ++s)
@@ -773,7 +849,8 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         float Xgk[kKgMax][kVec] = {};
-        if (a.coupled) {
+        const bool xg_regs = a.coupled && a.cp.Kg <= kKgMax;     // Kg > 4: Wg_loc . Xg^T arrives through mbuf
+        if (xg_regs) {
 #pragma unroll
             for (int k = 0; k < kKgMax; ++k) {
                 const F4 t = ld4(a.cp.Xg + k * a.ld + j0);
@@ -788,8 +865,10 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             float wg[kKgMax] = {0.f, 0.f, 0.f, 0.f}, cbr = 0.f, clamr = 0.f;
             if (a.coupled) {
+                if (xg_regs) {
 #pragma unroll
-                for (int k = 0; k < kKgMax; ++k) wg[k] = a.cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                    for (int k = 0; k < kKgMax; ++k) wg[k] = a.cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
+                }
                 cbr = a.cp.cb[r];
                 clamr = a.cp.clam[r];
             }
@@ -996,42 +1075,44 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
 }
 
 #ifdef BRIE_HOST_TU
-// cell_finalize: per cell, sum the gene blocks' row partials (fp64) and apply Adam to Wg_loc
-// (model_TFProb.py:85,124-125) and, in cell mode, to the per-cell intercept (clip) and sigma_log.
-// `rowstat` (kRowStats, Nc) receives the reduced statistics (the buffer a multi-GPU run all-reduces).
+// cell_finalize: sum the gene blocks' row chunks (fp64) and apply Adam to Wg_loc (model_TFProb.py:85,124-125)
+// and, in cell mode, to the per-cell intercept (clip) and sigma_log.  One thread per float of the chunk layout
+// [Nc][kgp] | [Nc] | [Nc] (see CoupledArgs); `rowstat` (same layout) receives the reduced statistics -- the
+// buffer a multi-GPU run all-reduces.
 struct CellFinalizeArgs {
-    const float *row_partials;  // (gene_blocks, kRowStats, Nc)
-    float *rowstat;             // (kRowStats, Nc)
-    float *Wg, *m_Wg, *v_Wg;    // (Nc, kKgMax)
+    const float *row_partials;  // (gene_blocks, (kgp + 2) * Nc)
+    float *rowstat;             // ((kgp + 2) * Nc)
+    float *Wg, *m_Wg, *v_Wg;    // (Nc, kgp)
     float *cb, *m_cb, *v_cb;    // (Nc)
     float *clam, *m_clam, *v_clam;
     int32_t Nc, gene_blocks, Kg, cell_mode, train_b, train_lam;
     int32_t phase;              // 0: reduce + Adam; 1: reduce only; 2: Adam only (rowstat given)
     float alpha;
+    int32_t kgp;
 };
 __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int q = blockIdx.y;                       // statistic
-    if (i >= a.Nc) return;
+    const int64_t chunk = static_cast<int64_t>(a.kgp + 2) * a.Nc;
+    const int64_t e = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
+    if (e >= chunk) return;
     float t;
     if (a.phase != 2) {
         double acc = 0.0;
-        for (int g = 0; g < a.gene_blocks; ++g)
-            acc += static_cast<double>(a.row_partials[(static_cast<int64_t>(g) * kRowStats + q) * a.Nc + i]);
+        for (int g = 0; g < a.gene_blocks; ++g) acc += static_cast<double>(a.row_partials[g * chunk + e]);
         t = static_cast<float>(acc);
-        a.rowstat[static_cast<int64_t>(q) * a.Nc + i] = t;
+        a.rowstat[e] = t;
         if (a.phase == 1) return;
     } else {
-        t = a.rowstat[static_cast<int64_t>(q) * a.Nc + i];
+        t = a.rowstat[e];
     }
-    if (q < kKgMax) {
-        if (q < a.Kg) {
-            const int64_t o = static_cast<int64_t>(i) * kKgMax + q;
-            float x = a.Wg[o], m = a.m_Wg[o], v = a.v_Wg[o];
+    const int64_t n_w = static_cast<int64_t>(a.Nc) * a.kgp;
+    if (e < n_w) {
+        if (static_cast<int>(e % a.kgp) < a.Kg) {
+            float x = a.Wg[e], m = a.m_Wg[e], v = a.v_Wg[e];
             adam_scalar(x, m, v, -t, a.alpha);                                  // dL/dWg = -r . Xg
-            a.Wg[o] = x; a.m_Wg[o] = m; a.v_Wg[o] = v;
+            a.Wg[e] = x; a.m_Wg[e] = m; a.v_Wg[e] = v;
         }
-    } else if (q == kKgMax) {
+    } else if (e < n_w + a.Nc) {
+        const int64_t i = e - n_w;
         if (a.cell_mode && a.train_b) {
             float x = a.cb[i], m = a.m_cb[i], v = a.v_cb[i];
             adam_scalar(x, m, v, -t, a.alpha);
@@ -1039,6 +1120,7 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
             a.cb[i] = x; a.m_cb[i] = m; a.v_cb[i] = v;
         }
     } else if (a.cell_mode && a.train_lam) {
+        const int64_t i = e - n_w - a.Nc;
         float x = a.clam[i], m = a.m_clam[i], v = a.v_clam[i];
         adam_scalar(x, m, v, t, a.alpha);
         a.clam[i] = x; a.m_clam[i] = m; a.v_clam[i] = v;
@@ -1229,14 +1311,20 @@ __global__ void init_gene_rows(float *dst, int64_t ld, int rows, int Ng, uint32_
 }
 
 // per-cell initial state (gene index NOT offset by the shard: identical on every rank):
-//   Wg_loc[i, k] = eps(kInitDraw, 4, cell i, gene k)  (k < Kg <= 4 = one Philox call), zero beyond Kg
+//   Wg_loc[i, k] = eps(kInitDraw, 4, cell i, "gene" k)  (feature k in the gene slot of the counter), zero beyond Kg
 //   cell-mode intercept[i] = eps(kInitDraw, 3, cell i, gene 0)
-__global__ void init_cell_params(float *Wg, float *cb, int Nc, int Kg, int init_cb, uint32_t seed_lo, uint32_t seed_hi) {
+__global__ void init_cell_params(float *Wg, float *cb, int Nc, int Kg, int kgp, int init_cb, uint32_t seed_lo,
+                                 uint32_t seed_hi) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nc) return;
     float e[kVec];
-    normal4(0u, static_cast<uint32_t>(i), kInitDraw, 4u, seed_lo, seed_hi, e);
-    for (int k = 0; k < kKgMax; ++k) Wg[static_cast<int64_t>(i) * kKgMax + k] = k < Kg ? e[k] : 0.0f;
+    for (int q = 0; q < kgp / kVec; ++q) {
+        normal4(static_cast<uint32_t>(q), static_cast<uint32_t>(i), kInitDraw, 4u, seed_lo, seed_hi, e);
+        for (int v = 0; v < kVec; ++v) {
+            const int k = q * kVec + v;
+            Wg[static_cast<int64_t>(i) * kgp + k] = k < Kg ? e[v] : 0.0f;
+        }
+    }
     if (init_cb) {
         normal4(0u, static_cast<uint32_t>(i), kInitDraw, 3u, seed_lo, seed_hi, e);
         cb[i] = e[0];

@@ -21,6 +21,7 @@ struct LaunchCfg {
     hipStream_t stream;
     int coupled;   // 1: gene features and/or per-cell intercept (CoupledArgs valid)
     float *rbuf = nullptr;         // wide designs (Kc > 8): residual buffer read back by wide_design_grad
+    int gw_lds_bytes = 0;          // > 0: Kg > 4, GW variant with an Xg tile of this many bytes in dynamic LDS
 };
 
 #define BRIE_DECLARE_KC(N)                                                                          \

@@ -226,7 +226,7 @@ class BRIE2(object):
 
         if self._comm is not None and self._stat is None:
             import torch
-            self._stat = torch.zeros(6 * self.Nc, dtype=torch.float32, device=torch.device("cuda", self.device))
+            self._stat = torch.zeros(sh.rowstat_size(), dtype=torch.float32, device=torch.device("cuda", self.device))
 
         def run(n_steps, lr):
             if self._comm is not None:          # coupled gene shard: per-step all-reduce of per-cell statistics

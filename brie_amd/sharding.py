@@ -12,7 +12,7 @@ RCCL (torch.distributed backend "nccl") is used only for
 Cell x gene matrices (Psi, Z_std, Psi_95CI) stay sharded (rank 0 can gather them at the end).
 
 Coupled fits (Kg > 0 or intercept_mode='cell') do have a per-step exchange: the per-cell
-parameters are replicated and every step all-reduces the (6, Nc) per-cell statistics
+parameters are replicated and every step all-reduces the ((max(Kg,4)+2) x Nc) per-cell statistics
 (`allreduce_inplace`, 1.2 MB at Nc = 50k) between brie_step_begin and brie_step_end.
 """
 import numpy as np
@@ -76,7 +76,7 @@ class GeneComm(object):
 
     def allreduce_inplace(self, t):
         """Sum a float32 device tensor over ranks in place and return once the result is visible to every
-        stream (the per-step exchange of a gene-sharded COUPLED fit: (6, Nc) per-cell statistics)."""
+        stream (the per-step exchange of a gene-sharded COUPLED fit: per-cell statistics)."""
         import torch
         if self.backend == "nccl":
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)

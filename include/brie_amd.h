@@ -76,7 +76,7 @@ typedef struct brie_problem {
     int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
                                  keys the noise stream so results do not depend on sharding */
     int32_t Kc;               /* cell features (0..BRIE_MAX_KC_WIDE) */
-    int32_t Kg;               /* gene features (0..BRIE_MAX_KG); > 0 couples the genes of a shard */
+    int32_t Kg;               /* gene features (0..BRIE_MAX_KG_WIDE); > 0 couples the genes of a shard */
     int32_t n_layers;         /* 2 or 3 count layers */
     int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
                                  1: effLen likelihood (model_TFProb.py:168-185) */
@@ -90,7 +90,8 @@ typedef struct brie_problem {
 
 #define BRIE_MAX_KC 8         /* cell features fused into the streaming kernel (Xc row in SGPRs) */
 #define BRIE_MAX_KC_WIDE 64   /* wider designs: W tile in LDS for Xc.W, hand-written fp32 MFMA kernel for Xc^T.r */
-#define BRIE_MAX_KG 4
+#define BRIE_MAX_KG 4          /* gene features kept in registers; above: Xg tile in LDS */
+#define BRIE_MAX_KG_WIDE 64
 
 typedef struct brie_handle brie_handle;
 
@@ -149,8 +150,10 @@ int brie_set_target(brie_handle *h, int32_t target);
  * freely"): the per-cell parameters are replicated on every rank and need the sum over ALL genes of
  * the per-cell statistics before their Adam update.  One step is then
  *     brie_step_begin(h, lr, mc)            main pass + per-gene Adam + local per-cell sums
- *     all-reduce(sum) the (6, Nc) buffer    (RCCL; brie_rowstat_buffer, or a caller-owned device
- *                                            buffer registered with brie_set_rowstat_buffer)
+ *     all-reduce(sum) the statistics buffer (RCCL; brie_rowstat_buffer reports it and its size,
+ *                                            (max(4, Kg rounded up to 4) + 2) * Nc floats laid out as
+ *                                            [Nc][kgp] Wg_loc gradient | [Nc] | [Nc]; or a caller-owned
+ *                                            device buffer registered with brie_set_rowstat_buffer)
  *     brie_step_end(h, &loss)               Adam for Wg_loc / per-cell intercept / sigma; local loss
  * brie_step() = begin + end without the exchange (single shard). */
 int brie_step_begin(brie_handle *h, float lr, int32_t mc_size);

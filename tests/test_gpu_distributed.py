@@ -11,10 +11,10 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-NC, NG, KC, KG, STEPS = 120, 520, 1, 2, 6
+NC, NG, KC, STEPS = 120, 520, 1, 6
 
 
-def _problem():
+def _problem(KG):
     from tests import util
     P = util.problem(NC, NG, KC, 2, seed=51)
     P["Xg"] = np.random.default_rng(8).standard_normal((NG, KG)).astype(np.float32)
@@ -29,7 +29,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, KG):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
@@ -38,7 +38,7 @@ def _worker(rank, world, port, out_dir):
     from brie_amd.sharding import GeneComm, gene_shard
     from tests import util
     comm = GeneComm()
-    P = _problem()
+    P = _problem(KG)
     g0, g1 = gene_shard(NG, rank, world)
     Ps = dict(P, counts=[c[:, g0:g1].copy() for c in P["counts"]], Xg=P["Xg"][g0:g1].copy())
     sh = _capi.Shard(NC, g1 - g0, KC, n_layers=2, seed=61, gene_offset=g0, Kg=KG, intercept_mode=1, sharded=True)
@@ -50,7 +50,7 @@ def _worker(rank, world, port, out_dir):
     sh.init_state()
     with pytest.raises(_capi.BrieError):
         sh.step(1, 0.01)                       # a coupled shard must use the begin/end protocol
-    stat = torch.zeros(6 * NC, dtype=torch.float32, device="cuda:0")
+    stat = torch.zeros(sh.rowstat_size(), dtype=torch.float32, device="cuda:0")
     trace = sh.step_sharded(STEPS, 0.01, 1, comm.allreduce_inplace, stat)
     trace = comm.allreduce_sum(trace)
     st = util.device_state(sh)
@@ -59,10 +59,11 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_coupled_gene_shards_world2_match_single_fit(lib, tmp_path):
+@pytest.mark.parametrize("KG", [2, 6])          # registers (Kg <= 4) / Xg tile in LDS
+def test_coupled_gene_shards_world2_match_single_fit(lib, tmp_path, KG):
     from tests import util
-    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    P = _problem()
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), KG), nprocs=2, join=True)
+    P = _problem(KG)
     full = util.device_shard(P, NC, NG, KC, 61, Kg=KG, mode="cell")
     tr = full.step(STEPS, 0.01, 1)
     ref = util.device_state(full)

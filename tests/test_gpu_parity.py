@@ -160,7 +160,7 @@ def test_gene_shard_invariance(lib):
 def test_errors_are_loud(lib):
     from brie_amd import _capi
     with pytest.raises(NotImplementedError):
-        _capi.Shard(10, 10, Kg=5)
+        _capi.Shard(10, 10, Kg=65)                                  # more gene features than the LDS tile holds
     with pytest.raises(NotImplementedError):
         _capi.Shard(10, 12, intercept_mode=1, gene_offset=4)       # coupled modes cannot be gene-sharded
     with pytest.raises(ValueError):
@@ -278,7 +278,10 @@ def test_count_storage_tiers(lib):
 
 
 @pytest.mark.parametrize("mode,Kg,Kc,L,MC", [("cell", 0, 1, 2, 1), ("gene", 2, 1, 2, 1), ("cell", 4, 2, 3, 3),
-                                             ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1)])
+                                             ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1),
+                                             # Kg > 4: Xg tile in LDS, Wg_loc row broadcast with v_readlane
+                                             ("gene", 5, 1, 2, 1), ("cell", 16, 2, 3, 2), ("gene", 33, 8, 2, 3),
+                                             ("gene", 64, 0, 2, 1)])
 def test_coupled_modes_match_oracle(lib, mode, Kg, Kc, L, MC):
     """Gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125) and per-cell intercept /
     sigma (intercept_mode='cell', :53-55): per-cell statistics are wave-reduced over genes on the device."""
@@ -301,9 +304,10 @@ def test_coupled_modes_match_oracle(lib, mode, Kg, Kc, L, MC):
     np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
 
 
-def test_coupled_fit_through_python_api(lib):
+@pytest.mark.parametrize("Kg", [2, 9])
+def test_coupled_fit_through_python_api(lib, Kg):
     import brie_amd
-    Nc, Ng, Kc, Kg = 80, 70, 1, 2
+    Nc, Ng, Kc = 80, 70, 1
     P = util.problem(Nc, Ng, Kc, 2, seed=43)
     Xg = np.random.default_rng(6).standard_normal((Ng, Kg)).astype(np.float32)
     m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, Kg=Kg, intercept_mode='cell', seed=9)
@@ -467,7 +471,7 @@ def _random_cases(n, seed=20261001):
         MC = int(rng.choice([1, 2, 3, 5]))
         kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin"][i % 7]
         Kc = int(rng.integers(9, 41)) if kind == "wide" else int(rng.integers(0, 9))
-        Kg = int(rng.integers(1, 5)) if kind == "xg" else 0
+        Kg = int(rng.choice([1, 2, 3, 4, 5, 7, 12, 40])) if kind == "xg" else 0
         eff = bool(L == 3 or rng.random() < 0.3)
         cases.append((i, kind, Nc, Ng, Kc, Kg, L, MC, eff))
     return cases

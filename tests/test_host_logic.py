@@ -37,7 +37,7 @@ def test_capi_exports_every_declared_symbol(built_lib):
 def test_capi_struct_layout_matches_header():
     import ctypes
     from brie_amd import _capi
-    assert _capi.MAX_KC == 64 and _capi.MAX_KG == 4
+    assert _capi.MAX_KC == 64 and _capi.MAX_KG == 64
     assert ctypes.sizeof(_capi.BrieProblem) == 72
     assert _capi.BrieProblem.seed.offset == 64 and _capi.BrieProblem.Kc.offset == 32
 
@@ -157,7 +157,7 @@ def test_fitBRIE_emulated_batches_equal_whole_fit(patched_wrap):
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):
-        brie_amd.BRIE2(10, 10, Kg=5)
+        brie_amd.BRIE2(10, 10, Kg=65)
     with pytest.raises(NotImplementedError):
         brie_amd.BRIE2(10, 12, intercept_mode='cell', gene_offset=4)
     m = brie_amd.BRIE2(10, 10)

@@ -172,7 +172,7 @@ int check_ready(const brie_handle *h) {
 
 void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
                  const brie::StepScalars &a, const brie::CoupledArgs &cp) {
-    if (h->wide) { brie::launch_step_wide(c, q, a); return; }
+    if (h->wide) { brie::launch_step_wide(c, q, a, cp); return; }
     switch (h->p.Kc) {
 #define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a, cp); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
@@ -419,9 +419,6 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_WIDE);
     if (p->Kg > BRIE_MAX_KG_WIDE)
         return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG_WIDE);
-    if (p->Kc > BRIE_MAX_KC && (p->Kg > 0 || p->intercept_mode == 1))
-        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d > %d (wide design) together with gene features / cell intercepts "
-                    "is not built", p->Kc, BRIE_MAX_KC);
     if (p->Kg < 0) return fail(BRIE_ERR_INVALID, "Kg=%d", p->Kg);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
         return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
@@ -885,14 +882,14 @@ int cell_finalize_blocks(const brie_handle *h) {
 
 // Kg > 4, forward only (loss_gene_eval reads it): Mbuf = Wg_loc . Xg^T -- the same (rows x K).(K x genes) product as
 // the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
-int gwide_forward_mean(brie_handle *h) {
+int gwide_forward_mean(brie_handle *h, bool accumulate) {
     if (!h->Mbuf) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
     }
     hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Wg,
                        h->Xg, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->kgp, h->ld, h->row_stride,
-                       h->gb_stride, h->rows_per_chunk);
+                       h->gb_stride, h->rows_per_chunk, accumulate ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
 }
@@ -904,7 +901,7 @@ int wide_forward_mean(brie_handle *h) {
     }
     hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Xc,
                        h->W, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->p.Kc, h->ld, h->row_stride,
-                       h->gb_stride, h->rows_per_chunk);
+                       h->gb_stride, h->rows_per_chunk, 0);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
 }
@@ -1098,8 +1095,8 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
         if ((rc = wide_forward_mean(h)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
-    if (h->gwide) {
-        if ((rc = gwide_forward_mean(h)) != BRIE_OK) return rc;
+    if (h->gwide) {          // after the wide cell design's Xc . Wc_loc, if any (same buffer)
+        if ((rc = gwide_forward_mean(h, h->wide)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;

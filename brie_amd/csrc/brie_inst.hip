@@ -103,30 +103,35 @@ void BRIE_CAT(launch_loss_gene_kc, BRIE_KC)(const LaunchCfg &c, const LossGeneAr
 #if BRIE_KC == 0
 namespace {
 template <int MODE, int CS>
-void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
-    const CoupledArgs cp{};
-#define BRIE_WIDE(MC)                                                                                          \
-    hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, false, true>), c.grid, dim3(kBlock), 0, c.stream, q.c1,   \
+void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+#define BRIE_WIDE(MC, CPL, GW, LDS)                                                                              \
+    hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, CPL, true, GW>), c.grid, dim3(kBlock), LDS, c.stream, q.c1, \
                        q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, \
                        q.partials, a, cp, c.rbuf)
-    if (a.mc == 1) BRIE_WIDE(1);
-    else if (a.mc == 3) BRIE_WIDE(3);
-    else BRIE_WIDE(0);
+    if (c.coupled && c.gw_lds_bytes > 0) {          // wide cell design + Kg > 4: W tile (static) + Xg tile (dynamic) in LDS
+        auto kern = elbo_adam_step<0, MODE, 0, CS, true, true, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
+        BRIE_WIDE(0, true, true, c.gw_lds_bytes);
+    } else if (c.coupled) BRIE_WIDE(0, true, false, 0);
+    else if (a.mc == 1) BRIE_WIDE(1, false, false, 0);
+    else if (a.mc == 3) BRIE_WIDE(3, false, false, 0);
+    else BRIE_WIDE(0, false, false, 0);
 #undef BRIE_WIDE
 }
 template <int MODE>
-void wide_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
-    if (c.cs == kCountU8) wide_mc<MODE, kCountU8>(c, q, a);
-    else if (c.cs == kCountU16) wide_mc<MODE, kCountU16>(c, q, a);
-    else wide_mc<MODE, kCountF32>(c, q, a);
+void wide_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    if (c.cs == kCountU8) wide_mc<MODE, kCountU8>(c, q, a, cp);
+    else if (c.cs == kCountU16) wide_mc<MODE, kCountU16>(c, q, a, cp);
+    else wide_mc<MODE, kCountF32>(c, q, a, cp);
 }
 }  // namespace
 
-void launch_step_wide(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
+void launch_step_wide(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     switch (c.mode) {
-        case kLik2: wide_cs<kLik2>(c, q, a); break;
-        case kLikEff2: wide_cs<kLikEff2>(c, q, a); break;
-        default: wide_cs<kLikEff3>(c, q, a); break;
+        case kLik2: wide_cs<kLik2>(c, q, a, cp); break;
+        case kLikEff2: wide_cs<kLikEff2>(c, q, a, cp); break;
+        default: wide_cs<kLikEff3>(c, q, a, cp); break;
     }
 }
 #endif

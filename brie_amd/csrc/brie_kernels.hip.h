@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
     const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
     static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
-    static_assert(!GW || (CPL && !WIDE), "GW is the coupled variant for Kg > 4");
+    static_assert(!GW || CPL, "GW is the coupled variant for Kg > 4");
     extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
 // wide designs, forward only (loss_gene_eval reads it): Mbuf = Xc . Wc_loc, tiled like the state arrays
 __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const float *W, float *Mbuf, int Nc, int Ng,
                                                           int Kc, int64_t ld, int64_t row_stride, int64_t gb_stride,
-                                                          int rows_per_chunk) {
+                                                          int rows_per_chunk, int accumulate) {
     __shared__ float wlds[kWideKcMax * kGenesPerBlock];
     for (int i = threadIdx.x; i < Kc * kGenesPerBlock; i += kBlock)
         wlds[i] = W[static_cast<int64_t>(i / kGenesPerBlock) * ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
@@ -1143,6 +1143,7 @@ __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const
     for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
         const int xbits = __builtin_bit_cast(int, lane < Kc ? Xc[static_cast<int64_t>(r) * Kc + lane] : 0.0f);
         F4 m = {{0.f, 0.f, 0.f, 0.f}};
+        if (accumulate) m = ld4(Mbuf + mbase + static_cast<int64_t>(r) * row_stride);
         for (int k = 0; k < Kc; ++k) {
             const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xbits, k));
             const F4 wk = ld4(wlds + k * kGenesPerBlock + lane * kVec);

@@ -33,6 +33,6 @@ BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE
 BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)
 #undef BRIE_DECLARE_KC
 // wide cell designs: KC == 0 kernels with the W tile in LDS, writing the residual buffer (defined in the kc0 unit)
-void launch_step_wide(const LaunchCfg &, const StepPointers &, const StepScalars &);
+void launch_step_wide(const LaunchCfg &, const StepPointers &, const StepScalars &, const CoupledArgs &);
 
 }  // namespace brie

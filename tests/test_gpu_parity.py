@@ -281,7 +281,9 @@ def test_count_storage_tiers(lib):
                                              ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1),
                                              # Kg > 4: Xg tile in LDS, Wg_loc row broadcast with v_readlane
                                              ("gene", 5, 1, 2, 1), ("cell", 16, 2, 3, 2), ("gene", 33, 8, 2, 3),
-                                             ("gene", 64, 0, 2, 1)])
+                                             ("gene", 64, 0, 2, 1),
+                                             # wide cell design (Kc > 8) together with the coupled terms
+                                             ("cell", 0, 12, 2, 1), ("gene", 3, 20, 3, 2), ("cell", 9, 33, 2, 1)])
 def test_coupled_modes_match_oracle(lib, mode, Kg, Kc, L, MC):
     """Gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125) and per-cell intercept /
     sigma (intercept_mode='cell', :53-55): per-cell statistics are wave-reduced over genes on the device."""
@@ -469,15 +471,15 @@ def _random_cases(n, seed=20261001):
         Ng = int(rng.choice([1, 3, 4, 5, 255, 256, 257, 511, 700, 1025]))
         L = int(rng.choice([2, 3]))
         MC = int(rng.choice([1, 2, 3, 5]))
-        kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin"][i % 7]
-        Kc = int(rng.integers(9, 41)) if kind == "wide" else int(rng.integers(0, 9))
-        Kg = int(rng.choice([1, 2, 3, 4, 5, 7, 12, 40])) if kind == "xg" else 0
+        kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin", "wide_cell", "wide_xg"][i % 9]
+        Kc = int(rng.integers(9, 41)) if kind.startswith("wide") else int(rng.integers(0, 9))
+        Kg = int(rng.choice([1, 2, 3, 4, 5, 7, 12, 40])) if kind.endswith("xg") else 0
         eff = bool(L == 3 or rng.random() < 0.3)
         cases.append((i, kind, Nc, Ng, Kc, Kg, L, MC, eff))
     return cases
 
 
-@pytest.mark.parametrize("i,kind,Nc,Ng,Kc,Kg,L,MC,eff", _random_cases(56))
+@pytest.mark.parametrize("i,kind,Nc,Ng,Kc,Kg,L,MC,eff", _random_cases(63))
 def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff):
     """Every product switch of BRIE2.__init__/fit (model_TFProb.py:42-85,214-273) at awkward sizes: partly filled
     gene blocks, fewer cells than one chunk, single cell / single gene, Kc across the fused/wide boundary."""
@@ -489,7 +491,7 @@ def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff
         P["effLen"] = np.random.default_rng(i).uniform(50, 400, (Ng, 6)).astype(np.float32)
     if Kg:
         P["Xg"] = np.random.default_rng(i + 77).standard_normal((Ng, Kg)).astype(np.float32)
-    mode = "cell" if kind == "cell" else "gene"
+    mode = "cell" if kind in ("cell", "wide_cell") else "gene"
     fixed = dict(intercept=0.25, sigma=1.5) if kind == "fixed" else {}
     seed = 5000 + i
     o = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode, **fixed)
@@ -502,12 +504,11 @@ def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff
     np.testing.assert_allclose(tr_d, tr_o, rtol=5e-5, atol=1e-3)
     assert_states_close(util.oracle_state(o), util.device_state(sh))
     d = np.abs(sh.read(_capi.PSI) - o.Psi)
-    assert d.max() < 1e-4
-    np.testing.assert_allclose(sh.read(_capi.PSI95CI), o.Psi95CI, atol=2e-4)
+    assert np.percentile(d, 99.9) < 2e-5 and d.max() < 5e-4     # bulk + Adam-amplified outliers, as assert_states_close
+    np.testing.assert_allclose(sh.read(_capi.PSI95CI), o.Psi95CI, atol=5e-4)
     np.testing.assert_allclose(sh.read(_capi.Z_STD), o.Z_std, rtol=1e-3, atol=1e-6)
-    if kind not in ("wide",):                       # 3-draw per-gene loss on the updated state
-        lg_o = o.eval_loss_gene(P["counts_pc"], P["Xc"], 3, target=target)
-        np.testing.assert_allclose(sh.loss_gene(3), lg_o, rtol=2e-4, atol=2e-3)
+    lg_o = o.eval_loss_gene(P["counts_pc"], P["Xc"], 3, target=target)          # 3-draw per-gene loss, updated state
+    np.testing.assert_allclose(sh.loss_gene(3), lg_o, rtol=2e-4, atol=2e-3)
     sh.close()
 
 

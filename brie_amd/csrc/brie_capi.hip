@@ -1272,22 +1272,38 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     const dim3 grid(8192), block(brie::kBlock);
     const bool nt = lds_bytes_per_block < 0;          // negative: non-temporal variant, |value| = LDS bytes
     const int lds = lds_bytes_per_block < 0 ? -lds_bytes_per_block - 1 : lds_bytes_per_block;
-    for (int it = -2; it < iters; ++it) {
-        if (it == 0) hipEventRecord(e0, nullptr);
-#define BRIE_SM(NR, NW)                                                                                  \
-    do {                                                                                                 \
-        if (nt) hipLaunchKernelGGL((brie::stream_mix<NR, NW, true>), grid, block, lds, nullptr, a);      \
-        else hipLaunchKernelGGL((brie::stream_mix<NR, NW, false>), grid, block, lds, nullptr, a);        \
-    } while (0)
-        if (n_read == 1) BRIE_SM(1, 1);
-        else if (n_read == 8) BRIE_SM(8, 6);
-        else BRIE_SM(9, 6);
-#undef BRIE_SM
-    }
-    hipEventRecord(e1, nullptr);
-    hipError_t e = hipEventSynchronize(e1);
+    // three depths of loads in flight per thread (1, 2, 4 vectors x n_read streams); the best one is reported
     float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
+    hipError_t e = hipSuccess;
+    const char *only_env = getenv("BRIE_CALIB_VARIANT");      // experiments: time one variant (1, 2 or 4) only
+    const int only = only_env ? atoi(only_env) : 0;
+    for (int unroll = 1; unroll <= 4 && e == hipSuccess; unroll *= 2) {
+        if (only && unroll != only) continue;
+        for (int it = -2; it < iters; ++it) {
+            if (it == 0) hipEventRecord(e0, nullptr);
+#define BRIE_SM2(NR, NW, U)                                                                               \
+    do {                                                                                                 \
+        if (nt) hipLaunchKernelGGL((brie::stream_mix<NR, NW, true, U>), grid, block, lds, nullptr, a);   \
+        else hipLaunchKernelGGL((brie::stream_mix<NR, NW, false, U>), grid, block, lds, nullptr, a);     \
+    } while (0)
+#define BRIE_SM(NR, NW)                                  \
+    do {                                                 \
+        if (unroll == 1) BRIE_SM2(NR, NW, 1);            \
+        else if (unroll == 2) BRIE_SM2(NR, NW, 2);       \
+        else BRIE_SM2(NR, NW, 4);                        \
+    } while (0)
+            if (n_read == 1) BRIE_SM(1, 1);
+            else if (n_read == 8) BRIE_SM(8, 6);
+            else BRIE_SM(9, 6);
+#undef BRIE_SM
+#undef BRIE_SM2
+        }
+        hipEventRecord(e1, nullptr);
+        e = hipEventSynchronize(e1);
+        float t = 0.f;
+        hipEventElapsedTime(&t, e0, e1);
+        if (e == hipSuccess && (ms == 0.f || t < ms)) ms = t;
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     cleanup();
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "calibration: %s", hipGetErrorString(e));

@@ -1616,21 +1616,73 @@ struct StreamArgs {
     float *out[12];
     int64_t n4;          // float4 elements per stream
 };
-template <int NR, int NW, bool NT>
+template <int NR, int NW, bool NT, int U = 1>
 __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < a.n4;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        F4 acc = {{0.f, 0.f, 0.f, 0.f}};
+    // U independent 16-B vectors per thread and iteration, all NR*U loads issued before the first store
+    // (the fused kernel keeps a comparable number of bytes in flight through its row prefetch)
+    // U == 4 additionally walks the streams the way the fused kernel does: a workgroup owns a contiguous 256-KiB
+    // piece of every stream (consecutive 4-KiB slabs) instead of slabs a whole grid apart
+    if constexpr (U == 4) {
+        constexpr int64_t kPiece = 16384;                       // float4 per workgroup piece
+        const int64_t n_pieces = (a.n4 + kPiece - 1) / kPiece;
+        for (int64_t p = blockIdx.x; p < n_pieces; p += gridDim.x) {
+            const int64_t base = p * kPiece, end = base + kPiece < a.n4 ? base + kPiece : a.n4;
+            for (int64_t i0 = base + threadIdx.x; i0 < end; i0 += kBlock * 2) {
+                F4 t[2][NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const F4 t = NT ? ld4s(a.in[r] + 4 * i) : ld4(a.in[r] + 4 * i);
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t i = i0 + u * kBlock;
+                    if (i < end) {
 #pragma unroll
-            for (int v = 0; v < kVec; ++v) acc.v[v] += t.v[v];
+                        for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * i) : ld4(a.in[r] + 4 * i);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int64_t i = i0 + u * kBlock;
+                    if (i < end) {
+                        F4 acc = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+#pragma unroll
+                            for (int v = 0; v < kVec; ++v) acc.v[v] += t[u][r].v[v];
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) {
+                            if (NT) st4s(a.out[w] + 4 * i, acc);
+                            else st4(a.out[w] + 4 * i, acc);
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * blockDim.x;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i0 < a.n4; i0 += stride * U) {
+        F4 t[U][NR];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < a.n4) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * i) : ld4(a.in[r] + 4 * i);
+            }
         }
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            if (NT) st4s(a.out[w] + 4 * i, acc);
-            else st4(a.out[w] + 4 * i, acc);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < a.n4) {
+                F4 acc = {{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) acc.v[v] += t[u][r].v[v];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    if (NT) st4s(a.out[w] + 4 * i, acc);
+                    else st4(a.out[w] + 4 * i, acc);
+                }
+            }
         }
     }
 }

@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-psi-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
+    # RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this driver (exported on the pool already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
     from brie_amd import _capi

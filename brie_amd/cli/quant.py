@@ -130,6 +130,7 @@ def _distributed_comm(device):
     """One process per GPU under torchrun: NCCL (= RCCL) group + GeneComm; None for a single process."""
     if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) <= 1:
         return None, (0 if device is None else device)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # RCCL across processes: dmabuf IPC
     import torch
     import torch.distributed as dist
     from ..sharding import GeneComm

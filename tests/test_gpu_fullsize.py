@@ -161,3 +161,57 @@ def test_full_size_config3_staged_schedule_psi(lib):
     assert np.percentile(d, 99) < 1e-4 and np.percentile(d, 99.9) < 3e-4 and d.max() < 5e-3
     np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:g0 + 4], o.Wc_loc, atol=5e-4)
     sh.close()
+
+
+def test_full_size_config3_properties(lib):
+    """Size-independent properties at 50k x 20k: run-to-run determinism (no atomics anywhere on the path), the loss
+    trace is the sum of the per-gene losses of the ring (model_TFProb.py:208-211 reduce_sum), a fully frozen shard is
+    a fixed point, and the 500-draw loss_gene is the mean of its parts (two halves of the noise stream)."""
+    import zlib
+    import torch
+    import bench
+    from brie_amd import _capi
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS["c3"]
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 99
+    Xc, layers = _generate(torch, dev, cfg, seed)
+
+    def fresh():
+        sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=seed)
+        for l in range(2):
+            sh.upload(_capi.COUNT1 + l, layers[l])
+        sh.add_pseudo_count(0.01)
+        sh.upload(_capi.XC, Xc)
+        sh.init_state()
+        return sh
+
+    def digest(sh):
+        return [zlib.crc32(np.ascontiguousarray(sh.read(w)).tobytes())
+                for w in (_capi.Z_LOC, _capi.Z_STD_LOG, _capi.WC_LOC, _capi.INTERCEPT, _capi.SIGMA_LOG)]
+
+    sh = fresh()
+    tr_a = sh.step(5, 0.01, 1)
+    dig_a = digest(sh)
+    win = sh.read_loss_window(5)                                   # (5, Ng) per-gene KL - ll of those steps
+    np.testing.assert_allclose(win.astype(np.float64).sum(axis=1), tr_a, rtol=2e-6)
+    # frozen shard: nothing moves, the noise stream still advances
+    sh.set_gene_mask(np.zeros(Ng, bool))
+    sh.step(2, 0.01, 1, trace=False)
+    assert digest(sh) == dig_a
+    sh.set_gene_mask(None)
+    draw = sh.draw
+    lg_all = sh.loss_gene(8)
+    sh.draw = draw
+    lg_1 = sh.loss_gene(4)
+    lg_2 = sh.loss_gene(4)
+    np.testing.assert_allclose(lg_all, 0.5 * (lg_1.astype(np.float64) + lg_2), rtol=1e-5, atol=1e-3)
+    sh.close()
+    del sh
+    torch.cuda.empty_cache()
+
+    sh = fresh()                                                   # second run from scratch: bit-identical
+    tr_b = sh.step(5, 0.01, 1)
+    np.testing.assert_array_equal(tr_a, tr_b)
+    assert digest(sh) == dig_a
+    sh.close()

@@ -1,15 +1,15 @@
 // brie_kernels.hip.h -- CDNA4 (gfx950) device code of the brie-quant ELBO hot path.
 //
-// Data layout in HBM (one gene shard): every cell x gene array is (Nc, ld)
-// fp32 row-major, ld = Ng rounded up to 64 genes (256-B aligned rows), i.e.
-// exactly the reference's C-order (Nc, Ng) layers with a padded pitch.  A lane
-// owns 4 consecutive genes (one 16-B vector); a 64-lane wavefront owns a
-// 256-gene "gene block" and streams cells (rows) through it, so every global
-// access is a fully coalesced 1-KiB wave transaction and every per-gene
-// statistic is a private per-lane register accumulation over cells -- no
-// cross-lane traffic in the streaming loop.  The four waves of a workgroup
-// interleave the rows of one cell chunk and fold their per-gene partials
-// through LDS once per chunk.
+// Data layout in HBM (one gene shard): every cell x gene array is stored as gene-block-major
+// tiles [gene block g = gene / 256][cell][256 genes] fp32 (row_stride = 256, gb_stride = Nc * 256;
+// per-gene vectors have pitch ld = Ng rounded up to 256).  A lane owns 4 consecutive genes (one
+// 16-B vector); a 64-lane wavefront owns a 256-gene "gene block" and streams cells (rows)
+// through it, so every global access is a fully coalesced, contiguous 1-KiB wave transaction,
+// a workgroup walks one contiguous piece of every array, and every per-gene statistic is a
+// private per-lane register accumulation over cells -- no cross-lane traffic in the streaming
+// loop.  The four waves of a workgroup interleave the rows of one cell chunk and fold their
+// per-gene partials through LDS once per chunk.  (BRIE_LAYOUT=rowmajor keeps the reference's
+// C-order (Nc, ld) arrays instead: same kernels, different strides; A/B experiments only.)
 //
 // Reference semantics restated per kernel (paths relative to /root/reference):
 //   elbo_adam_step   brie/models/model_TFProb.py:118-127 (Z_prior), 130-191

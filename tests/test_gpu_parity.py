@@ -539,3 +539,75 @@ def test_gene_shards_bit_identical_to_whole_fit(lib, Nc, Ng, Kc, L, MC, cuts):
         np.testing.assert_array_equal(lg[g0:g1], part.loss_gene(4))
         part.close()
     whole.close()
+
+
+def _op_sequences(n, seed=777):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        Nc = int(rng.choice([5, 64, 130, 300]))
+        Ng = int(rng.choice([4, 9, 257, 600, 1100]))
+        Kc = int(rng.choice([0, 1, 3, 8, 11]))
+        L = int(rng.choice([2, 3]))
+        ops = [str(rng.choice(["step", "step", "mask", "unmask", "reset", "loss_gene", "tiling", "window", "read"]))
+               for _ in range(8)]
+        out.append((i, Nc, Ng, Kc, L, bool(rng.random() < 0.5), bool(rng.random() < 0.5), tuple(ops)))
+    return out
+
+
+@pytest.mark.parametrize("i,Nc,Ng,Kc,L,sparse,f32,ops", _op_sequences(40))
+def test_randomised_operation_sequences(lib, i, Nc, Ng, Kc, L, sparse, f32, ops):
+    """Random interleavings of the calls a fit makes (steps, per-batch masks incl. packing and un-packing, fresh
+    optimiser, loss_gene, loss window, read-back, re-tiling) on random shapes, sparse or dense upload, compact or
+    fp32 count storage -- the oracle follows with the same masks and the same noise-stream position."""
+    import scipy.sparse as sp
+    from brie_amd import _capi
+    rng = np.random.default_rng(900 + i)
+    P = util.problem(Nc, Ng, Kc, L, seed=300 + i)
+    o = util.oracle_model(P, Nc, Ng, Kc, 40 + i, np.float32)
+    sh = _capi.Shard(Nc, Ng, Kc, n_layers=L, has_efflen=P["effLen"] is not None, seed=40 + i)
+    if f32:
+        sh.set_count_storage(1)
+    for l in range(L):
+        sh.upload(_capi.COUNT1 + l, sp.csc_matrix(P["counts"][l]) if sparse else P["counts"][l])
+    sh.add_pseudo_count(0.01)
+    if P["effLen"] is not None:
+        sh.upload(_capi.EFFLEN, P["effLen"])
+    if Kc:
+        sh.upload(_capi.XC, P["Xc"])
+    sh.init_state()
+    masked = False
+    for op in ops:
+        if op == "step":
+            n, mc = int(rng.integers(1, 4)), int(rng.choice([1, 3, 2]))
+            np.testing.assert_allclose(sh.step(n, 0.01, mc), o.minimize(P["counts_pc"], P["Xc"], n, 0.01, mc),
+                                       rtol=5e-5, atol=1e-3, err_msg=str((op, ops)))
+        elif op == "mask":
+            if not o.lg_hist:
+                continue                           # a mask needs a previous loss to carry forward
+            mask = rng.random(Ng) < rng.choice([0.1, 0.5, 0.9])
+            if Ng > 300:
+                mask[256:300] = False
+            o.gene_active = mask.copy()
+            sh.set_gene_mask(mask)
+            masked = True
+        elif op == "unmask":
+            o.gene_active = np.ones(Ng, bool)
+            sh.set_gene_mask(None)
+            masked = False
+        elif op == "reset":
+            o.reset_optimizer()
+            sh.reset_optimizer()
+        elif op == "loss_gene":
+            np.testing.assert_allclose(sh.loss_gene(2), o.eval_loss_gene(P["counts_pc"], P["Xc"], 2),
+                                       rtol=2e-4, atol=2e-3, err_msg=str((op, ops)))
+        elif op == "tiling":
+            sh.set_tiling(int(rng.choice([16, 32, 256])))
+        elif op == "window" and o.lg_hist:
+            k = min(len(o.lg_hist), 3)
+            np.testing.assert_allclose(sh.read_loss_window(k), np.asarray(o.lg_hist[-k:]), rtol=5e-5, atol=2e-3)
+        elif op == "read":
+            assert_states_close(util.oracle_state(o), util.device_state(sh))
+    assert_states_close(util.oracle_state(o), util.device_state(sh))
+    np.testing.assert_array_equal(sh.read(_capi.COUNT1), P["counts_pc"][0])
+    sh.close()

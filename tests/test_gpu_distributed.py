@@ -77,3 +77,50 @@ def test_coupled_gene_shards_world2_match_single_fit(lib, tmp_path, KG):
         got = np.concatenate([r[0][key], r[1][key]], axis=1)
         d = np.abs(got - ref[key])
         assert np.percentile(d, 99.9) < 2e-5 and d.max() < 1e-3, key
+
+
+FIT = dict(min_iter=120, max_iter=120, n_loss_gene=5, verbose=False, seed=3)
+FNC, FNG, FKC = 60, 44, 2
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brie_amd
+    from brie_amd.sharding import GeneComm
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    P = make_problem(FNC, FNG, Kc=FKC, L=3, seed=21)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1], 'ambiguous': P["counts"][2]},
+                     effLen=P["effLen"])
+    res = brie_amd.fitBRIE(ad, Xc=P["Xc"], LRT_index=[1], comm=GeneComm(), **FIT)
+    np.savez(os.path.join(out_dir, "fit%d.npz" % rank), sigma=res.sigma, intercept=res.intercept,
+             cell_coeff=res.cell_coeff, loss_gene=res.loss_gene, ELBO_gain=res.ELBO_gain, pval=res.pval,
+             losses=res.losses, Psi_full=ad.layers.get('Psi', np.zeros(0)), Psi_shard=ad.layers['Psi_shard'],
+             gene_range=np.array(res.gene_range))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fitBRIE_gene_sharded_world2_real_engine(lib, tmp_path):
+    """The whole gene-sharded fitBRIE (BASELINE configs[3] in miniature) with the HIP engine: two ranks, each with its
+    gene block on cuda:0, collectives over gloo.  Genes are independent, so every per-gene result must equal the
+    single-process fit bit for bit; only the summed loss trace is formed in another order."""
+    import brie_amd
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    mp.spawn(_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    P = make_problem(FNC, FNG, Kc=FKC, L=3, seed=21)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1], 'ambiguous': P["counts"][2]},
+                     effLen=P["effLen"])
+    ref = brie_amd.fitBRIE(ad, Xc=P["Xc"], LRT_index=[1], **FIT)
+    r = [np.load(tmp_path / ("fit%d.npz" % k)) for k in range(2)]
+    assert tuple(r[0]["gene_range"]) == (0, 24) and tuple(r[1]["gene_range"]) == (24, 44)
+    for key in ("sigma", "intercept", "cell_coeff", "loss_gene", "ELBO_gain", "pval"):
+        np.testing.assert_array_equal(r[0][key], r[1][key])
+        np.testing.assert_array_equal(r[0][key], getattr(ref, key), err_msg=key)
+    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=1e-6)
+    np.testing.assert_array_equal(r[0]["Psi_full"], ref.Psi)
+    np.testing.assert_array_equal(np.concatenate([r[0]["Psi_shard"], r[1]["Psi_shard"]], axis=1), ref.Psi)
+    assert r[1]["Psi_full"].size == 0

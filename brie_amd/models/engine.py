@@ -37,6 +37,14 @@ def _wrap(a):
     return np.asarray(a).view(HostArray)
 
 
+def _weak(obj):
+    import weakref
+    try:
+        return weakref.ref(obj)
+    except TypeError:            # e.g. a list of lists: never considered "the same"
+        return None
+
+
 def _dense_f32(x):
     """logLik_MC densifies sparse layers on the host (model_TFProb.py:135-137); here scipy sparse
     layers are handed to the library as they are and densified on the device (brie_upload_sparse)."""
@@ -84,15 +92,14 @@ class BRIE2(object):
         if self.effLen is None:
             n_layers = 2                          # third layer unused without effLen (model_TFProb.py:162-167)
         if self._shard is not None and self._n_layers == n_layers:
+            if not self._same_layers(count_layers[:n_layers]):      # other data on the fitted model (e.g. get_loss)
+                self._upload_layers(self._shard, count_layers, n_layers)
             return self._shard
         sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
                          train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
                          seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
                          intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
-        for l in range(n_layers):
-            sh.upload(_capi.COUNT1 + l, _dense_f32(count_layers[l]))
-        if self._pseudo_count:
-            sh.add_pseudo_count(self._pseudo_count)
+        self._upload_layers(sh, count_layers, n_layers)
         if self.effLen is not None:
             sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
         if self.Kc > 0:
@@ -126,6 +133,20 @@ class BRIE2(object):
                 sh.upload(_capi.SIGMA_LOG, np.log(np.asarray(get('sigma'), np.float32)).reshape(par))
         self._shard, self._n_layers = sh, n_layers
         return sh
+
+    def _upload_layers(self, sh, count_layers, n_layers):
+        for l in range(n_layers):
+            sh.upload(_capi.COUNT1 + l, _dense_f32(count_layers[l]))
+        if self._pseudo_count:
+            sh.add_pseudo_count(self._pseudo_count)
+        # the device copy is reused while the caller keeps passing the SAME array objects (weak references: the
+        # model does not keep the host data alive); arrays modified in place are not detected
+        self._layer_refs = [_weak(c) for c in count_layers[:n_layers]]
+
+    def _same_layers(self, layers):
+        refs = getattr(self, "_layer_refs", None)
+        return refs is not None and len(refs) == len(layers) and all(r is not None and r() is c
+                                                                     for r, c in zip(refs, layers))
 
     def _need(self):
         if self._shard is None:

@@ -38,6 +38,11 @@ def test_BRIE2_fit_matches_oracle_fit(lib):
     np.testing.assert_allclose(float(tot.numpy()), o.eval_loss_gene(cnt, P["Xc"], 2).sum(), rtol=1e-3)
     with pytest.raises(ValueError):
         m.get_loss(P["counts"], target="nonsense")
+    # other data on the fitted model (the reference takes the layers per call, model_TFProb.py:194)
+    other = [np.ascontiguousarray(c[::-1]) for c in P["counts"]]
+    lg2 = m.get_loss(other, axis=0, MC_size=3)
+    np.testing.assert_allclose(lg2.numpy(), o.eval_loss_gene(add_pseudo_count(other), P["Xc"], 3), rtol=2e-3, atol=2e-2)
+    assert np.abs(lg2.numpy() - lg.numpy()).max() > 1.0
     m.close()
 
 

@@ -37,7 +37,7 @@ class BrieProblem(ctypes.Structure):
         ("Kc", ctypes.c_int32), ("Kg", ctypes.c_int32), ("n_layers", ctypes.c_int32),
         ("has_efflen", ctypes.c_int32), ("intercept_mode", ctypes.c_int32),
         ("train_intercept", ctypes.c_int32), ("train_sigma", ctypes.c_int32),
-        ("reserved", ctypes.c_int32), ("seed", ctypes.c_uint64),
+        ("sharded", ctypes.c_int32), ("seed", ctypes.c_uint64),
     ]
 
 

@@ -422,7 +422,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     if (p->Kg < 0) return fail(BRIE_ERR_INVALID, "Kg=%d", p->Kg);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
         return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
-    if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0 && p->reserved == 0)
+    if ((p->Kg > 0 || p->intercept_mode == 1) && p->gene_offset != 0 && p->sharded == 0)
         return fail(BRIE_ERR_UNSUPPORTED, "gene features / cell intercepts couple all genes: a gene shard "
                     "(gene_offset=%lld) must be created with sharded=1 and stepped with brie_step_begin/_end",
                     (long long)p->gene_offset);
@@ -913,7 +913,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (rc != BRIE_OK) return rc;
     if (n_steps < 0 || mc_size < 1) return fail(BRIE_ERR_INVALID, "n_steps=%d mc_size=%d", n_steps, mc_size);
     if (h->step_open) return fail(BRIE_ERR_STATE, "brie_step_begin without brie_step_end");
-    if (split == 0 && h->coupled && h->p.reserved != 0)
+    if (split == 0 && h->coupled && h->p.sharded != 0)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: use brie_step_begin / "
                     "all-reduce brie_rowstat_buffer / brie_step_end");
     if (h->target == 1 && (h->coupled || h->wide))

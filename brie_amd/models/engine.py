@@ -94,6 +94,10 @@ class BRIE2(object):
         if self._shard is not None and self._n_layers == n_layers:
             if not self._same_layers(count_layers[:n_layers]):      # other data on the fitted model (e.g. get_loss)
                 self._upload_layers(self._shard, count_layers, n_layers)
+            if self.Kc > 0 and Xc is not None:                       # design matrices are taken per call as well
+                self._shard.upload(_capi.XC, np.ascontiguousarray(Xc, dtype=np.float32))
+            if self.Kg > 0 and Xg is not None:
+                self._shard.upload(_capi.XG, np.ascontiguousarray(Xg, dtype=np.float32))
             return self._shard
         sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
                          train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,

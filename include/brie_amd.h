@@ -83,7 +83,7 @@ typedef struct brie_problem {
     int32_t intercept_mode;   /* 0 = 'gene' (1,Ng) intercept and sigma; 1 = 'cell' (Nc,1) (model_TFProb.py:53-60) */
     int32_t train_intercept;  /* 1: intercept is a variable clipped to [-9,9] (model_TFProb.py:67-69) */
     int32_t train_sigma;      /* 1: sigma_log is a variable (model_TFProb.py:73-75) */
-    int32_t reserved;         /* "sharded": 1 = this handle is ONE gene shard of a coupled fit (Kg > 0 or cell
+    int32_t sharded;          /* 1 = this handle is ONE gene shard of a coupled fit (Kg > 0 or cell
                                  mode); its per-cell statistics must be all-reduced every step (see below) */
     uint64_t seed;            /* key of the Philox4x32-10 noise stream */
 } brie_problem;

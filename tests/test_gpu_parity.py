@@ -170,6 +170,10 @@ def test_errors_are_loud(lib):
         sh.step(1, 0.01)                 # nothing uploaded yet
     with pytest.raises(ValueError):
         sh.upload(_capi.COUNT1, np.zeros((3, 3), np.float32))
+    with pytest.raises(_capi.BrieError):                   # 2.9 TB of state: allocation fails, nothing leaks, no crash
+        _capi.Shard(300000, 300000)
+    ok = _capi.Shard(8, 8)                                 # the device is still usable afterwards
+    ok.close()
 
 
 @pytest.mark.parametrize("Nc,Ng,Kc", [(1, 1, 0), (3, 5, 1), (2, 257, 0), (700, 4, 2), (5, 1030, 3)])

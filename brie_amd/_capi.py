@@ -25,7 +25,7 @@ EXPORTS = [
     "brie_step_end", "brie_set_gene_mask", "brie_read_loss_window", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
-    "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts",
+    "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts", "brie_device_memory",
     "brie_last_error", "brie_abi_version",
 ]
 
@@ -92,6 +92,7 @@ def load_library(path=None):
     lib.brie_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     lib.brie_set_tiling.argtypes = [vp, i32]
     lib.brie_calibrate_stream.argtypes = [i32, i32, i32, i64, i32, i32, ctypes.POINTER(ctypes.c_double)]
+    lib.brie_device_memory.argtypes = [i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.brie_simulate_psi.argtypes = [i32, i64, i64, i64, ctypes.c_uint64, vp, vp, vp]
     lib.brie_simulate_counts.argtypes = [i32, i64, i64, i64, ctypes.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.brie_step_algorithmic_bytes.argtypes = [vp]
@@ -156,6 +157,23 @@ def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=
     _check(lib, lib.brie_calibrate_stream(int(device), int(n_read), int(n_write), int(bytes_per_stream),
                                           int(iters), int(lds_bytes), ctypes.byref(out)))
     return out.value
+
+
+def device_memory(device=0):
+    """(free, total) HBM bytes of `device`."""
+    lib = load_library()
+    free, total = ctypes.c_int64(), ctypes.c_int64()
+    _check(lib, lib.brie_device_memory(int(device), ctypes.byref(free), ctypes.byref(total)))
+    return free.value, total.value
+
+
+def shard_bytes(Nc, Ng, n_layers, Kc=0):
+    """Upper estimate of the HBM a gene shard needs while it is being set up: state + 4 Adam moments (24 B per
+    element), fp32 count layers before they are compacted, read-back staging, the residual buffer of wide designs,
+    per-chunk partial sums."""
+    ld = -(-int(Ng) // 256) * 256
+    per_elem = 24 + 4 * n_layers + 4 + (4 if Kc > 8 else 0)
+    return int(Nc) * ld * per_elem + (256 << 20)
 
 
 def _f32_matrix(a, shape=None):

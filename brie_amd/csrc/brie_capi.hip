@@ -1331,6 +1331,16 @@ int64_t sim_slab_elems() {
 }
 }  // namespace
 
+int brie_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes) {
+    if (!free_bytes || !total_bytes) return fail(BRIE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    *free_bytes = static_cast<int64_t>(f);
+    *total_bytes = static_cast<int64_t>(t);
+    return BRIE_OK;
+}
+
 int brie_simulate_psi(int32_t device, int64_t Nc, int64_t Ng, int64_t gene_offset, uint64_t seed,
                       const float *mean_logit, const float *sigma, float *psi_out) {
     if (!mean_logit || !sigma || !psi_out) return fail(BRIE_ERR_INVALID, "null argument");

@@ -86,6 +86,11 @@ class BRIE2(object):
             raise NotImplementedError("gene features / cell intercepts couple all genes: a gene shard needs "
                                       "comm= (brie_amd.sharding.GeneComm) for the per-step all-reduce")
 
+    @staticmethod
+    def free_device_memory(device=0):
+        """Free HBM of `device` in bytes (fitBRIE sizes its sequential super-batches with it)."""
+        return _capi.device_memory(device)[0]
+
     # ------------------------------------------------------------------ device state
     def _ensure_shard(self, count_layers, Xc, Xg=None):
         n_layers = len(count_layers)

@@ -164,16 +164,39 @@ def _write_back(adata, res, Xc, Xg, put_layer, LRT_index, params):
     adata.uns['brie_param'] = params
 
 
+def _super_batch_genes(limit, Nc, n_genes, n_layers, Kc, device, n_batch_genes):
+    """Genes per sequential super-batch, or None when the whole range is fitted at once.  'auto': as many genes as
+    fit into 90 % of the free HBM; always a multiple of the convergence batch and of 256 (one gene block)."""
+    from .. import _capi
+    unit = int(np.lcm(256, max(1, n_batch_genes)))
+    if limit is None:
+        return None
+    if isinstance(limit, str):
+        if limit.lower() != 'auto':
+            raise ValueError("max_genes_per_fit=%r" % (limit,))
+        free = BRIE2.free_device_memory(device)
+        if _capi.shard_bytes(Nc, n_genes, n_layers, Kc) <= 0.9 * free:
+            return None
+        per_unit = _capi.shard_bytes(Nc, unit, n_layers, Kc) - (256 << 20)
+        limit = int(max(1, (0.9 * free - (256 << 20)) // per_unit)) * unit
+    limit = int(limit)
+    if limit >= n_genes:
+        return None
+    return max(unit, limit // unit * unit) if limit >= unit else max(4, limit // 4 * 4)
+
+
 def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_index=[],
             layer_keys=['isoform1', 'isoform2', 'ambiguous'], batch_size=500000,
             pseudo_count=0.01, sigma=None, base_mode='full', tau_prior=[3, 27],
-            seed=0, device=0, emulate_batches=False, comm=None, gather_layers=True, **keyargs):
+            seed=0, device=0, emulate_batches=False, comm=None, gather_layers=True, max_genes_per_fit='auto',
+            **keyargs):
     """Fit a BRIE model from an AnnData-like object and write the results back (model_wrap.py:202-314).
 
     `adata` needs `.shape`, `.layers`, `.varm`, `.obsm`, `.var`, `.uns` (anndata.AnnData,
     brie_amd.io.CountData, or any duck-typed stand-in).  New optional arguments: seed, device,
     emulate_batches, comm (a `brie_amd.sharding.GeneComm`: one process per GPU, genes sharded over
-    ranks), gather_layers.
+    ranks), gather_layers, max_genes_per_fit ('auto': a gene range that does not fit into the free HBM of the
+    device is fitted as sequential super-batches -- what the reference's batch_size does for 500k elements).
     """
     Nc, Ng = adata.shape[0], adata.shape[1]
     Xc = np.ones((Nc, 0), np.float32) if Xc is None else Xc
@@ -203,6 +226,10 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
         keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
 
     n_batch_genes = int(np.ceil(batch_size / Nc))                     # model_wrap.py:242
+    super_batch = None
+    if separable and not emulate_batches:
+        super_batch = _super_batch_genes(max_genes_per_fit, Nc, g_hi - g_lo, len(layer_keys), Xc.shape[1], device,
+                                         n_batch_genes)
     if separable and emulate_batches:                                 # the literal loop of model_wrap.py:244-260
         step = max(4, (n_batch_genes + 3) // 4 * 4)                   # the noise stream is keyed per gene quad
         parts = []
@@ -214,7 +241,16 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
         if separable and 'conv_batch_genes' not in keyargs:
             # all genes at once, but each reference-sized batch still stops on its own loss window
             keyargs = dict(keyargs, conv_batch_genes=n_batch_genes)
-        ResVal = fit_range(g_lo, g_hi, seed)
+        if super_batch is None:
+            ResVal = fit_range(g_lo, g_hi, seed)
+        else:                                                         # larger than the device: sequential super-batches
+            parts = []
+            for g0 in range(g_lo, g_hi, super_batch):
+                parts.append(fit_range(g0, min(g0 + super_batch, g_hi), seed))
+                print("[BRIE2] %d out %d genes done" % (min(g0 + super_batch, g_hi), Ng))
+            ResVal = concate(parts)
+            if hasattr(ResVal, 'pval'):          # one Benjamini-Hochberg pass over all genes, as in the unsplit fit
+                ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
 
     ResVal.gene_range = (g_lo, g_hi)
     if sharded:                                                       # RCCL all-gather of the per-gene vectors

@@ -205,6 +205,11 @@ int brie_get_count_storage(const brie_handle *h);
 int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream,
                           int32_t iters, int32_t lds_bytes_per_block, double *gbps);
 
+/* Free / total HBM of a device in bytes (hipMemGetInfo).  fitBRIE uses it to split a gene range that does not
+ * fit into sequential super-batches -- the role of the reference's batch_size (model_wrap.py:241-260), sized for
+ * 288 GB instead of for 500k elements. */
+int brie_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
+
 /* Count simulator -- brie/models/simulator.py:7-75.  Stateless; every array is C-order (Nc, Ng) fp32 in host or
  * device memory (copied through HBM in row slabs), genes are addressed globally (gene_offset) so a gene shard
  * simulates exactly its columns of the whole matrix.  All draws come from the library's Philox stream keyed by

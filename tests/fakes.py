@@ -45,6 +45,10 @@ class OracleBackedBRIE2(object):
                               gene_offset=gene_offset, dtype=np.float32, Kg=Kg, intercept_mode=intercept_mode)
         OracleBackedBRIE2.instances.append(self)
 
+    @staticmethod
+    def free_device_memory(device=0):
+        return 1 << 62
+
     def fit(self, count_layers, Xc=None, Xg=None, min_iter=1000, max_iter=5000, add_iter=500,
             epsilon_conv=1e-2, verbose=True, n_loss_gene=500, pseudo_count=None, MC_size=1,
             trace_reduce=None, conv_batch_genes=None, **kw):

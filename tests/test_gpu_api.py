@@ -175,3 +175,23 @@ def test_fitBRIE_per_batch_convergence_matches_oracle_backed_run(lib, monkeypatc
     if len(res.losses) == len(ref.losses):
         d = np.abs(res.Psi - ref.Psi)
         assert np.percentile(d, 99) < 2e-4
+
+
+def test_fitBRIE_super_batches_on_gpu(lib):
+    """A gene range larger than the device is fitted as sequential super-batches (whole gene blocks); per-gene
+    results equal the unsplit fit bit for bit, and 'auto' leaves a problem that fits alone."""
+    import brie_amd
+    import brie_amd.models.wrap as wrap
+    Nc, Ng = 40, 700
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=14)
+    mk = lambda: FakeAnnData({'isoform1': P["counts"][0].copy(), 'isoform2': P["counts"][1].copy()})
+    kw = dict(Xc=P["Xc"], LRT_index=[0], min_iter=120, max_iter=120, n_loss_gene=4, seed=5, verbose=False)
+    whole = brie_amd.fitBRIE(mk(), **kw)                               # max_genes_per_fit='auto': fits
+    ad = mk()
+    split = brie_amd.fitBRIE(ad, max_genes_per_fit=300, **kw)          # -> 256-gene super-batches: 256 + 256 + 188
+    for key in ("Psi", "Psi95CI", "Z_std", "cell_coeff", "sigma", "intercept", "loss_gene", "ELBO_gain", "pval", "fdr"):
+        np.testing.assert_array_equal(getattr(split, key), getattr(whole, key), err_msg=key)
+    assert ad.layers['Psi'].shape == (Nc, Ng) and len(split.losses) == 3 * len(whole.losses)
+    free, total = brie_amd._capi.device_memory(0)
+    assert 0 < free <= total and total > (100 << 30)
+    assert wrap._super_batch_genes('auto', Nc, Ng, 2, 1, 0, 12500) is None

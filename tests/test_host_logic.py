@@ -154,6 +154,51 @@ def test_fitBRIE_emulated_batches_equal_whole_fit(patched_wrap):
     assert len(batched.losses) == 3 * len(whole.losses)                     # traces concatenated (model_wrap.py:61)
 
 
+def test_super_batch_sizing():
+    """Ranges larger than the device are fitted as sequential super-batches: whole gene blocks (256) and whole
+    convergence batches, as many as fit into 90 % of the free HBM."""
+    import brie_amd.models.wrap as wrap
+    from brie_amd import _capi
+
+    class Mem(object):
+        free = 0
+
+        @staticmethod
+        def free_device_memory(device=0):
+            return Mem.free
+    saved = wrap.BRIE2
+    wrap.BRIE2 = Mem
+    try:
+        Nc, Ng = 50000, 20000
+        Mem.free = 288 << 30
+        assert wrap._super_batch_genes('auto', Nc, Ng, 2, 3, 0, 10) is None              # C3 fits an MI355X whole
+        Mem.free = 24 << 30                                                              # a 24 GB card would not
+        sb = wrap._super_batch_genes('auto', Nc, Ng, 2, 3, 0, 10)
+        assert sb % 1280 == 0 and 0 < sb < Ng                                            # lcm(256, 10)
+        assert _capi.shard_bytes(Nc, sb, 2, 3) <= 0.9 * Mem.free < _capi.shard_bytes(Nc, sb + 1280, 2, 3)
+        assert wrap._super_batch_genes(None, Nc, Ng, 2, 3, 0, 10) is None
+        assert wrap._super_batch_genes(5000, Nc, Ng, 2, 3, 0, 10) == 3840                # explicit limit, rounded down
+        assert wrap._super_batch_genes(100, Nc, Ng, 2, 3, 0, 10) == 100                  # below one unit: multiples of 4
+        assert wrap._super_batch_genes(50000, Nc, Ng, 2, 3, 0, 10) is None
+        with pytest.raises(ValueError):
+            wrap._super_batch_genes('sometimes', Nc, Ng, 2, 3, 0, 10)
+    finally:
+        wrap.BRIE2 = saved
+
+
+def test_fitBRIE_super_batches_equal_whole_fit(patched_wrap):
+    Nc, Ng = 25, 24
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=8)
+    mk = lambda: FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    whole = patched_wrap.fitBRIE(mk(), Xc=P["Xc"], LRT_index=[0], **FIT)
+    n0 = len(OracleBackedBRIE2.instances)
+    split = patched_wrap.fitBRIE(mk(), Xc=P["Xc"], LRT_index=[0], max_genes_per_fit=8, **FIT)
+    assert len(OracleBackedBRIE2.instances) - n0 == 3 * 2                               # 3 super-batches x (base + test)
+    np.testing.assert_allclose(split.Psi, whole.Psi, atol=2e-6)
+    np.testing.assert_allclose(split.ELBO_gain, whole.ELBO_gain, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(split.fdr, whole.fdr, rtol=1e-3, atol=1e-6)           # BH over all genes, not per part
+
+
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):

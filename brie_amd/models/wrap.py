@@ -222,6 +222,9 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
         # per-cell statistics every step (brie_step_begin/_end).  The loss trace is summed over ranks so that
         # every rank takes the same convergence decisions.
         from ..sharding import gene_shard
+        if gene_shard(Ng, comm.world - 1, comm.world)[0] >= Ng:
+            raise ValueError("%d genes cannot be sharded over %d ranks (a rank would be empty): use fewer GPUs"
+                             % (Ng, comm.world))
         g_lo, g_hi = gene_shard(Ng, comm.rank, comm.world)
         keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
 

@@ -199,6 +199,15 @@ def test_fitBRIE_super_batches_equal_whole_fit(patched_wrap):
     np.testing.assert_allclose(split.fdr, whole.fdr, rtol=1e-3, atol=1e-6)           # BH over all genes, not per part
 
 
+def test_more_ranks_than_gene_quads_is_refused(patched_wrap):
+    class Comm(object):
+        rank, world = 0, 8
+    P = make_problem(10, 8, Kc=0, L=2, seed=1)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    with pytest.raises(ValueError, match="cannot be sharded"):
+        patched_wrap.fitBRIE(ad, comm=Comm(), **FIT)
+
+
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):

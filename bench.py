@@ -192,8 +192,10 @@ def main():
         sh.upload(_capi.EFFLEN, eff_all.cpu().numpy())
     if Kc:
         sh.upload(_capi.XC, Xc)
-    sample_layers = [layers[l][:, :min(ng, 64)].cpu().numpy() for l in range(L)] if rank == 0 else None
-    eff_host = eff_all[:min(ng, 64)].cpu().numpy() if (L == 3 and rank == 0) else None
+    # host sample for the CPU baselines: three reference-sized gene batches (model_wrap.py:242), at least 64 genes
+    n_keep = min(ng, max(64, 3 * min(int(math.ceil(500000 / float(Nc))), Ng)))
+    sample_layers = [layers[l][:, :n_keep].cpu().numpy() for l in range(L)] if rank == 0 else None
+    eff_host = eff_all[:n_keep].cpu().numpy() if (L == 3 and rank == 0) else None
     # one gene quad in the middle of the shard: the oracle re-runs it over ALL cells after the timed region
     q0 = (ng // 2) // 4 * 4
     quad_layers = [layers[l][:, q0:q0 + 4].cpu().numpy() for l in range(L)] if rank == 0 else None
@@ -301,7 +303,7 @@ def main():
             from oracle.brie_oracle_torch import time_reference_shape
             import torch as _t
             cores = min(6, os.cpu_count() or 1)          # reference default --nproc 6 (bin/quant.py:183)
-            n_gene = int(math.ceil(500000 / float(Nc)))
+            n_gene = min(int(math.ceil(500000 / float(Nc))), sample_layers[0].shape[1])
             nb = max(1, min(3, sample_layers[0].shape[1] // n_gene))
 
             def counts_fn(a, b):

@@ -141,7 +141,7 @@ class TorchBRIE2(object):
         for _ in range(num_steps):
             loss = self.get_loss(count_layers, None, MC_size)
             grads = torch.autograd.grad(loss, vs)
-            trace.append(float(loss))
+            trace.append(float(loss.detach()))
             opt['t'] += 1
             t = opt['t']
             alpha = opt['lr'] * math.sqrt(1 - ADAM_B2 ** t) / (1 - ADAM_B1 ** t)

@@ -38,6 +38,8 @@ _OPTIONS = [
     ("--pseudoCount", None, "pseudo_count", float, 0.01, "added to both isoform-specific layers where they have reads"),
     ("--nproc", "-p", "nproc", int, 6, "ignored (CPU threads of the TensorFlow reference)"),
     ("--seed", None, "seed", int, 0, "seed of the noise stream"),
+    ("--commonNoise", None, "common_noise", int, 0, "1: base and test fits of the LRT share the noise stream "
+                                                     "(common random numbers: far less Monte-Carlo error in ELBO_gain)"),
     ("--device", None, "device", int, None, "GPU ordinal [default: LOCAL_RANK or 0]"),
 ]
 
@@ -157,7 +159,8 @@ def main(argv=None):
     quant(opt.in_file, opt.cell_file, opt.gene_file, opt.out_file, parse_lrt_index(opt.LRT_index),
           opt.layers.split(','), intercept, opt.intercept_mode, opt.nproc, opt.min_count, opt.min_uniq_count,
           opt.min_cell, opt.min_MIF, opt.min_iter, opt.max_iter, opt.MC_size, opt.batch_size,
-          opt.pseudo_count, opt.test_base, seed=opt.seed, device=device, comm=comm)
+          opt.pseudo_count, opt.test_base, seed=opt.seed, device=device, comm=comm,
+          common_noise=bool(opt.common_noise))
     if comm is not None:
         import torch.distributed as dist
         dist.barrier()

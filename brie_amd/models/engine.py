@@ -232,7 +232,8 @@ class BRIE2(object):
     # ------------------------------------------------------------------ fit (model_TFProb.py:214-273)
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
-            n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, **kwargs):
+            n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, loss_gene_draw=None,
+            **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
@@ -300,6 +301,8 @@ class BRIE2(object):
             n_iter += add_iter
             losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])
 
+        if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
+            sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
         self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
         self.losses = _wrap(losses)
         self.n_iter = n_iter

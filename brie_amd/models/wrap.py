@@ -16,6 +16,7 @@ from .engine import BRIE2
 from ..stats import elbo_gain_pval, fdr_bh
 
 verbosity = 3      # brie/settings.py:4
+_COMMON_LOSS_DRAW = 0xE0000000      # draw ids of the shared loss_gene evaluation (far above any step counter)
 
 #: result attribute <- model attribute (model_wrap.py:28-38)
 _RV_FIELDS = (("sigma", "sigma"), ("intercept", "intercept"), ("cell_coeff", "Wc_loc"), ("gene_coeff", "Wg_loc"),
@@ -80,8 +81,13 @@ def _design_for_base(Xc, LRT_index, base_mode, Nc):
 
 def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, intercept_mode='gene',
                     LRT_index=None, pseudo_count=0.01, sigma=None, base_mode='full',
-                    tau_prior=[3, 27], seed=0, device=0, gene_offset=0, comm=None, **keyargs):
+                    tau_prior=[3, 27], seed=0, device=0, gene_offset=0, comm=None, common_noise=False, **keyargs):
     """Fit a BRIE model with cell / gene features on count matrices (model_wrap.py:88-199).
+
+    common_noise : False = the base and the test models draw independent noise, like the (unseeded) reference.
+                   True  = all models of the test share the seed and evaluate their final 500-draw `loss_gene` on the
+                   same stretch of the noise stream, so the Monte-Carlo error largely cancels in ELBO_gain
+                   (common random numbers; only possible because the noise here is counter-based).
 
     data : list of 2 or 3 (Nc, Ng) matrices (ndarray, scipy sparse, or torch tensors already in HBM)
     Xc   : (Nc, Kc) float32 cell features;  Xg : (Ng, Kg) float32 gene features
@@ -99,8 +105,12 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
         mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=design.shape[1], Kg=Xg.shape[1], effLen=effLen, intercept=intercept,
                     intercept_mode=mode, sigma=sigma, tau_prior=tau_prior, seed=fit_seed, device=device,
                     gene_offset=gene_offset, comm=comm)
-        mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **keyargs)
+        mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **fit_args)
         return mdl
+
+    fit_args = dict(keyargs)
+    if common_noise:
+        fit_args.setdefault('loss_gene_draw', _COMMON_LOSS_DRAW)
 
     base = run(Xc_base, seed)
     result = BRIE_RV(base)
@@ -121,7 +131,7 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
         design = np.delete(Xc, feat, 1) if full_base else np.append(Xc_base, Xc[:, feat:(feat + 1)], axis=1)
         # the reference builds these models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always with
         # the 'gene' default, whatever the base model uses -- mirrored
-        other = run(design, seed + 1 + col, mode='gene')
+        other = run(design, seed if common_noise else seed + 1 + col, mode='gene')
         other_loss = _host(other.loss_gene)
         if full_base:
             gain[:, col] = other_loss - result.loss_gene

@@ -195,3 +195,25 @@ def test_fitBRIE_super_batches_on_gpu(lib):
     free, total = brie_amd._capi.device_memory(0)
     assert 0 < free <= total and total > (100 << 30)
     assert wrap._super_batch_genes('auto', Nc, Ng, 2, 1, 0, 12500) is None
+
+
+def test_common_noise_reduces_the_monte_carlo_error_of_ELBO_gain(lib):
+    """fit_BRIE_matrix(common_noise=True): base and test model share seed and loss_gene draws, so for genes WITHOUT an
+    effect the ELBO gain (model_wrap.py:155-187) is no longer dominated by the independent Monte-Carlo errors of two
+    500-draw (here 40-draw) averages."""
+    import brie_amd
+    Nc, Ng = 1500, 64
+    rng = np.random.default_rng(5)
+    Xc = np.stack([(rng.random(Nc) < 0.5).astype(np.float32), rng.standard_normal(Nc).astype(np.float32)], axis=1)
+    z = rng.normal(0, 1.5, (1, Ng)) + rng.normal(0, 1.0, (Nc, Ng))                 # no dependence on Xc at all
+    psi = 1 / (1 + np.exp(-z))
+    depth = rng.poisson(6.0, (Nc, Ng))
+    c1 = rng.binomial(depth, psi).astype(np.float32)
+    data = [c1, (depth - c1).astype(np.float32)]
+    kw = dict(Xc=Xc, LRT_index=[0], min_iter=1500, max_iter=1500, n_loss_gene=40, seed=2, verbose=False)
+    indep = brie_amd.fit_BRIE_matrix(data, **kw)
+    common = brie_amd.fit_BRIE_matrix(data, common_noise=True, **kw)
+    s_i, s_c = np.std(indep.ELBO_gain[:, 0]), np.std(common.ELBO_gain[:, 0])
+    print("std of ELBO_gain on null genes: independent %.3f, common noise %.3f" % (s_i, s_c))
+    assert s_c < 0.5 * s_i
+    np.testing.assert_allclose(common.cell_coeff, indep.cell_coeff, atol=0.2)       # same model, same estimates

@@ -233,7 +233,7 @@ class BRIE2(object):
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
             n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, loss_gene_draw=None,
-            **kwargs):
+            n_iter_schedule=None, **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
@@ -243,6 +243,9 @@ class BRIE2(object):
         (model_TFProb.py:247-258).  conv_batch_genes=n (set by fitBRIE to ceil(batch_size/Nc)): every
         batch of n consecutive genes is one of the reference's sequential fits (model_wrap.py:241-260)
         and stops on its own windowed loss; stopped batches are frozen on the device.
+        n_iter_schedule: iteration counts of an earlier fit (its `n_iter_batch`, or `[n_iter]`) to be repeated
+        instead of taking new convergence decisions -- the companion fits of a common-noise LRT stop where the base
+        model stopped, so both evaluate the same stretch of the noise stream.
         """
         start_time = time.time()
         if target not in ("ELBO", "marginLik"):
@@ -268,6 +271,7 @@ class BRIE2(object):
                 trace = np.asarray(trace_reduce(trace), np.float32)
             return trace
 
+        self.n_iter_batch = None
         losses = np.zeros(0, np.float32)
         for i in range(6):                                           # model_TFProb.py:235-241
             sh.reset_optimizer()                                     # fresh Adam per stage
@@ -281,8 +285,11 @@ class BRIE2(object):
             batch_on = np.ones(len(starts), bool)
             self.n_iter_batch = np.full(len(starts), n_iter)
             while n_iter < max_iter and len(losses) >= d2 and 0 < d2 <= 128:
-                win = np.add.reduceat(sh.read_loss_window(d2).astype(np.float64), starts, axis=1).astype(np.float32)
-                batch_on &= (win[:d1].mean(0) - win[d1:].mean(0)) > epsilon_conv      # per batch, model_TFProb.py:250
+                if n_iter_schedule is not None and len(n_iter_schedule) == len(starts):
+                    batch_on &= np.asarray(n_iter_schedule) > n_iter                  # repeat the earlier fit's stops
+                else:
+                    win = np.add.reduceat(sh.read_loss_window(d2).astype(np.float64), starts, axis=1).astype(np.float32)
+                    batch_on &= (win[:d1].mean(0) - win[d1:].mean(0)) > epsilon_conv  # per batch, model_TFProb.py:250
                 n_on = int(batch_on.sum())
                 if trace_reduce is not None:                         # gene shards: stop when no rank has work left
                     n_on = int(round(float(np.asarray(trace_reduce(np.array([float(n_on)])))[0])))
@@ -296,8 +303,10 @@ class BRIE2(object):
             conv_batch_genes = True
         else:
             conv_batch_genes = False
-        while (not conv_batch_genes and len(losses) >= d2 and d1 > 0 and
-               losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv and n_iter < max_iter):
+        repeat_to = None if (n_iter_schedule is None or conv_batch_genes) else int(np.max(n_iter_schedule))
+        while (not conv_batch_genes and n_iter < max_iter and
+               (n_iter < repeat_to if repeat_to is not None else
+                (len(losses) >= d2 and d1 > 0 and losses[-d2:-d1].mean() - losses[-d1:].mean() > epsilon_conv))):
             n_iter += add_iter
             losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])
 

@@ -101,11 +101,11 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     full_base = base_mode.upper() == 'FULL'
     Xc_base = _design_for_base(Xc, LRT_index, base_mode, Nc)
 
-    def run(design, fit_seed, mode=intercept_mode):
+    def run(design, fit_seed, mode=intercept_mode, **extra):
         mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=design.shape[1], Kg=Xg.shape[1], effLen=effLen, intercept=intercept,
                     intercept_mode=mode, sigma=sigma, tau_prior=tau_prior, seed=fit_seed, device=device,
                     gene_offset=gene_offset, comm=comm)
-        mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **fit_args)
+        mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **dict(fit_args, **extra))
         return mdl
 
     fit_args = dict(keyargs)
@@ -114,6 +114,12 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
 
     base = run(Xc_base, seed)
     result = BRIE_RV(base)
+    # common noise: the companion fits repeat the base model's stopping times (per batch, or the global one), so that
+    # every model has consumed the same stretch of the noise stream when its loss is evaluated
+    repeat = {}
+    if common_noise:
+        sched = getattr(base, 'n_iter_batch', None)
+        repeat = dict(n_iter_schedule=np.asarray(sched if sched is not None else [getattr(base, 'n_iter', 0)]))
     base.close()
 
     tested = np.arange(Xc.shape[1]) if LRT_index is None else LRT_index            # model_wrap.py:149-153
@@ -131,7 +137,7 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
         design = np.delete(Xc, feat, 1) if full_base else np.append(Xc_base, Xc[:, feat:(feat + 1)], axis=1)
         # the reference builds these models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always with
         # the 'gene' default, whatever the base model uses -- mirrored
-        other = run(design, seed if common_noise else seed + 1 + col, mode='gene')
+        other = run(design, seed if common_noise else seed + 1 + col, mode='gene', **repeat)
         other_loss = _host(other.loss_gene)
         if full_base:
             gain[:, col] = other_loss - result.loss_gene

@@ -217,3 +217,22 @@ def test_common_noise_reduces_the_monte_carlo_error_of_ELBO_gain(lib):
     print("std of ELBO_gain on null genes: independent %.3f, common noise %.3f" % (s_i, s_c))
     assert s_c < 0.5 * s_i
     np.testing.assert_allclose(common.cell_coeff, indep.cell_coeff, atol=0.2)       # same model, same estimates
+
+
+def test_n_iter_schedule_repeats_an_earlier_fit(lib):
+    import brie_amd
+    Nc, Ng = 80, 48
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=23)
+    kw = dict(Xc=P["Xc"], min_iter=300, max_iter=700, add_iter=40, epsilon_conv=0.3, n_loss_gene=3,
+              pseudo_count=0.01, verbose=False, conv_batch_genes=8)
+    a = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=1)
+    a.fit(P["counts"], **kw)
+    assert len(set(a.n_iter_batch)) > 1                                   # batches stopped at different times
+    b = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=9)                              # other noise: own decisions would differ
+    b.fit(P["counts"], n_iter_schedule=a.n_iter_batch, **dict(kw, epsilon_conv=-1e9))
+    np.testing.assert_array_equal(b.n_iter_batch, a.n_iter_batch)
+    c = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=9)                              # global rule: run exactly as long as `a`
+    c.fit(P["counts"], n_iter_schedule=[a.n_iter], **dict(kw, conv_batch_genes=None, epsilon_conv=1e9))
+    assert c.n_iter == a.n_iter and c.n_iter_batch is None
+    for m in (a, b, c):
+        m.close()

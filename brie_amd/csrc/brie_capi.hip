@@ -31,9 +31,11 @@ int fail(int code, const char *fmt, ...) {
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
-        if (_e != hipSuccess)                                                              \
+        if (_e != hipSuccess) {                                                            \
+            (void)hipGetLastError(); /* reported here: do not leave it behind as a stale "last error" */ \
             return fail(BRIE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                         __FILE__, __LINE__);                                               \
+        }                                                                                  \
     } while (0)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

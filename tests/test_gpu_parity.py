@@ -172,7 +172,11 @@ def test_errors_are_loud(lib):
         sh.upload(_capi.COUNT1, np.zeros((3, 3), np.float32))
     with pytest.raises(_capi.BrieError):                   # 2.9 TB of state: allocation fails, nothing leaks, no crash
         _capi.Shard(300000, 300000)
-    ok = _capi.Shard(8, 8)                                 # the device is still usable afterwards
+    ok = _capi.Shard(8, 8)                                 # the device is still usable afterwards, and the failed
+    for l in range(2):                                     # hipMalloc is not reported again by a later call
+        ok.upload(_capi.COUNT1 + l, np.ones((8, 8), np.float32))
+    ok.init_state()
+    assert np.isfinite(ok.step(2, 0.01, 1)).all()
     ok.close()
 
 

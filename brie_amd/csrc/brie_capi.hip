@@ -25,17 +25,18 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_last_error = buf;
+    // a HIP failure is reported through this return value: do not leave it behind as the runtime's sticky
+    // "last error", where the next hipGetLastError() check of an unrelated call would find it
+    if (code == BRIE_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \
-        if (_e != hipSuccess) {                                                            \
-            (void)hipGetLastError(); /* reported here: do not leave it behind as a stale "last error" */ \
+        if (_e != hipSuccess)                                                              \
             return fail(BRIE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                         __FILE__, __LINE__);                                               \
-        }                                                                                  \
     } while (0)
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

@@ -1,0 +1,60 @@
+/* Plain-C client of include/brie_amd.h: proves the boundary needs nothing but a C compiler.
+ * Fits a tiny problem (counts drawn with a fixed LCG), prints the loss trace and a checksum of Psi.
+ * Build:  gcc tests/c_abi/smoke.c -Iinclude -Lbrie_amd/lib -lbrie_amd -Wl,-rpath,$PWD/brie_amd/lib -lm -o smoke
+ * (tests/test_c_abi.py compiles it on CPU and runs it on the GPU box) */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "brie_amd.h"
+
+#define CHECK(call)                                                            \
+    do {                                                                       \
+        int rc_ = (call);                                                      \
+        if (rc_ != BRIE_OK) {                                                  \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, brie_last_error()); \
+            return 1;                                                          \
+        }                                                                      \
+    } while (0)
+
+int main(void) {
+    enum { NC = 96, NG = 300, KC = 2, STEPS = 40 };
+    static float c1[NC * NG], c2[NC * NG], xc[NC * KC], psi[NC * NG], trace[STEPS], lg[NG];
+    unsigned long long s = 88172645463325252ULL;
+    for (int i = 0; i < NC * NG; ++i) {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        c1[i] = (float)((s >> 33) % 7);
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        c2[i] = (float)((s >> 33) % 5);
+    }
+    for (int i = 0; i < NC; ++i) { xc[i * KC] = (float)(i & 1); xc[i * KC + 1] = (float)sin(0.37 * i); }
+
+    brie_problem p;
+    memset(&p, 0, sizeof p);
+    p.abi_version = BRIE_AMD_ABI_VERSION;
+    p.Nc = NC; p.Ng = NG; p.Kc = KC; p.n_layers = 2;
+    p.train_intercept = 1; p.train_sigma = 1; p.seed = 2024;
+    brie_handle *h = NULL;
+    if (brie_abi_version() != BRIE_AMD_ABI_VERSION) { fprintf(stderr, "ABI mismatch\n"); return 1; }
+    CHECK(brie_create(&p, &h));
+    CHECK(brie_upload(h, BRIE_COUNT1, c1, NC, NG, NG));
+    CHECK(brie_upload(h, BRIE_COUNT2, c2, NC, NG, NG));
+    CHECK(brie_add_pseudo_count(h, 0.01f));
+    CHECK(brie_upload(h, BRIE_XC, xc, NC, KC, KC));
+    CHECK(brie_init_state(h, NAN, NAN));
+    CHECK(brie_reset_optimizer(h));
+    CHECK(brie_step(h, STEPS, 0.02f, 1, trace));
+    CHECK(brie_loss_gene(h, 5, lg));
+    CHECK(brie_read(h, BRIE_PSI, psi, NC, NG, NG));
+    double sum = 0.0;
+    for (int i = 0; i < NC * NG; ++i) {
+        if (!(psi[i] > 0.0f && psi[i] < 1.0f)) { fprintf(stderr, "psi[%d] = %g\n", i, psi[i]); return 1; }
+        sum += psi[i];
+    }
+    if (brie_step(h, 1, 0.02f, 0, NULL) == BRIE_OK) { fprintf(stderr, "mc_size 0 accepted\n"); return 1; }
+    printf("loss %.3f -> %.3f  mean_psi %.6f  loss_gene0 %.3f  last_error \"%s\"\n", trace[0], trace[STEPS - 1],
+           sum / (NC * NG), lg[0], brie_last_error());
+    CHECK(brie_destroy(h));
+    return trace[STEPS - 1] < trace[0] ? 0 : 1;
+}

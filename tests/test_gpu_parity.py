@@ -619,3 +619,30 @@ def test_randomised_operation_sequences(lib, i, Nc, Ng, Kc, L, sparse, f32, ops)
     assert_states_close(util.oracle_state(o), util.device_state(sh))
     np.testing.assert_array_equal(sh.read(_capi.COUNT1), P["counts_pc"][0])
     sh.close()
+
+
+def test_distinct_handles_are_independent_across_threads(lib):
+    """include/brie_amd.h: a handle is not thread-safe, distinct handles are.  Four host threads drive four shards
+    (own HIP streams) at the same time; every result equals the same fit run alone."""
+    import threading
+    from brie_amd import _capi
+    Nc, Ng, Kc = 70, 300, 2
+    P = util.problem(Nc, Ng, Kc, 2, seed=91)
+
+    def fit(seed, out, slot):
+        sh = util.device_shard(P, Nc, Ng, Kc, seed)
+        tr = [sh.step(5, 0.01, 1) for _ in range(6)]
+        out[slot] = (np.concatenate(tr), sh.read(_capi.Z_LOC), sh.loss_gene(3))
+        sh.close()
+
+    alone, together = {}, {}
+    for k in range(4):
+        fit(100 + k, alone, k)
+    threads = [threading.Thread(target=fit, args=(100 + k, together, k)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k in range(4):
+        for a, b in zip(alone[k], together[k]):
+            np.testing.assert_array_equal(a, b)

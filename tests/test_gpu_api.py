@@ -236,3 +236,32 @@ def test_n_iter_schedule_repeats_an_earlier_fit(lib):
     assert c.n_iter == a.n_iter and c.n_iter_batch is None
     for m in (a, b, c):
         m.close()
+
+
+def test_count_layers_in_any_container_give_the_same_fit(lib):
+    """model_wrap.py:108-111 accepts whatever `.toarray()` / np.asarray understand; so does the upload path: integer
+    and float64 arrays, Fortran order, scipy COO / CSR, torch tensors on the host -- all bit-identical fits."""
+    import torch
+    import brie_amd
+    Nc, Ng = 50, 90
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=6)
+    variants = {
+        "float32": lambda c: c,
+        "int32": lambda c: c.astype(np.int32),
+        "float64_fortran": lambda c: np.asfortranarray(c.astype(np.float64)),
+        "coo": lambda c: sp.coo_matrix(c),
+        "csr": lambda c: sp.csr_matrix(c),
+        "torch_cpu": lambda c: torch.from_numpy(c.copy()),
+        "strided_view": lambda c: np.concatenate([c, c], axis=1)[:, :Ng],
+    }
+    ref = None
+    for name, conv in variants.items():
+        m = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=4)
+        m.fit([conv(c) for c in P["counts"]], Xc=P["Xc"], min_iter=60, max_iter=60, n_loss_gene=2, pseudo_count=0.01,
+              verbose=False)
+        got = (m.Psi.numpy(), m.loss_gene.numpy(), m.losses.numpy())
+        m.close()
+        if ref is None:
+            ref = got
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b, err_msg=name)

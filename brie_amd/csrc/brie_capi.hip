@@ -209,7 +209,6 @@ int grid_1d(int64_t n);
 int try_compact_counts(brie_handle *h) {
     if (h->compact_tried) return BRIE_OK;
     h->compact_tried = true;
-    if (!h->allow_compact || !h->tiled) return BRIE_OK;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
     int *flag = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int)));
@@ -221,7 +220,11 @@ int try_compact_counts(brie_handle *h) {
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(flag);
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "count range check: %s", hipGetErrorString(e));
-    if (bits & 1) return BRIE_OK;                 // fractional / negative / huge: stay fp32
+    if (bits & 4) {                               // the reference would silently produce NaN posteriors
+        h->compact_tried = false;                 // checked again (and refused again) on the next attempt
+        return fail(BRIE_ERR_INVALID, "count layers contain negative or non-finite values");
+    }
+    if ((bits & 1) || !h->allow_compact || !h->tiled) return BRIE_OK;     // fractional / huge: stay fp32
     const int cs = (bits & 2) ? brie::kCountU16 : brie::kCountU8;
     const size_t bytes = static_cast<size_t>(n) * (cs == brie::kCountU16 ? 2 : 1);
     for (int l = 0; l < h->p.n_layers; ++l) {

@@ -1375,6 +1375,7 @@ __global__ void count_range_check(const float *c, int64_t n4, int *flag) {
         for (int v = 0; v < kVec; ++v) {
             bad |= !(a.v[v] >= 0.0f && a.v[v] <= 65535.0f && a.v[v] == truncf(a.v[v]));
             bad |= (a.v[v] > 255.0f) ? 2 : 0;
+            bad |= !(a.v[v] >= 0.0f && a.v[v] < __builtin_inff()) ? 4 : 0;      // negative, NaN or inf: not a count
         }
     }
     if (bad) atomicOr(flag, bad);

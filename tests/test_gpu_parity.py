@@ -170,6 +170,17 @@ def test_errors_are_loud(lib):
         sh.step(1, 0.01)                 # nothing uploaded yet
     with pytest.raises(ValueError):
         sh.upload(_capi.COUNT1, np.zeros((3, 3), np.float32))
+    for bad_value in (-1.0, np.nan, np.inf):               # not counts: refused instead of NaN posteriors
+        bad = _capi.Shard(6, 8)
+        layer = np.ones((6, 8), np.float32)
+        layer[3, 5] = bad_value
+        bad.upload(_capi.COUNT1, layer)
+        bad.upload(_capi.COUNT2, np.ones((6, 8), np.float32))
+        bad.init_state()
+        for _ in range(2):
+            with pytest.raises(ValueError, match="negative or non-finite"):
+                bad.step(1, 0.01, 1)
+        bad.close()
     with pytest.raises(_capi.BrieError):                   # 2.9 TB of state: allocation fails, nothing leaks, no crash
         _capi.Shard(300000, 300000)
     ok = _capi.Shard(8, 8)                                 # the device is still usable afterwards, and the failed

@@ -129,6 +129,9 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     # ELBO gain per tested feature, in analogy to a likelihood ratio (model_wrap.py:155-187):
     # 'full' base: refit WITHOUT the feature, gain = loss(reduced) - loss(full);
     # 'null' base: refit WITH the feature added, gain = loss(base) - loss(extended), its weight is kept.
+    if verbosity == 3 and not common_noise:
+        print("[BRIE2] note: ELBO_gain is the difference of two independently sampled loss estimates; "
+              "common_noise=True (--commonNoise 1) shares the noise stream and removes most of that error")
     gain = np.zeros((Ng, len(tested)), dtype=np.float32)
     for col, feat in enumerate(tested):
         if verbosity == 3:

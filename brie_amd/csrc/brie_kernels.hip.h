@@ -120,12 +120,32 @@ __device__ __forceinline__ float f_log1p(float x) {
     return log1pf(x);
 #endif
 }
-__device__ __forceinline__ float f_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// BRIE_FAST_MATH=0 is strict throughout: IEEE division and square root (hipcc rounds both correctly by
+// default), ocml exp / log / log1p / sincospi.  The Adam update can be made strict on its own
+// (BRIE_STRICT_ADAM=1 with fast transcendentals): two divisions + two square roots per element.
+#ifndef BRIE_STRICT_ADAM
+#define BRIE_STRICT_ADAM (!BRIE_FAST_MATH)
+#endif
+__device__ __forceinline__ float f_rcp(float x) {
+#if BRIE_FAST_MATH
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
 __device__ __forceinline__ float f_sqrt(float x) {
 #if BRIE_FAST_MATH
     return __builtin_amdgcn_sqrtf(x);
 #else
     return sqrtf(x);
+#endif
+}
+// x - (m * alpha) / (sqrt(v) + eps): the Keras Adam update
+__device__ __forceinline__ float adam_update(float x, float m, float v, float alpha) {
+#if BRIE_STRICT_ADAM
+    return x - (m * alpha) / (sqrtf(v) + 1e-7f);
+#else
+    return x - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + 1e-7f);
 #endif
 }
 
@@ -175,7 +195,11 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
     const float az = fabsf(z);
     const float e = f_exp(-az);                   // exp(-|z|) in (0,1]
     const float inv = f_rcp(1.0f + e);
+#if BRIE_FAST_MATH
     const float big = inv, small = e * inv;       // sigmoid(|z|), sigmoid(-|z|)
+#else
+    const float big = inv, small = e / (1.0f + e);
+#endif
     const float sp = z >= 0.0f ? big : small;     // sigmoid(z)
     const float sn = z >= 0.0f ? small : big;     // sigmoid(-z)
     const float l1p = f_log1p(e);
@@ -569,9 +593,9 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
                 const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
                 const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
-                float nmu = R.mu.v[v] - (n_mm * a.alpha) * f_rcp(f_sqrt(n_vm) + kAdamEps);
+                float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
                 nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
-                const float nrho = R.rho.v[v] - (n_mr * a.alpha) * f_rcp(f_sqrt(n_vr) + kAdamEps);
+                const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
                 R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
                 R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
                 R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];

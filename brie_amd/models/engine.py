@@ -104,10 +104,7 @@ class BRIE2(object):
             if self.Kg > 0 and Xg is not None:
                 self._shard.upload(_capi.XG, np.ascontiguousarray(Xg, dtype=np.float32))
             return self._shard
-        sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
-                         train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
-                         seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
-                         intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
+        sh = self._new_shard(n_layers)
         self._upload_layers(sh, count_layers, n_layers)
         if self.effLen is not None:
             sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
@@ -142,6 +139,13 @@ class BRIE2(object):
                 sh.upload(_capi.SIGMA_LOG, np.log(np.asarray(get('sigma'), np.float32)).reshape(par))
         self._shard, self._n_layers = sh, n_layers
         return sh
+
+    def _new_shard(self, n_layers):
+        """One `brie_handle` (gene shard on one GPU) for this model; the only place a backend is chosen."""
+        return _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
+                           train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
+                           seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
+                           intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
 
     def _upload_layers(self, sh, count_layers, n_layers):
         for l in range(n_layers):
@@ -233,7 +237,7 @@ class BRIE2(object):
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
             n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, loss_gene_draw=None,
-            n_iter_schedule=None, **kwargs):
+            n_iter_schedule=None, conv_total_genes=None, **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
@@ -242,7 +246,10 @@ class BRIE2(object):
         conv_batch_genes=None: one model, one convergence decision on the summed loss trace
         (model_TFProb.py:247-258).  conv_batch_genes=n (set by fitBRIE to ceil(batch_size/Nc)): every
         batch of n consecutive genes is one of the reference's sequential fits (model_wrap.py:241-260)
-        and stops on its own windowed loss; stopped batches are frozen on the device.
+        and stops on its own windowed loss; stopped batches are frozen on the device.  Batches are anchored on the
+        GLOBAL gene index (gene_offset + j) // n, so the grouping does not depend on how the genes are sharded; with
+        `trace_reduce` and `conv_total_genes` (all genes of the job) the windowed sums of every batch are summed over
+        the ranks before the decision, so a batch that straddles two gene shards stops as one.
         n_iter_schedule: iteration counts of an earlier fit (its `n_iter_batch`, or `[n_iter]`) to be repeated
         instead of taking new convergence decisions -- the companion fits of a common-noise LRT stop where the base
         model stopped, so both evaluate the same stretch of the noise stream.
@@ -280,15 +287,25 @@ class BRIE2(object):
         d1 = int(min(50, add_iter / 2))
         d2 = d1 * 2
         if conv_batch_genes and not self._coupled and target == "ELBO":
-            starts = np.arange(0, self.Ng, int(conv_batch_genes))
+            cbg = int(conv_batch_genes)
+            first = (-self.gene_offset) % cbg                        # first global batch boundary inside this shard
+            starts = np.unique(np.concatenate([[0], np.arange(first, self.Ng, cbg)])).astype(np.int64)
             sizes = np.diff(np.append(starts, self.Ng))
+            gids = (self.gene_offset + starts) // cbg                # global batch id of every local group
+            glob = trace_reduce is not None and conv_total_genes is not None
+            n_glob = -(-int(conv_total_genes) // cbg) if glob else 0
             batch_on = np.ones(len(starts), bool)
             self.n_iter_batch = np.full(len(starts), n_iter)
             while n_iter < max_iter and len(losses) >= d2 and 0 < d2 <= 128:
                 if n_iter_schedule is not None and len(n_iter_schedule) == len(starts):
                     batch_on &= np.asarray(n_iter_schedule) > n_iter                  # repeat the earlier fit's stops
                 else:
-                    win = np.add.reduceat(sh.read_loss_window(d2).astype(np.float64), starts, axis=1).astype(np.float32)
+                    win = np.add.reduceat(sh.read_loss_window(d2).astype(np.float64), starts, axis=1)
+                    if glob:                                         # sums over ALL ranks' genes of every batch
+                        full = np.zeros((d2, n_glob))
+                        full[:, gids] = win
+                        win = np.asarray(trace_reduce(full.ravel()), np.float64).reshape(d2, n_glob)[:, gids]
+                    win = win.astype(np.float32)
                     batch_on &= (win[:d1].mean(0) - win[d1:].mean(0)) > epsilon_conv  # per batch, model_TFProb.py:250
                 n_on = int(batch_on.sum())
                 if trace_reduce is not None:                         # gene shards: stop when no rank has work left

@@ -183,9 +183,27 @@ def _write_back(adata, res, Xc, Xg, put_layer, LRT_index, params):
     adata.uns['brie_param'] = params
 
 
-def _super_batch_genes(limit, Nc, n_genes, n_layers, Kc, device, n_batch_genes):
+def _part_bounds(g_lo, g_hi, n_parts, super_batch, n_batch_genes):
+    """[g_lo, g_hi) cut into exactly `n_parts` consecutive non-empty pieces, or fewer if that is impossible.
+    Pieces of `super_batch` genes when that gives the right count (the rank with the largest shard), otherwise equal
+    pieces rounded up to whole gene blocks + convergence batches, whole convergence batches, or gene quads."""
+    def cut(piece):
+        return [(a, min(a + piece, g_hi)) for a in range(g_lo, g_hi, piece)]
+    best = cut(super_batch)
+    if len(best) == n_parts:
+        return best
+    even = -(-(g_hi - g_lo) // n_parts)
+    for unit in (int(np.lcm(256, max(1, n_batch_genes))), int(np.lcm(4, max(1, n_batch_genes))), 4):
+        parts = cut(-(-even // unit) * unit)
+        if len(parts) == n_parts:
+            return parts
+    return best
+
+
+def _super_batch_genes(limit, Nc, n_genes, n_layers, Kc, device, n_batch_genes, free=None):
     """Genes per sequential super-batch, or None when the whole range is fitted at once.  'auto': as many genes as
-    fit into 90 % of the free HBM; always a multiple of the convergence batch and of 256 (one gene block)."""
+    fit into 90 % of the free HBM (`free`; asked from the device when None); always a multiple of the convergence
+    batch and of 256 (one gene block)."""
     from .. import _capi
     unit = int(np.lcm(256, max(1, n_batch_genes)))
     if limit is None:
@@ -193,7 +211,8 @@ def _super_batch_genes(limit, Nc, n_genes, n_layers, Kc, device, n_batch_genes):
     if isinstance(limit, str):
         if limit.lower() != 'auto':
             raise ValueError("max_genes_per_fit=%r" % (limit,))
-        free = BRIE2.free_device_memory(device)
+        if free is None:
+            free = BRIE2.free_device_memory(device)
         if _capi.shard_bytes(Nc, n_genes, n_layers, Kc) <= 0.9 * free:
             return None
         per_unit = _capi.shard_bytes(Nc, unit, n_layers, Kc) - (256 << 20)
@@ -221,7 +240,12 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
     Xc = np.ones((Nc, 0), np.float32) if Xc is None else Xc
     Xg = np.ones((Ng, 0), np.float32) if Xg is None else Xg
     LRT_index = np.arange(Xc.shape[1]) if LRT_index is None else LRT_index
-    layer_keys = [k for k in layer_keys if k in adata.layers]
+    # adata.layers[key] raises KeyError in the reference for a missing unique layer (model_wrap.py:247,262); only the
+    # optional third ("ambiguous") layer may be absent
+    for key in layer_keys[:2]:
+        if key not in adata.layers:
+            raise KeyError("count layer %r not in adata.layers (have: %s)" % (key, sorted(adata.layers)))
+    layer_keys = list(layer_keys[:2]) + [k for k in layer_keys[2:] if k in adata.layers]
     has_eff = 'effLen' in adata.varm
     # genes are independent unless gene features or per-cell intercepts tie them together (model_wrap.py:241)
     separable = Xg.shape[1] == 0 and intercept_mode.upper() != 'CELL'
@@ -236,54 +260,76 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
 
     g_lo, g_hi = 0, Ng
     sharded = comm is not None and comm.world > 1
+    n_batch_genes = int(np.ceil(batch_size / Nc))                     # model_wrap.py:242
+    ranges = [(0, Ng)]
     if sharded:
         # separable fits shard freely; coupled fits (Kg > 0 / cell mode) shard the genes too and all-reduce the
         # per-cell statistics every step (brie_step_begin/_end).  The loss trace is summed over ranks so that
         # every rank takes the same convergence decisions.
         from ..sharding import gene_shard
-        if gene_shard(Ng, comm.world - 1, comm.world)[0] >= Ng:
+        # shard boundaries on whole convergence batches when that leaves no rank empty (else on gene quads: a
+        # batch that straddles two ranks is then decided on its windowed loss summed over both, see BRIE2.fit)
+        align = int(np.lcm(4, max(1, n_batch_genes))) if separable else 4
+        if gene_shard(Ng, comm.world - 1, comm.world, align)[0] >= Ng:
+            align = 4
+        if gene_shard(Ng, comm.world - 1, comm.world, align)[0] >= Ng:
             raise ValueError("%d genes cannot be sharded over %d ranks (a rank would be empty): use fewer GPUs"
                              % (Ng, comm.world))
-        g_lo, g_hi = gene_shard(Ng, comm.rank, comm.world)
-        keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum)
+        ranges = [gene_shard(Ng, r, comm.world, align) for r in range(comm.world)]
+        g_lo, g_hi = ranges[comm.rank]
+        if not emulate_batches:       # literal sequential batches are independent fits: nothing is exchanged in the loop
+            keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum, conv_total_genes=Ng)
 
-    n_batch_genes = int(np.ceil(batch_size / Nc))                     # model_wrap.py:242
-    super_batch = None
-    if separable and not emulate_batches:
-        super_batch = _super_batch_genes(max_genes_per_fit, Nc, g_hi - g_lo, len(layer_keys), Xc.shape[1], device,
-                                         n_batch_genes)
+    parts = [(g_lo, g_hi)]
     if separable and emulate_batches:                                 # the literal loop of model_wrap.py:244-260
         step = max(4, (n_batch_genes + 3) // 4 * 4)                   # the noise stream is keyed per gene quad
-        parts = []
-        for g0 in range(g_lo, g_hi, step):
-            parts.append(fit_range(g0, min(g0 + step, g_hi), seed))
-            print("[BRIE2] %d out %d genes done" % (min(g0 + step, g_hi), Ng))
-        ResVal = concate(parts)
-    else:
-        if separable and 'conv_batch_genes' not in keyargs:
+        parts = [(g0, min(g0 + step, g_hi)) for g0 in range(g_lo, g_hi, step)]
+    elif separable:
+        if 'conv_batch_genes' not in keyargs:
             # all genes at once, but each reference-sized batch still stops on its own loss window
             keyargs = dict(keyargs, conv_batch_genes=n_batch_genes)
-        if super_batch is None:
-            ResVal = fit_range(g_lo, g_hi, seed)
-        else:                                                         # larger than the device: sequential super-batches
-            parts = []
-            for g0 in range(g_lo, g_hi, super_batch):
-                parts.append(fit_range(g0, min(g0 + super_batch, g_hi), seed))
-                print("[BRIE2] %d out %d genes done" % (min(g0 + super_batch, g_hi), Ng))
-            ResVal = concate(parts)
-            if hasattr(ResVal, 'pval'):          # one Benjamini-Hochberg pass over all genes, as in the unsplit fit
-                ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
+        # Larger than the device: sequential super-batches.  With several ranks the split is a COLLECTIVE decision --
+        # every fit issues all-reduces, so every rank must run the same number of parts: sized for the largest shard
+        # and the smallest free memory, and every rank cuts its own range into that many non-empty pieces.
+        n_max = max(b - a for a, b in ranges)
+        free = None
+        if isinstance(max_genes_per_fit, str) and max_genes_per_fit.lower() == 'auto':
+            free = BRIE2.free_device_memory(device)
+            if sharded:
+                free = int(comm.allreduce_min(np.array([float(free)]))[0])
+        super_batch = _super_batch_genes(max_genes_per_fit, Nc, n_max, len(layer_keys), Xc.shape[1], device,
+                                         n_batch_genes, free=free)
+        if super_batch is not None:
+            n_parts = -(-n_max // super_batch)
+            cuts = [_part_bounds(a, b, n_parts, super_batch, n_batch_genes) for a, b in ranges]
+            short = [r for r, c in enumerate(cuts) if len(c) != n_parts]
+            if short:
+                raise ValueError("the gene range must be fitted in %d sequential parts, but rank(s) %s hold too few "
+                                 "genes to be cut that often: use fewer GPUs or a larger max_genes_per_fit"
+                                 % (n_parts, short))
+            parts = cuts[comm.rank if sharded else 0]
+
+    if len(parts) == 1:
+        ResVal = fit_range(parts[0][0], parts[0][1], seed)
+    else:
+        done = []
+        for g0, g1 in parts:
+            done.append(fit_range(g0, g1, seed))
+            print("[BRIE2] %d out %d genes done" % (g1, Ng))
+        ResVal = concate(done)
+        if hasattr(ResVal, 'pval') and not emulate_batches:   # one Benjamini-Hochberg pass over all genes, as unsplit
+            ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
 
     ResVal.gene_range = (g_lo, g_hi)
     if sharded:                                                       # RCCL all-gather of the per-gene vectors
         if ResVal.sigma.shape[0] == 1:                                # (Nc,1) cell-mode vectors are replicated
-            ResVal.sigma = comm.allgather_genes(ResVal.sigma, Ng)
-            ResVal.intercept = comm.allgather_genes(ResVal.intercept, Ng)
-        ResVal.cell_coeff = comm.allgather_genes(ResVal.cell_coeff, Ng) if ResVal.cell_coeff.shape[0] \
+            ResVal.sigma = comm.allgather_genes(ResVal.sigma, Ng, ranges)
+            ResVal.intercept = comm.allgather_genes(ResVal.intercept, Ng, ranges)
+        ResVal.cell_coeff = comm.allgather_genes(ResVal.cell_coeff, Ng, ranges) if ResVal.cell_coeff.shape[0] \
             else np.zeros((0, Ng), np.float32)
-        ResVal.loss_gene = comm.allgather_genes(ResVal.loss_gene, Ng)[0]
+        ResVal.loss_gene = comm.allgather_genes(ResVal.loss_gene, Ng, ranges)[0]
         if hasattr(ResVal, 'ELBO_gain'):
-            ResVal.ELBO_gain = comm.allgather_genes(ResVal.ELBO_gain.T, Ng).T
+            ResVal.ELBO_gain = comm.allgather_genes(ResVal.ELBO_gain.T, Ng, ranges).T
             ResVal.pval = elbo_gain_pval(ResVal.ELBO_gain)
             ResVal.fdr = np.stack([fdr_bh(ResVal.pval[:, i]) for i in range(ResVal.pval.shape[1])], axis=1)
 
@@ -297,7 +343,7 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
             return
         adata.layers[key + '_shard'] = local
         if gather_layers:
-            full = comm.gather_columns(local, Ng)
+            full = comm.gather_columns(local, Ng, ranges=ranges)
             if full is not None:
                 adata.layers[key] = full
 

@@ -18,10 +18,14 @@ parameters are replicated and every step all-reduces the ((max(Kg,4)+2) x Nc) pe
 import numpy as np
 
 
-def gene_shard(Ng, rank, world):
-    """[g0, g1) of `rank`; boundaries are multiples of 4 (one Philox draw = one gene quad)."""
+def gene_shard(Ng, rank, world, align=4):
+    """[g0, g1) of `rank`; boundaries are multiples of `align` (itself a multiple of 4: one Philox draw = one gene
+    quad; fitBRIE passes lcm(4, genes per convergence batch) so that no batch straddles two ranks)."""
+    align = int(align)
+    if align < 4 or align % 4:
+        raise ValueError("align=%d must be a positive multiple of 4" % align)
     per = -(-int(Ng) // int(world))
-    per = -(-per // 4) * 4
+    per = -(-per // align) * align
     g0 = min(rank * per, Ng)
     g1 = min(g0 + per, Ng)
     return g0, g1
@@ -55,24 +59,31 @@ class GeneComm(object):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t.cpu().numpy()
 
-    def allgather_genes(self, local, Ng):
-        """local (k, n_local) per-gene rows -> (k, Ng) on every rank."""
+    def allreduce_min(self, a):
+        """Minimum of a small host vector over ranks (e.g. the free HBM every rank reports)."""
+        import torch
+        t = self._tensor(np.asarray(a, np.float64), torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return t.cpu().numpy()
+
+    def _ranges(self, Ng, ranges):
+        return [gene_shard(Ng, r, self.world) for r in range(self.world)] if ranges is None else list(ranges)
+
+    def allgather_genes(self, local, Ng, ranges=None):
+        """local (k, n_local) per-gene rows -> (k, Ng) on every rank.  `ranges`: the [g0, g1) of every rank
+        (default: gene_shard with quad alignment)."""
         import torch
         local = np.asarray(local, np.float32)
         if local.ndim == 1:
             local = local.reshape(1, -1)
-        k = local.shape[0]
-        per = gene_shard(Ng, 0, self.world)[1]
-        buf = np.zeros((k, per), np.float32)
+        ranges = self._ranges(Ng, ranges)
+        per = max(b - a for a, b in ranges)
+        buf = np.zeros((local.shape[0], per), np.float32)
         buf[:, :local.shape[1]] = local
         t = self._tensor(buf)
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
-        full = np.concatenate([o.cpu().numpy() for o in out], axis=1)
-        keep = np.concatenate([np.arange(r * per, r * per + (gene_shard(Ng, r, self.world)[1] -
-                                                              gene_shard(Ng, r, self.world)[0]))
-                               for r in range(self.world)]) if self.world > 1 else np.arange(Ng)
-        return full[:, keep.astype(np.int64)]
+        return np.concatenate([o.cpu().numpy()[:, :b - a] for o, (a, b) in zip(out, ranges)], axis=1)
 
     def allreduce_inplace(self, t):
         """Sum a float32 device tensor over ranks in place and return once the result is visible to every
@@ -89,12 +100,13 @@ class GeneComm(object):
                 torch.cuda.current_stream(t.device).synchronize()
         return t
 
-    def gather_columns(self, local, Ng, root=0):
+    def gather_columns(self, local, Ng, root=0, ranges=None):
         """Column shards (Nc, n_local) of a cell x gene matrix -> the full (Nc, Ng) matrix on `root`
         (None elsewhere).  Used once per output layer at the end of a fit; inside the loop nothing moves."""
         import torch
         local = np.ascontiguousarray(local, np.float32)
-        per = gene_shard(Ng, 0, self.world)[1]
+        ranges = self._ranges(Ng, ranges)
+        per = max(b - a for a, b in ranges)
         buf = np.zeros((local.shape[0], per), np.float32)
         buf[:, :local.shape[1]] = local
         t = self._tensor(buf)
@@ -102,11 +114,7 @@ class GeneComm(object):
         self.dist.gather(t, out, dst=root, group=self.group)
         if self.rank != root:
             return None
-        parts = []
-        for r, o in enumerate(out):
-            g0, g1 = gene_shard(Ng, r, self.world)
-            parts.append(o.cpu().numpy()[:, :g1 - g0])
-        return np.concatenate(parts, axis=1)
+        return np.concatenate([o.cpu().numpy()[:, :b - a] for o, (a, b) in zip(out, ranges)], axis=1)
 
     def barrier(self):
         self.dist.barrier(group=self.group)

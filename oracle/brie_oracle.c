@@ -9,6 +9,8 @@
  *   2. bench.py's "cpu_baseline_fused": what a tuned multi-core CPU kernel of the same algorithm reaches
  *      (reported NEXT TO the reference-shaped eager baseline, never instead of it -- BASELINE.md section 3).
  * Build: gcc -O3 -fopenmp -shared -fPIC oracle/brie_oracle.c -o oracle/_build/libbrie_oracle.so -lm
+ *        (+ -DBRIE_ORACLE_F64 -o .../libbrie_oracle_f64.so: the same code with every fp32 quantity held in
+ *         double -- the precision-independent answer the fp32 results are measured against)
  * Nothing in brie_amd/ may link or load this file.
  */
 #include <math.h>
@@ -29,22 +31,48 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
 }
+#ifdef BRIE_ORACLE_F64
+typedef double real;
+#define R_EXP exp
+#define R_LOG log
+#define R_LOG1P log1p
+#define R_EXPM1 expm1
+#define R_SQRT sqrt
+#define R_POW pow
+#define R_FABS fabs
+#define R_FMIN fmin
+#define R_FMAX fmax
+#else
+typedef float real;
+#define R_EXP expf
+#define R_LOG logf
+#define R_LOG1P log1pf
+#define R_EXPM1 expm1f
+#define R_SQRT sqrtf
+#define R_POW powf
+#define R_FABS fabsf
+#define R_FMIN fminf
+#define R_FMAX fmaxf
+#endif
+#define RC(x) ((real)(x))
+
 static double u01(uint32_t x) { return ((double)(x >> 9) + 0.5) * (1.0 / 8388608.0); }
-static void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uint64_t seed, float e[4]) {
+/* eps is the fp32 value of oracle/philox.py in both precisions (the noise stream is DEFINED in fp32) */
+static void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uint64_t seed, real e[4]) {
     uint32_t c[4] = {quad, cell, draw, k};
     philox4x32_10(c, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
     for (int p = 0; p < 2; ++p) {
         const double r = sqrt(-2.0 * log(u01(c[2 * p]))), th = 6.283185307179586476925 * u01(c[2 * p + 1]);
-        e[2 * p] = (float)(r * cos(th));
-        e[2 * p + 1] = (float)(r * sin(th));
+        e[2 * p] = (real)(float)(r * cos(th));
+        e[2 * p + 1] = (real)(float)(r * sin(th));
     }
 }
 
-static inline float sigmoidf_(float x) {
-    const float e = expf(-fabsf(x));
-    return x >= 0.0f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+static inline real sigmoidf_(real x) {
+    const real e = R_EXP(-R_FABS(x));
+    return x >= RC(0) ? RC(1) / (RC(1) + e) : e / (RC(1) + e);
 }
-static inline float log_sigmoidf_(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
+static inline real log_sigmoidf_(real x) { return R_FMIN(x, RC(0)) - R_LOG1P(R_EXP(-R_FABS(x))); }
 
 typedef struct {
     int32_t Nc, Ng, Kc, n_layers, has_efflen, mc, train_b, train_lam;
@@ -52,35 +80,36 @@ typedef struct {
     uint64_t seed;
 } brie_oracle_problem;
 
-static void adam(float *x, float *m, float *v, float g, float alpha, int clip) {
-    *m += (g - *m) * (1.0f - 0.9f);
-    *v += (g * g - *v) * (1.0f - 0.999f);
-    *x -= (*m * alpha) / (sqrtf(*v) + 1e-7f);
-    if (clip) *x = fminf(fmaxf(*x, -9.0f), 9.0f);
+static void adam(real *x, real *m, real *v, real g, real alpha, int clip) {
+    *m += (g - *m) * (RC(1) - RC(0.9));
+    *v += (g * g - *v) * (RC(1) - RC(0.999));
+    *x -= (*m * alpha) / (R_SQRT(*v) + RC(1e-7));
+    if (clip) *x = R_FMIN(R_FMAX(*x, RC(-9)), RC(9));
 }
 
 /* n_steps optimisation steps in place; trace[i] = loss BEFORE update i (sum KL - sum ll, double sums).
  * t0 = Adam iterations already taken by this optimiser, draw0 = first noise draw id.  Returns 0. */
-int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, float lr, int32_t t0, uint32_t draw0,
-                      const float *c1, const float *c2, const float *c3, const float *Xc, const float *effLen,
-                      float *Z_loc, float *Z_std_log, float *m_mu, float *v_mu, float *m_rho, float *v_rho,
-                      float *W, float *m_W, float *v_W, float *b, float *m_b, float *v_b, float *lam, float *m_lam,
-                      float *v_lam, float *trace) {
+int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_, int32_t t0, uint32_t draw0,
+                      const real *c1, const real *c2, const real *c3, const real *Xc, const real *effLen,
+                      real *Z_loc, real *Z_std_log, real *m_mu, real *v_mu, real *m_rho, real *v_rho,
+                      real *W, real *m_W, real *v_W, real *b, real *m_b, real *v_b, real *lam, real *m_lam,
+                      real *v_lam, real *trace) {
+    const real lr = (real)lr_;
     const int Nc = p->Nc, Ng = p->Ng, Kc = p->Kc, S = Kc + 4;
     int nthreads = 1;
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
     double *acc = (double *)malloc(sizeof(double) * (size_t)nthreads * S * Ng);
-    float *lL = (float *)malloc(sizeof(float) * 3 * (size_t)Ng);
+    real *lL = (real *)malloc(sizeof(real) * 3 * (size_t)Ng);
     if (!acc || !lL) return -1;
     if (p->has_efflen)
         for (int j = 0; j < Ng; ++j) {
-            lL[j] = logf(effLen[6 * j + 0]); lL[Ng + j] = logf(effLen[6 * j + 4]); lL[2 * Ng + j] = logf(effLen[6 * j + 5]);
+            lL[j] = R_LOG(effLen[6 * j + 0]); lL[Ng + j] = R_LOG(effLen[6 * j + 4]); lL[2 * Ng + j] = R_LOG(effLen[6 * j + 5]);
         }
     for (int step = 0; step < n_steps; ++step) {
         const int t = t0 + step + 1;
-        const float alpha = lr * sqrtf(1.0f - powf(0.999f, (float)t)) / (1.0f - powf(0.9f, (float)t));
+        const real alpha = lr * R_SQRT(RC(1) - R_POW(RC(0.999), (real)t)) / (RC(1) - R_POW(RC(0.9), (real)t));
         const uint32_t draw = draw0 + (uint32_t)step;
         memset(acc, 0, sizeof(double) * (size_t)nthreads * S * Ng);
 #pragma omp parallel
@@ -92,45 +121,45 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, float lr, i
             double *a = acc + (size_t)tid * S * Ng;
 #pragma omp for schedule(static)
             for (int i = 0; i < Nc; ++i) {
-                const float *x = Xc + (size_t)i * Kc;
+                const real *x = Xc + (size_t)i * Kc;
                 for (int j0 = 0; j0 < Ng; j0 += 4) {
-                    float eps[8][4];                       /* up to 8 MC samples */
+                    real eps[8][4];                        /* up to 8 MC samples */
                     const uint32_t quad = (uint32_t)((p->gene_offset + j0) / 4);
                     for (int k = 0; k < p->mc; ++k) normal4(quad, (uint32_t)i, draw, (uint32_t)k, p->seed, eps[k]);
                     for (int v = 0; v < 4 && j0 + v < Ng; ++v) {
                         const int j = j0 + v;
                         const size_t o = (size_t)i * Ng + j;
-                        const float mu = Z_loc[o], rho = Z_std_log[o], s = expf(rho);
-                        float m = b[j];
+                        const real mu = Z_loc[o], rho = Z_std_log[o], s = R_EXP(rho);
+                        real m = b[j];
                         for (int k = 0; k < Kc; ++k) m += x[k] * W[(size_t)k * Ng + j];
-                        const float isig2 = expf(-2.0f * lam[j]), d = mu - m, rr = d * isig2, s2r = s * s * isig2;
-                        const float kl = 0.5f * d * d * isig2 + 0.5f * expm1f(2.0f * (rho - lam[j])) - (rho - lam[j]);
-                        float gbar = 0.0f, gse = 0.0f, ll = 0.0f;
+                        const real isig2 = R_EXP(RC(-2) * lam[j]), d = mu - m, rr = d * isig2, s2r = s * s * isig2;
+                        const real kl = RC(0.5) * d * d * isig2 + RC(0.5) * R_EXPM1(RC(2) * (rho - lam[j])) - (rho - lam[j]);
+                        real gbar = RC(0), gse = RC(0), ll = RC(0);
                         for (int k = 0; k < p->mc; ++k) {
-                            const float z = mu + s * eps[k][v];
-                            const float ls1 = log_sigmoidf_(z), ls2 = log_sigmoidf_(-z), sp = sigmoidf_(z);
-                            float l, g;
+                            const real z = mu + s * eps[k][v];
+                            const real ls1 = log_sigmoidf_(z), ls2 = log_sigmoidf_(-z), sp = sigmoidf_(z);
+                            real l, g;
                             if (!p->has_efflen) {
                                 l = c1[o] * ls1 + c2[o] * ls2;
                                 g = c1[o] - (c1[o] + c2[o]) * sp;
                             } else {
-                                const float a1 = ls1 + lL[j], a2 = ls2 + lL[Ng + j], a3 = lL[2 * Ng + j];
-                                const float mx = fmaxf(a1, fmaxf(a2, a3));
-                                const float lse = mx + logf(expf(a1 - mx) + expf(a2 - mx) + expf(a3 - mx));
-                                const float cc3 = p->n_layers > 2 ? c3[o] : 0.0f, N = c1[o] + c2[o] + cc3;
+                                const real a1 = ls1 + lL[j], a2 = ls2 + lL[Ng + j], a3 = lL[2 * Ng + j];
+                                const real mx = R_FMAX(a1, R_FMAX(a2, a3));
+                                const real lse = mx + R_LOG(R_EXP(a1 - mx) + R_EXP(a2 - mx) + R_EXP(a3 - mx));
+                                const real cc3 = p->n_layers > 2 ? c3[o] : RC(0), N = c1[o] + c2[o] + cc3;
                                 l = c1[o] * (a1 - lse) + c2[o] * (a2 - lse) + cc3 * (a3 - lse);
-                                g = c1[o] * (1.0f - sp) - c2[o] * sp - N * (expf(a1 - lse) * (1.0f - sp) - expf(a2 - lse) * sp);
+                                g = c1[o] * (RC(1) - sp) - c2[o] * sp - N * (R_EXP(a1 - lse) * (RC(1) - sp) - R_EXP(a2 - lse) * sp);
                             }
                             ll += l; gbar += g; gse += g * s * eps[k][v];
                         }
-                        ll /= (float)p->mc; gbar /= (float)p->mc; gse /= (float)p->mc;
+                        ll /= (real)p->mc; gbar /= (real)p->mc; gse /= (real)p->mc;
                         for (int k = 0; k < Kc; ++k) a[(size_t)k * Ng + j] += (double)(x[k] * rr);
                         a[(size_t)(Kc + 0) * Ng + j] += rr;
-                        a[(size_t)(Kc + 1) * Ng + j] += 1.0f - d * d * isig2 - s2r;
+                        a[(size_t)(Kc + 1) * Ng + j] += RC(1) - d * d * isig2 - s2r;
                         a[(size_t)(Kc + 2) * Ng + j] += kl;
                         a[(size_t)(Kc + 3) * Ng + j] += ll;
                         adam(&Z_loc[o], &m_mu[o], &v_mu[o], rr - gbar, alpha, 1);
-                        adam(&Z_std_log[o], &m_rho[o], &v_rho[o], s2r - 1.0f - gse, alpha, 0);
+                        adam(&Z_std_log[o], &m_rho[o], &v_rho[o], s2r - RC(1) - gse, alpha, 0);
                     }
                 }
             }
@@ -142,16 +171,18 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, float lr, i
                 tot[s] = 0.0;
                 for (int th = 0; th < nthreads; ++th) tot[s] += acc[((size_t)th * S + s) * Ng + j];
             }
-            for (int k = 0; k < Kc; ++k) adam(&W[(size_t)k * Ng + j], &m_W[(size_t)k * Ng + j], &v_W[(size_t)k * Ng + j], (float)(-tot[k]), alpha, 0);
-            if (p->train_b) adam(&b[j], &m_b[j], &v_b[j], (float)(-tot[Kc]), alpha, 1);
-            if (p->train_lam) adam(&lam[j], &m_lam[j], &v_lam[j], (float)tot[Kc + 1], alpha, 0);
+            for (int k = 0; k < Kc; ++k) adam(&W[(size_t)k * Ng + j], &m_W[(size_t)k * Ng + j], &v_W[(size_t)k * Ng + j], (real)(-tot[k]), alpha, 0);
+            if (p->train_b) adam(&b[j], &m_b[j], &v_b[j], (real)(-tot[Kc]), alpha, 1);
+            if (p->train_lam) adam(&lam[j], &m_lam[j], &v_lam[j], (real)tot[Kc + 1], alpha, 0);
             loss_kl += tot[Kc + 2]; loss_ll += tot[Kc + 3];
         }
-        if (trace) trace[step] = (float)(loss_kl - loss_ll);
+        if (trace) trace[step] = (real)(loss_kl - loss_ll);
     }
     free(acc); free(lL);
     return 0;
 }
+
+int brie_oracle_real_bytes(void) { return (int)sizeof(real); }
 
 int brie_oracle_threads(void) {
 #ifdef _OPENMP

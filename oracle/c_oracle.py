@@ -8,14 +8,19 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "brie_oracle.c")
 LIB = os.path.join(HERE, "_build", "libbrie_oracle.so")
+LIB_F64 = os.path.join(HERE, "_build", "libbrie_oracle_f64.so")
 
 
-def build(force=False):
-    """gcc -O3 -fopenmp -> oracle/_build/libbrie_oracle.so"""
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(SRC):
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        subprocess.run(["gcc", "-O3", "-fopenmp", "-shared", "-fPIC", SRC, "-o", LIB, "-lm"], check=True)
-    return LIB
+def build(force=False, f64=False):
+    """gcc -O3 -fopenmp -> oracle/_build/libbrie_oracle.so (fp32, the reference's precision) or, with f64=True,
+    libbrie_oracle_f64.so (the same code with every quantity in double).  -ffp-contract=off: no fused
+    multiply-adds, so the fp32 build rounds after every operation like the eager reference does."""
+    lib = LIB_F64 if f64 else LIB
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(SRC):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC"] +
+                       (["-DBRIE_ORACLE_F64"] if f64 else []) + [SRC, "-o", lib, "-lm"], check=True)
+    return lib
 
 
 class _Problem(ctypes.Structure):
@@ -27,19 +32,23 @@ class _Problem(ctypes.Structure):
 class COracle(object):
     """State + optimiser slots as float32 arrays, stepped by the C kernel; mirrors OracleBRIE2's fields."""
 
-    def __init__(self, counts, Xc, effLen=None, seed=0, gene_offset=0, intercept=None, sigma=None, init=None):
+    def __init__(self, counts, Xc, effLen=None, seed=0, gene_offset=0, intercept=None, sigma=None, init=None,
+                 dtype=np.float32):
         from .brie_oracle import OracleBRIE2
-        self.lib = ctypes.CDLL(build())
-        self.counts = [np.ascontiguousarray(c, np.float32) for c in counts]
+        self.dtype = np.dtype(dtype)
+        self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64))
+        assert self.lib.brie_oracle_real_bytes() == self.dtype.itemsize
+        dt = self.dtype
+        self.counts = [np.ascontiguousarray(c, dt) for c in counts]
         self.Nc, self.Ng = self.counts[0].shape
-        self.Xc = np.ascontiguousarray(Xc if Xc is not None else np.zeros((self.Nc, 0)), np.float32)
+        self.Xc = np.ascontiguousarray(Xc if Xc is not None else np.zeros((self.Nc, 0)), dt)
         self.Kc = self.Xc.shape[1]
-        self.effLen = None if effLen is None else np.ascontiguousarray(effLen, np.float32)
+        self.effLen = None if effLen is None else np.ascontiguousarray(effLen, dt)
         self.seed, self.gene_offset, self.draw, self.t = int(seed), int(gene_offset), 0, 0
         self.train_b, self.train_lam = intercept is None, sigma is None
         o = OracleBRIE2(self.Nc, self.Ng, self.Kc, effLen=effLen, intercept=intercept, sigma=sigma, seed=seed,
                         gene_offset=gene_offset, dtype=np.float32, init=init)
-        f = lambda a: np.ascontiguousarray(a, np.float32)
+        f = lambda a: np.ascontiguousarray(a, dt)
         self.Z_loc, self.Z_std_log, self.Wc_loc = f(o.Z_loc), f(o.Z_std_log), f(o.Wc_loc)
         self.intercept, self.sigma_log = f(o.intercept).reshape(-1), f(o.sigma_log).reshape(-1)
         self.reset_optimizer()
@@ -52,12 +61,12 @@ class COracle(object):
     def minimize(self, n_steps, lr, MC_size=1):
         p = _Problem(self.Nc, self.Ng, self.Kc, len(self.counts), int(self.effLen is not None), int(MC_size),
                      int(self.train_b), int(self.train_lam), self.gene_offset, self.seed)
-        trace = np.zeros(n_steps, np.float32)
+        trace = np.zeros(n_steps, self.dtype)
         ptr = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
         c3 = self.counts[2] if len(self.counts) > 2 else None
         s = self.slots
         rc = self.lib.brie_oracle_steps(
-            ctypes.byref(p), ctypes.c_int32(n_steps), ctypes.c_float(lr), ctypes.c_int32(self.t),
+            ctypes.byref(p), ctypes.c_int32(n_steps), ctypes.c_double(float(np.float32(lr))), ctypes.c_int32(self.t),
             ctypes.c_uint32(self.draw), ptr(self.counts[0]), ptr(self.counts[1]), ptr(c3), ptr(self.Xc), ptr(self.effLen),
             ptr(self.Z_loc), ptr(self.Z_std_log), ptr(s["Z_loc"][0]), ptr(s["Z_loc"][1]), ptr(s["Z_std_log"][0]),
             ptr(s["Z_std_log"][1]), ptr(self.Wc_loc), ptr(s["Wc_loc"][0]), ptr(s["Wc_loc"][1]), ptr(self.intercept),
@@ -68,6 +77,11 @@ class COracle(object):
         self.t += n_steps
         self.draw += n_steps
         return trace
+
+    @property
+    def Psi(self):
+        from .brie_oracle import sigmoid
+        return sigmoid(self.Z_loc)
 
     def threads(self):
         return int(self.lib.brie_oracle_threads())

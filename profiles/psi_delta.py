@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""PSI-delta evidence: how far is the HIP path from the CPU reference, and how far is the reference's own
+fp32 precision from the precision-independent answer, after the FULL default schedules?
+
+    python profiles/psi_delta.py --out profiles/psi_delta_r02.json            (GPU box)
+    python profiles/psi_delta.py --oracles-only                               (no GPU: fills the oracle cache)
+
+For every case the same seeded problem (same init, same Philox noise stream) is run through
+  hip        libbrie_amd.so as built by default (hardware transcendentals, v_rcp/v_sqrt in the Adam update)
+  hip_adam   -DBRIE_STRICT_ADAM=1: IEEE division + square root in the Adam update only
+  hip_strict -DBRIE_FAST_MATH=0: ocml transcendentals + IEEE division / square root everywhere
+  o32        oracle/brie_oracle.c in fp32 (the reference's precision, operation by operation)
+  o64        the same code in fp64 (precision-independent answer)
+and |dPsi| is summarised for the pairs that matter: max, p99, p99.9, fraction > 1e-4, the same restricted to
+entries with c1 + c2 > 0 ("covered"), and which share of the exceedances are zero-coverage entries.
+Schedules: BRIE2.fit defaults (6 x 166 = 996 steps, MC_size 1; model_TFProb.py:214-241) and the brie-quant
+defaults (6 x 833 = 4998 steps, MC_size 3; bin/quant.py:173-177).  Genes are independent (model_wrap.py:241),
+so a gene sample over ALL cells of configs[1] / configs[2] is exact for those genes.
+The oracle is the checker here, never the thing measured.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+CACHE = os.path.join(ROOT, "profiles", "_psi_cache")
+
+CASES = {
+    # name: Nc, Ng, Kc, L, theta, min_iter, MC
+    "c1_api": dict(Nc=200, Ng=500, Kc=1, L=2, theta=3.0, min_iter=1000, MC=1,
+                   desc="configs[0] 200 x 500 (+1 covariate), BRIE2.fit default schedule: 996 steps, MC_size 1"),
+    "c1_kc0_api": dict(Nc=200, Ng=500, Kc=0, L=2, theta=3.0, min_iter=1000, MC=1,
+                       desc="configs[0] 200 x 500, no covariate, 996 steps, MC_size 1"),
+    "c1_cli": dict(Nc=200, Ng=500, Kc=1, L=2, theta=3.0, min_iter=5000, MC=3,
+                   desc="configs[0] 200 x 500 (+1 covariate), brie-quant default schedule: 4998 steps, MC_size 3"),
+    "c2_api": dict(Nc=10000, Ng=64, Kc=1, L=3, theta=1.5, min_iter=1000, MC=1,
+                   desc="configs[1] 10k cells, effLen, Kc=1: 64-gene sample over all cells, 996 steps, MC_size 1"),
+    "c2_cli": dict(Nc=10000, Ng=32, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3,
+                   desc="configs[1]: 32-gene sample over all cells, 4998 steps, MC_size 3"),
+    "c3_api": dict(Nc=50000, Ng=32, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1,
+                   desc="configs[2] 50k cells, Kc=3: 32-gene sample over all cells, 996 steps, MC_size 1"),
+    "c3_cli": dict(Nc=50000, Ng=16, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3,
+                   desc="configs[2]: 16-gene sample over all cells, 4998 steps, MC_size 3"),
+}
+QUICK = ("c1_api", "c1_kc0_api", "c2_api", "c3_api")
+SEED = 11
+VARIANTS = {"hip": [], "hip_adam": ["BRIE_STRICT_ADAM=1"], "hip_strict": ["BRIE_FAST_MATH=0"]}
+
+
+def problem(case):
+    from tests import util
+    c = CASES[case]
+    return util.problem(c["Nc"], c["Ng"], c["Kc"], c["L"], theta=c["theta"]), c
+
+
+def schedule(min_iter):
+    from oracle.brie_oracle import LEARNING_RATES
+    return [(int(min_iter / 6), lr) for lr in LEARNING_RATES]
+
+
+def run_oracle(case, dtype):
+    """Psi of the C restatement in `dtype` after the case's full staged schedule (cached)."""
+    os.makedirs(CACHE, exist_ok=True)
+    path = os.path.join(CACHE, "%s_%s.npz" % (case, np.dtype(dtype).name))
+    if os.path.exists(path):
+        return np.load(path)["psi"]
+    from oracle.c_oracle import COracle
+    P, c = problem(case)
+    t0 = time.time()
+    o = COracle(P["counts_pc"], P["Xc"], effLen=P["effLen"], seed=SEED, dtype=dtype)
+    for n, lr in schedule(c["min_iter"]):
+        o.reset_optimizer()
+        o.minimize(n, lr, c["MC"])
+    psi = np.asarray(o.Psi, np.float64)
+    np.savez_compressed(path, psi=psi, seconds=time.time() - t0)
+    print("oracle %s %s: %.1f s" % (case, np.dtype(dtype).name, time.time() - t0), flush=True)
+    return psi
+
+
+def run_hip_worker(case, out):
+    """(subprocess, BRIE_AMD_LIB selects the build) Psi of the HIP path after the full staged schedule."""
+    from brie_amd import _capi
+    from tests import util
+    P, c = problem(case)
+    sh = util.device_shard(P, c["Nc"], c["Ng"], c["Kc"], SEED)
+    t0 = time.time()
+    for n, lr in schedule(c["min_iter"]):
+        sh.reset_optimizer()
+        sh.step(n, lr, c["MC"], trace=False)
+    psi = sh.read(_capi.PSI)
+    np.savez_compressed(out, psi=psi, seconds=time.time() - t0)
+    sh.close()
+
+
+def summary(a, b, covered):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    ex = d > 1e-4
+    dc = d[covered]
+    out = {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "p99.9": float(np.percentile(d, 99.9)),
+           "frac_gt_1e-4": float(ex.mean()), "n_gt_1e-4": int(ex.sum()), "n": int(d.size),
+           "covered": {"max": float(dc.max()), "p99": float(np.percentile(dc, 99)),
+                       "p99.9": float(np.percentile(dc, 99.9)), "frac_gt_1e-4": float((dc > 1e-4).mean()),
+                       "n": int(dc.size)},
+           "share_of_exceedances_with_zero_coverage": float((ex & ~covered).sum() / max(1, ex.sum()))}
+    return out
+
+
+def build_variants():
+    from brie_amd.build import compile_library, LIB_DIR
+    paths = {}
+    for name, defs in VARIANTS.items():
+        if not defs:
+            paths[name] = compile_library()
+            continue
+        out = os.path.join(LIB_DIR, "libbrie_amd_%s.so" % name)
+        src_t = max(os.path.getmtime(os.path.join(ROOT, "brie_amd", "csrc", f))
+                    for f in os.listdir(os.path.join(ROOT, "brie_amd", "csrc")))
+        if not os.path.exists(out) or os.path.getmtime(out) < src_t:
+            compile_library(out=out, defines=defs)
+        paths[name] = out
+    return paths
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_r02.json"))
+    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--oracles-only", action="store_true")
+    ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--worker", default=None)
+    ap.add_argument("--worker-out", default=None)
+    args = ap.parse_args()
+    if args.worker:
+        run_hip_worker(args.worker, args.worker_out)
+        return
+    libs = build_variants()
+    if args.build_only:
+        print(libs)
+        return
+    cases = [c for c in args.cases.split(",") if c]
+    result = {"seed": SEED, "definition": __doc__.split("\n\n")[2].strip(), "cases": {}}
+    for case in cases:
+        P, c = problem(case)
+        covered = (np.asarray(P["counts"][0]) + np.asarray(P["counts"][1])) > 0
+        psi = {"o32": run_oracle(case, np.float32), "o64": run_oracle(case, np.float64)}
+        if args.oracles_only:
+            continue
+        secs = {}
+        for v in [v for v in args.variants.split(",") if v]:
+            tmp = os.path.join(CACHE, "_%s_%s.npz" % (case, v))
+            env = dict(os.environ, BRIE_AMD_LIB=libs[v])
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", case, "--worker-out", tmp],
+                           check=True, env=env)
+            z = np.load(tmp)
+            psi[v], secs[v] = z["psi"], float(z["seconds"])
+            os.remove(tmp)
+        pairs = [(v, "o64") for v in psi if v.startswith("hip")] + [(v, "o32") for v in psi if v.startswith("hip")] + \
+                [("o32", "o64")] + [("hip", v) for v in psi if v.startswith("hip_")]
+        entry = {"desc": c["desc"], "shape": [c["Nc"], c["Ng"]], "Kc": c["Kc"], "count_layers": c["L"],
+                 "steps": 6 * int(c["min_iter"] / 6), "MC_size": c["MC"],
+                 "zero_coverage_fraction": float(1 - covered.mean()), "hip_seconds": secs, "pairs": {}}
+        for a, b in pairs:
+            entry["pairs"]["%s_vs_%s" % (a, b)] = summary(psi[a], psi[b], covered)
+        result["cases"][case] = entry
+        f = entry["pairs"]
+        print("%-11s hip-o64 max %.2e p99.9 %.2e frac>1e-4 %.2e | o32-o64 max %.2e p99.9 %.2e frac %.2e | "
+              "strict-o64 max %.2e frac %.2e" % (
+                  case, f["hip_vs_o64"]["max"], f["hip_vs_o64"]["p99.9"], f["hip_vs_o64"]["frac_gt_1e-4"],
+                  f["o32_vs_o64"]["max"], f["o32_vs_o64"]["p99.9"], f["o32_vs_o64"]["frac_gt_1e-4"],
+                  f.get("hip_strict_vs_o64", {}).get("max", float("nan")),
+                  f.get("hip_strict_vs_o64", {}).get("frac_gt_1e-4", float("nan"))), flush=True)
+    if not args.oracles_only:
+        with open(args.out, "w") as fh:
+            json.dump(result, fh, indent=1)
+        print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

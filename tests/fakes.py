@@ -78,3 +78,91 @@ class OracleBackedBRIE2(object):
     intercept = property(lambda s: _w(s._o.intercept))
     Wc_loc = property(lambda s: _w(s._o.Wc_loc))
     Wg_loc = property(lambda s: _w(s._o.Wg_loc))
+
+
+class OracleShard(object):
+    """The `brie_amd._capi.Shard` surface that `BRIE2.fit` drives, answered by the CPU oracle: lets the CPU suite
+    run the engine's REAL control flow (stages, per-batch stopping, gene masks, collectives) without a GPU."""
+
+    def __init__(self, model, n_layers):
+        self.m, self.n_layers = model, n_layers
+        self.layers = [None] * n_layers
+        self.Xc = self.Xg = None
+        self.pc = None
+        self.target = "ELBO"
+        self.o = None
+
+    def upload(self, which, x):
+        from brie_amd import _capi
+        a = np.asarray(x.toarray() if hasattr(x, "toarray") else x, np.float32)
+        if which in (_capi.COUNT1, _capi.COUNT2, _capi.COUNT3):
+            self.layers[which - _capi.COUNT1] = a.copy()
+        elif which == _capi.XC:
+            self.Xc = a
+        elif which == _capi.XG:
+            self.Xg = a
+
+    def add_pseudo_count(self, pc):
+        self.pc = pc
+
+    def init_state(self, intercept=None, sigma=None):
+        m = self.m
+        self.o = OracleBRIE2(m.Nc, m.Ng, m.Kc, effLen=m.effLen, intercept=intercept, sigma=sigma, seed=m.seed,
+                             gene_offset=m.gene_offset, dtype=np.float32, Kg=m.Kg, intercept_mode=m.intercept_mode)
+
+    def _data(self):
+        return add_pseudo_count(self.layers, self.pc) if self.pc else self.layers
+
+    def set_target(self, target):
+        self.target = target
+
+    def reset_optimizer(self):
+        self.o.reset_optimizer()
+
+    def step(self, n_steps, lr, mc_size=1, trace=True):
+        self.o.Xg = self.Xg
+        return np.asarray(self.o.minimize(self._data(), self.Xc, int(n_steps), lr, mc_size, self.target), np.float32)
+
+    def set_gene_mask(self, active=None):
+        self.o.gene_active = np.ones(self.m.Ng, bool) if active is None else np.asarray(active, bool)
+
+    def read_loss_window(self, n_last):
+        return np.asarray(self.o.lg_hist[-int(n_last):], np.float32)
+
+    def loss_gene(self, n_repeats=500):
+        return np.asarray(self.o.eval_loss_gene(self._data(), self.Xc, n_repeats, self.target), np.float32)
+
+    def read(self, which):
+        from brie_amd import _capi
+        o = self.o
+        return np.asarray({_capi.Z_LOC: lambda: o.Z_loc, _capi.Z_STD_LOG: lambda: o.Z_std_log, _capi.Z_STD: lambda: o.Z_std,
+                           _capi.PSI: lambda: o.Psi, _capi.PSI95CI: lambda: o.Psi95CI, _capi.SIGMA: lambda: o.sigma,
+                           _capi.SIGMA_LOG: lambda: o.sigma_log, _capi.INTERCEPT: lambda: o.intercept,
+                           _capi.WC_LOC: lambda: o.Wc_loc, _capi.WG_LOC: lambda: o.Wg_loc}[which](), np.float32)
+
+    draw = property(lambda s: s.o.draw, lambda s, v: setattr(s.o, "draw", int(v)))
+
+    def close(self):
+        pass
+
+
+def engine_on_oracle():
+    """`brie_amd.BRIE2` (the real host engine) with `OracleShard` as its backend."""
+    from brie_amd.models.engine import BRIE2
+
+    class EngineOnOracle(BRIE2):
+        instances = []
+
+        def __init__(self, *a, **kw):
+            BRIE2.__init__(self, *a, **kw)
+            EngineOnOracle.instances.append(self)
+
+        def _new_shard(self, n_layers):
+            return OracleShard(self, n_layers)
+
+        @staticmethod
+        def free_device_memory(device=0):
+            return EngineOnOracle.free_bytes
+
+    EngineOnOracle.free_bytes = 1 << 62
+    return EngineOnOracle

@@ -75,3 +75,66 @@ def test_gene_sharded_fit_world2_gloo(tmp_path):
     # rank 0 holds the gathered layer, rank 1 only its shard
     np.testing.assert_allclose(r0["Psi_full"], ref.Psi, atol=2e-6)
     assert r1["Psi_full"].size == 0 and bool(r0["has_shard"]) and bool(r1["has_shard"])
+
+
+# ---- the engine's real fit loop (brie_amd.BRIE2 over tests.fakes.OracleShard) on two ranks -------------------
+def _engine_worker(rank, world, port, out_dir, case):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brie_amd.models.wrap as wrap
+    from brie_amd.sharding import GeneComm
+    from tests.fakes import FakeAnnData, engine_on_oracle
+    wrap.BRIE2 = engine_on_oracle()
+    P, kw = _engine_case(case)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    res = wrap.fitBRIE(ad, Xc=P["Xc"], comm=GeneComm(), **kw)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), sigma=res.sigma, cell_coeff=res.cell_coeff,
+             loss_gene=res.loss_gene, Psi=res.Psi, gene_range=np.array(res.gene_range), n_losses=len(res.losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _engine_case(case):
+    P = make_problem(30, 26, Kc=1, L=2, seed=14, depth=6.0)       # 26 genes -> 16 + 10 (quad boundary) or 24 + 2
+    base = dict(n_loss_gene=3, verbose=False)
+    if case == "conv":        # per-batch stopping with extensions; 8-gene batches, the third straddles the ranks
+        return P, dict(base, batch_size=30 * 8, min_iter=120, max_iter=200, add_iter=10, epsilon_conv=0.1)
+    if case == "straddle":    # one 28-gene batch > the shards: quad-aligned shards, the batch is decided on both ranks' sums
+        return P, dict(base, batch_size=30 * 28, min_iter=120, max_iter=200, add_iter=10, epsilon_conv=0.02)
+    if case == "split":       # unequal shards + sequential super-batches: the split must be a collective decision
+        return P, dict(base, batch_size=30 * 4, max_genes_per_fit=12, min_iter=60, max_iter=60)
+    if case == "emulate":     # literal reference batches: ranks run different numbers of independent fits
+        return P, dict(base, batch_size=30 * 8, emulate_batches=True, min_iter=60, max_iter=80, add_iter=10,
+                       epsilon_conv=0.1)
+    raise KeyError(case)
+
+
+@pytest.mark.parametrize("case", ["conv", "straddle", "split", "emulate"])
+def test_sharded_engine_loop_equals_single_process(tmp_path, case):
+    """(a) ranks must agree on the number of sequential parts (unequal shards, max_genes_per_fit /
+    emulate_batches used to end in mismatched collectives), (b) per-batch stopping must not depend on the world
+    size (batches anchored on the global gene index; a batch that straddles two ranks stops as one)."""
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(2, port, str(tmp_path), case), nprocs=2, join=True)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(2)]
+    import brie_amd.models.wrap as wrap
+    from tests.fakes import FakeAnnData, engine_on_oracle
+    saved = wrap.BRIE2
+    wrap.BRIE2 = E = engine_on_oracle()
+    try:
+        P, kw = _engine_case(case)
+        ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+        ref = wrap.fitBRIE(ad, Xc=P["Xc"], **kw)
+    finally:
+        wrap.BRIE2 = saved
+    if case == "conv":
+        assert len(set(E.instances[0].n_iter_batch)) > 1, E.instances[0].n_iter_batch   # batches really stop apart
+    assert r[0]["gene_range"][1] == r[1]["gene_range"][0] and r[1]["gene_range"][1] == 26
+    assert r[0]["gene_range"][1] - r[0]["gene_range"][0] != r[1]["gene_range"][1] - r[1]["gene_range"][0]
+    for key in ("sigma", "cell_coeff", "loss_gene"):
+        np.testing.assert_array_equal(r[0][key], r[1][key])
+        np.testing.assert_array_equal(r[0][key], getattr(ref, key))          # same oracle arithmetic per gene
+    np.testing.assert_array_equal(np.concatenate([r[0]["Psi"], r[1]["Psi"]], axis=1), ref.Psi)
+    if case == "straddle":
+        assert 20 < int(r[0]["n_losses"]) == len(ref.losses) < 100          # extended, and stopped before max_iter

@@ -10,12 +10,14 @@ Kc=3) through properties that do not need the oracle to process 10^9 elements:
 import numpy as np
 import pytest
 
+from tests.util import psi_parity_assert
+
 pytestmark = pytest.mark.gpu
 
 STEPS = 12
 
 
-def _generate(torch, dev, cfg, seed):
+def _generate(torch, dev, cfg, seed, with_eff=False):
     import bench
     Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
     gx = torch.Generator(device=dev)
@@ -25,12 +27,99 @@ def _generate(torch, dev, cfg, seed):
     Xc[:, 1:] = torch.randn(Nc, Kc - 1, generator=gx, device=dev)
     size = torch.exp(0.5 * torch.randn(Nc, generator=gx, device=dev))
     layers = [torch.empty(Nc, Ng, device=dev) for _ in range(L)]
+    eff_all = torch.zeros(Ng, 6, device=dev) if L == 3 else None
     for c0 in range(0, Ng, bench.GEN_CHUNK):
         c1 = min(c0 + bench.GEN_CHUNK, Ng)
-        cnt, _ = bench.gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
+        cnt, eff = bench.gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
         for l in range(L):
             layers[l][:, c0:c1] = cnt[l]
+        if eff is not None:
+            eff_all[c0:c1] = eff
+    if with_eff:
+        return Xc, layers, eff_all
     return Xc, layers
+
+
+def test_full_size_config2(lib):
+    """BASELINE configs[1] at full size: 10k cells x 5k exon-skipping events, 3 count layers + effLen
+    (model_TFProb.py:168-185), 1 cell covariate.  Scattered gene quads over all 10k cells against the fp32
+    oracle (MC_size 1 and the brie-quant default 3), gene-shard invariance bit for bit, and PSI after a staged
+    mini-schedule against the fp64 oracle."""
+    import torch
+    import bench
+    from brie_amd import _capi
+    from oracle.brie_oracle import OracleBRIE2, add_pseudo_count, LEARNING_RATES
+    dev = torch.device("cuda", 0)
+    cfg = bench.CONFIGS["c2"]
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 20240617 + 2
+    Xc, layers, eff = _generate(torch, dev, cfg, seed, with_eff=True)
+    eff_h, Xc_h = eff.cpu().numpy(), Xc.cpu().numpy()
+    assert layers[2].sum().item() > 0                      # the ambiguous layer is really used
+
+    def fresh(g0=0, g1=Ng):
+        sh = _capi.Shard(Nc, g1 - g0, Kc, n_layers=3, has_efflen=True, seed=seed, gene_offset=g0)
+        for l in range(3):
+            sh.upload(_capi.COUNT1 + l, layers[l][:, g0:g1])
+        sh.add_pseudo_count(0.01)
+        sh.upload(_capi.EFFLEN, eff_h[g0:g1])
+        sh.upload(_capi.XC, Xc)
+        sh.init_state()
+        return sh
+
+    for mc, steps in ((1, STEPS), (3, 6)):
+        sh = fresh()
+        trace = sh.step(steps, 0.01, mc)
+        assert np.all(np.isfinite(trace)) and trace[-1] < trace[0]
+        zloc, zsl = sh.read(_capi.Z_LOC), sh.read(_capi.Z_STD_LOG)
+        psi = sh.read(_capi.PSI)
+        W, b, lam = sh.read(_capi.WC_LOC), sh.read(_capi.INTERCEPT), sh.read(_capi.SIGMA_LOG)
+        assert psi.min() > 0 and psi.max() < 1 and np.abs(zloc).max() <= 9.0
+        lsum = 0.0
+        for g0 in (0, 2488, 3332, 4996):
+            cols = slice(g0, g0 + 4)
+            cnt = add_pseudo_count([layers[l][:, cols].cpu().numpy() for l in range(3)])
+            o = OracleBRIE2(Nc, 4, Kc, effLen=eff_h[cols], seed=seed, gene_offset=g0, dtype=np.float32)
+            tr = o.minimize(cnt, Xc_h, steps, 0.01, mc)
+            lsum += float(tr[0])
+            for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
+                                       ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
+                                       ("sigma_log", lam[:, cols], o.sigma_log)):
+                d = np.abs(dev_arr - ref)
+                assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (mc, g0, name, float(d.max()))
+            d = np.abs(psi[:, cols] - o.Psi)
+            assert d.max() < 5e-4 and np.percentile(d, 99) < 1e-5, (mc, g0, float(d.max()))
+        if mc == 1:
+            # gene-shard invariance (what a rank of an 8-way split holds: 628 genes starting at a quad boundary)
+            s0, s1 = 1256, 1884
+            part = fresh(s0, s1)
+            part.step(steps, 0.01, mc, trace=False)
+            np.testing.assert_array_equal(part.read(_capi.Z_LOC), zloc[:, s0:s1])
+            np.testing.assert_array_equal(part.read(_capi.Z_STD_LOG), zsl[:, s0:s1])
+            np.testing.assert_array_equal(part.read(_capi.WC_LOC), W[:, s0:s1])
+            np.testing.assert_array_equal(part.read(_capi.SIGMA_LOG), lam[:, s0:s1])
+            part.close()
+        sh.close()
+
+    # staged mini-schedule (6 stages x 30 steps, fresh Adam per stage) on the whole config, one quad vs fp64
+    sh = fresh()
+    g0 = 2024
+    cnt = add_pseudo_count([layers[l][:, g0:g0 + 4].cpu().numpy() for l in range(3)])
+    o64 = OracleBRIE2(Nc, 4, Kc, effLen=eff_h[g0:g0 + 4], seed=seed, gene_offset=g0, dtype=np.float64)
+    o32 = OracleBRIE2(Nc, 4, Kc, effLen=eff_h[g0:g0 + 4], seed=seed, gene_offset=g0, dtype=np.float32)
+    for lr in LEARNING_RATES:
+        sh.reset_optimizer()
+        sh.step(30, lr, 1, trace=False)
+        for o in (o64, o32):
+            o.reset_optimizer()
+            o.minimize(cnt, Xc_h, 30, lr, 1)
+    d = np.abs(sh.read(_capi.PSI)[:, g0:g0 + 4] - o64.Psi)
+    d32 = np.abs(o32.Psi - o64.Psi)
+    print("C2 PSI delta after 180 staged steps: HIP max %.3g p99.9 %.3g frac>1e-4 %.3g | fp32 oracle max %.3g "
+          "p99.9 %.3g frac %.3g" % (d.max(), np.percentile(d, 99.9), (d > 1e-4).mean(), d32.max(),
+                                     np.percentile(d32, 99.9), (d32 > 1e-4).mean()))
+    psi_parity_assert(d, d32)
+    sh.close()
 
 
 def test_full_size_config3(lib):

@@ -240,3 +240,23 @@ def test_per_batch_convergence_equals_sequential_reference_batches(patched_wrap)
     np.testing.assert_allclose(con.Psi, seq.Psi, atol=1e-5)
     np.testing.assert_allclose(con.cell_coeff, seq.cell_coeff, atol=1e-5)
     np.testing.assert_allclose(con.sigma, seq.sigma, atol=1e-5)
+
+
+def test_fitBRIE_missing_unique_layer_raises_keyerror(patched_wrap):
+    """model_wrap.py:247,262 index adata.layers[key]: a missing / misspelt unique layer is a KeyError at once; only
+    the optional third layer may be absent."""
+    P = make_problem(12, 8, Kc=0, L=2, seed=2)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform_2': P["counts"][1]})
+    with pytest.raises(KeyError, match="isoform2"):
+        patched_wrap.fitBRIE(ad, **FIT)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    patched_wrap.fitBRIE(ad, **FIT)                                        # no 'ambiguous' layer: fine
+    assert ad.uns['brie_param']['layer_keys'] == ['isoform1', 'isoform2']
+
+
+def test_gene_shard_alignment():
+    from brie_amd.sharding import gene_shard
+    assert [gene_shard(20000, r, 8, 20) for r in (0, 7)] == [(0, 2500), (17500, 20000)]
+    assert gene_shard(26, 1, 2, 8) == (16, 26) and gene_shard(26, 1, 2, 28) == (26, 26)
+    with pytest.raises(ValueError):
+        gene_shard(26, 0, 2, 6)

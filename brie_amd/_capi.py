@@ -15,7 +15,7 @@ from .build import LIB_PATH
 COUNT1, COUNT2, COUNT3, XC, EFFLEN, XG = 0, 1, 2, 3, 4, 5
 Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_KC = 64          # 0..8 in registers, 9..64 with the W tile in LDS + an MFMA kernel for Xc^T.r
 MAX_KG = 64
 
@@ -27,7 +27,10 @@ EXPORTS = [
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
     "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts", "brie_device_memory",
     "brie_last_error", "brie_abi_version",
+    "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
+    "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
 ]
+COMM_ID_BYTES = 128
 
 
 class BrieProblem(ctypes.Structure):
@@ -101,17 +104,79 @@ def load_library(path=None):
     lib.brie_step_storage_bytes.restype = i64
     lib.brie_set_count_storage.argtypes = [vp, i32]
     lib.brie_get_count_storage.argtypes = [vp]
+    lib.brie_comm_unique_id.argtypes = [vp]
+    lib.brie_comm_init.argtypes = [i32, i32, i32, vp, ctypes.POINTER(vp)]
+    lib.brie_comm_destroy.argtypes = [vp]
+    lib.brie_comm_rank.argtypes = [vp]
+    lib.brie_comm_world.argtypes = [vp]
+    lib.brie_comm_allgather.argtypes = [vp, vp, i64, vp]
+    lib.brie_comm_allreduce.argtypes = [vp, vp, i64, i32, i32]
+    lib.brie_attach_comm.argtypes = [vp, vp]
     lib.brie_last_error.restype = ctypes.c_char_p
     lib.brie_abi_version.restype = ctypes.c_int
     for name in EXPORTS:
         if name not in ("brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_last_error",
-                        "brie_abi_version"):
+                        "brie_abi_version", "brie_comm_rank", "brie_comm_world"):
             getattr(lib, name).restype = ctypes.c_int
     if lib.brie_abi_version() != ABI_VERSION:
         raise ImportError("libbrie_amd.so ABI %d != binding %d" % (lib.brie_abi_version(), ABI_VERSION))
     if path == os.environ.get("BRIE_AMD_LIB", LIB_PATH):
         _lib = lib
     return lib
+
+
+class Comm(object):
+    """`brie_comm`: an RCCL communicator created through the C ABI (one per process / GPU).
+
+    `unique_id()` on rank 0 -> hand the 128 bytes to every rank (any transport) -> `Comm(device, rank, world, id)`."""
+
+    @staticmethod
+    def unique_id():
+        lib = load_library()
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+        _check(lib, lib.brie_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, device, rank, world, unique_id):
+        self.lib = load_library()
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % COMM_ID_BYTES)
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._c = ctypes.c_void_p()
+        _check(self.lib, self.lib.brie_comm_init(int(device), int(rank), int(world), ctypes.cast(buf, ctypes.c_void_p),
+                                                 ctypes.byref(self._c)))
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    def allgather(self, send):
+        """(n,) float32 per rank -> (world, n) on every rank."""
+        send = np.ascontiguousarray(send, np.float32).ravel()
+        out = np.empty((self.world, send.size), np.float32)
+        _check(self.lib, self.lib.brie_comm_allgather(self._c, send.ctypes.data, send.size, out.ctypes.data))
+        return out
+
+    def allreduce(self, a, op="sum"):
+        """In-place-style reduction of a host float32 / float64 array over ranks; returns the reduced copy."""
+        a = np.array(a, dtype=np.float64 if np.asarray(a).dtype == np.float64 else np.float32, copy=True)
+        a = np.ascontiguousarray(a)
+        _check(self.lib, self.lib.brie_comm_allreduce(self._c, a.ctypes.data, a.size, 1 if a.dtype == np.float64 else 0,
+                                                      {"sum": 0, "max": 1, "min": 2}[op]))
+        return a
+
+    def allreduce_device(self, ptr, count, dtype="f32", op="sum"):
+        """In place on a device buffer (raw pointer)."""
+        _check(self.lib, self.lib.brie_comm_allreduce(self._c, ctypes.c_void_p(int(ptr)), int(count),
+                                                      {"f32": 0, "f64": 1}[dtype], {"sum": 0, "max": 1, "min": 2}[op]))
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self.lib.brie_comm_destroy(self._c)
+            self._c = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _check(lib, rc):
@@ -121,6 +186,8 @@ def _check(lib, rc):
             raise ValueError("brie_amd: " + msg)
         if rc == -4:
             raise NotImplementedError("brie_amd: " + msg)
+        if rc == -5:
+            raise BrieError("brie_amd (RCCL): " + msg)
         raise BrieError("brie_amd (status %d): %s" % (rc, msg))
 
 
@@ -298,6 +365,11 @@ class Shard(object):
             _check(self.lib, self.lib.brie_step_end(self._h, ctypes.byref(loss)))
             out[i] = loss.value
         return out
+
+    def attach_comm(self, comm):
+        """Sharded coupled fit: all-reduce the per-cell statistics inside brie_step (None detaches)."""
+        _check(self.lib, self.lib.brie_attach_comm(self._h, comm._c if comm is not None else None))
+        self._comm_keepalive = comm
 
     def set_gene_mask(self, active=None):
         """Per-gene train mask (bool (Ng,)); None = all genes active."""

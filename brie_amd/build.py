@@ -2,7 +2,7 @@
 
     python -m brie_amd.build
 
-Translation units: brie_capi.hip (C ABI + small kernels) and brie_inst.hip once per cell-feature
+Translation units: brie_capi.hip (C ABI + small kernels), brie_comm.hip (RCCL entry points) and brie_inst.hip once per cell-feature
 count KC = 0..8 (the template instantiations of the two streaming kernels), compiled in parallel
 and linked into brie_amd/lib/libbrie_amd.so.
 """
@@ -16,9 +16,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbrie_amd.so")
-SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip")]
+SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip"), os.path.join(CSRC, "brie_comm.hip")]
 HEADERS = [os.path.join(CSRC, "brie_kernels.hip.h"), os.path.join(CSRC, "brie_launch.h"),
-           os.path.join(ROOT, "include", "brie_amd.h")]
+           os.path.join(CSRC, "brie_comm_internal.h"), os.path.join(ROOT, "include", "brie_amd.h")]
 MAX_KC = 8
 
 
@@ -50,7 +50,8 @@ def compile_library(force=False, fast_math=None, verbose=False, out=None, define
     if fast_math is not None:
         base.append("-DBRIE_FAST_MATH=%d" % int(fast_math))
     base += ["-D" + d for d in defines]
-    units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), [])]
+    units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), []),
+             (os.path.join(CSRC, "brie_comm.hip"), os.path.join(obj_dir, "brie_comm.o"), [])]   # RCCL, bound by dlopen
     for kc in range(MAX_KC + 1):
         units.append((os.path.join(CSRC, "brie_inst.hip"), os.path.join(obj_dir, "brie_inst_kc%d.o" % kc),
                       ["-DBRIE_KC=%d" % kc]))
@@ -65,7 +66,7 @@ def compile_library(force=False, fast_math=None, verbose=False, out=None, define
 
     with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(cc, units))
-    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True)

@@ -4,6 +4,7 @@
 #include "brie_amd.h"
 #define BRIE_HOST_TU 1
 #include "brie_launch.h"
+#include "brie_comm_internal.h"
 
 #include <algorithm>
 #include <cmath>
@@ -43,8 +44,12 @@ inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 }  // namespace
 
+// brie_comm.hip reports its failures through the same thread-local message
+extern "C" int brie_internal_fail(int code, const char *msg) { return fail(code, "%s", msg); }
+
 struct brie_handle {
     brie_problem p{};
+    brie_comm *comm = nullptr;      // attached communicator: sharded coupled fits all-reduce rowstat in-library
     int64_t ld = 0;                 // gene_blocks * 256: pitch of per-gene vectors and of row-major matrices
     int64_t row_stride = 0, gb_stride = 0;   // matrix addressing (see StepScalars)
     bool tiled = true;              // gene-block-major tiles [gene block][cell][256 genes]
@@ -919,9 +924,10 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (rc != BRIE_OK) return rc;
     if (n_steps < 0 || mc_size < 1) return fail(BRIE_ERR_INVALID, "n_steps=%d mc_size=%d", n_steps, mc_size);
     if (h->step_open) return fail(BRIE_ERR_STATE, "brie_step_begin without brie_step_end");
-    if (split == 0 && h->coupled && h->p.sharded != 0)
-        return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: use brie_step_begin / "
-                    "all-reduce brie_rowstat_buffer / brie_step_end");
+    const bool lib_reduce = h->coupled && h->p.sharded != 0 && h->comm != nullptr;
+    if (split == 0 && h->coupled && h->p.sharded != 0 && !lib_reduce)
+        return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: attach a communicator "
+                    "(brie_attach_comm) or use brie_step_begin / all-reduce brie_rowstat_buffer / brie_step_end");
     if (h->target == 1 && (h->coupled || h->wide))
         return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts / Kc > %d is not built",
                     BRIE_MAX_KC);
@@ -1004,7 +1010,15 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
         if (h->wide && (rc = wide_backward(h, alpha)) != BRIE_OK) return rc;     // G = Xc^T . r (MFMA), Adam on Wc_loc
-        if (h->coupled)
+        if (h->coupled && lib_reduce && !split) {
+            // gene shard of a coupled fit: local sums -> RCCL all-reduce on this stream -> Adam, all enqueued
+            brie::CellFinalizeArgs c1 = cf, c2 = cf;
+            c1.phase = 1; c2.phase = 2;
+            hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, c1);
+            if ((rc = brie::comm_allreduce_sum_f32_async(h->comm, cf.rowstat, static_cast<int64_t>(h->kgp + 2) * h->p.Nc,
+                                                         h->stream)) != BRIE_OK) return rc;
+            hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, c2);
+        } else if (h->coupled)
             hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, cf);
     }
     HIP_TRY(hipGetLastError());
@@ -1039,6 +1053,16 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
 
 int brie_step_begin(brie_handle *h, float lr, int32_t mc_size) { return run_steps(h, 1, lr, mc_size, nullptr, 1); }
 
+int brie_attach_comm(brie_handle *h, brie_comm *c) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (h->step_open) return fail(BRIE_ERR_STATE, "a step is open");
+    if (c && brie::comm_device(c) != h->p.device)
+        return fail(BRIE_ERR_INVALID, "communicator lives on device %d, the handle on device %d", brie::comm_device(c),
+                    h->p.device);
+    h->comm = c;
+    return BRIE_OK;
+}
+
 int brie_rowstat_buffer(brie_handle *h, float **dev, int64_t *n_floats) {
     if (!h || !dev || !n_floats) return fail(BRIE_ERR_INVALID, "null argument");
     if (!h->coupled) return fail(BRIE_ERR_STATE, "no per-cell statistics: Kg == 0 and intercept_mode 'gene'");
@@ -1064,6 +1088,10 @@ int brie_step_end(brie_handle *h, float *loss) {
     if (h->coupled) {
         brie::CellFinalizeArgs cf = h->pending_cf;
         cf.phase = 2;
+        if (h->comm && h->p.sharded != 0 &&
+            (rc = brie::comm_allreduce_sum_f32_async(h->comm, cf.rowstat, static_cast<int64_t>(h->kgp + 2) * h->p.Nc,
+                                                     h->stream)) != BRIE_OK)
+            return rc;
         hipLaunchKernelGGL(brie::cell_finalize, dim3(cell_finalize_blocks(h)), dim3(brie::kBlock), 0, h->stream, cf);
         HIP_TRY(hipGetLastError());
     }

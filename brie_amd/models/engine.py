@@ -265,12 +265,21 @@ class BRIE2(object):
         sh = self._ensure_shard(count_layers, Xc, Xg)
         sh.set_target(target)
 
-        if self._comm is not None and self._stat is None:
-            import torch
-            self._stat = torch.zeros(sh.rowstat_size(), dtype=torch.float32, device=torch.device("cuda", self.device))
+        native = None
+        if self._comm is not None:
+            # coupled gene shard: the per-cell statistics are all-reduced every step.  On RCCL the exchange runs
+            # INSIDE brie_step on the handle's stream (brie_attach_comm); otherwise (gloo: CPU tests, two ranks on
+            # one GPU) through brie_step_begin / torch all-reduce / brie_step_end.
+            native = self._comm.native_comm(self.device) if hasattr(self._comm, "native_comm") else None
+            if native is not None:
+                sh.attach_comm(native)
+            elif self._stat is None:
+                import torch
+                self._stat = torch.zeros(sh.rowstat_size(), dtype=torch.float32,
+                                         device=torch.device("cuda", self.device))
 
         def run(n_steps, lr):
-            if self._comm is not None:          # coupled gene shard: per-step all-reduce of per-cell statistics
+            if self._comm is not None and native is None:
                 trace = sh.step_sharded(n_steps, lr, MC_size, self._comm.allreduce_inplace, self._stat)
             else:
                 trace = sh.step(n_steps, lr, MC_size)

@@ -42,6 +42,26 @@ class GeneComm(object):
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.device = device
+        self._native, self._native_tried = None, False
+
+    def native_comm(self, device=None):
+        """The library's own RCCL communicator (`brie_comm_*` of include/brie_amd.h) over the same ranks, or None.
+
+        Created once, when the process group runs on RCCL (backend "nccl": one rank per GPU); the 128-byte unique id
+        travels through torch.distributed's store -- torch is the rendezvous, the data path is librccl called from
+        libbrie_amd.so.  With gloo (CPU tests, two ranks sharing a GPU) there is no native communicator: RCCL
+        refuses two ranks on one device."""
+        if self._native is not None or self._native_tried:
+            return self._native
+        self._native_tried = True
+        if self.backend != "nccl":
+            return None
+        from . import _capi
+        box = [_capi.Comm.unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0, group=self.group)
+        dev = device if device is not None else (self.device.index if hasattr(self.device, "index") else self.device)
+        self._native = _capi.Comm(int(dev or 0), self.rank, self.world, box[0])
+        return self._native
 
     def _tensor(self, a, dtype=None):
         import torch

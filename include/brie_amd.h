@@ -33,14 +33,15 @@
 extern "C" {
 #endif
 
-#define BRIE_AMD_ABI_VERSION 1
+#define BRIE_AMD_ABI_VERSION 2
 
 typedef enum brie_status {
     BRIE_OK = 0,
     BRIE_ERR_INVALID = -1,      /* bad argument / shape                     */
     BRIE_ERR_STATE = -2,        /* call order: something not uploaded yet   */
     BRIE_ERR_HIP = -3,          /* HIP runtime failure (no GPU, OOM, ...)   */
-    BRIE_ERR_UNSUPPORTED = -4   /* mode outside the hot path built so far   */
+    BRIE_ERR_UNSUPPORTED = -4,  /* mode outside the hot path built so far   */
+    BRIE_ERR_COMM = -5          /* RCCL failure / librccl not loadable      */
 } brie_status;
 
 /* Arrays addressable through brie_upload / brie_read. */
@@ -160,6 +161,36 @@ int brie_step_begin(brie_handle *h, float lr, int32_t mc_size);
 int brie_rowstat_buffer(brie_handle *h, float **dev, int64_t *n_floats);
 int brie_set_rowstat_buffer(brie_handle *h, float *dev);
 int brie_step_end(brie_handle *h, float *loss);
+
+/* ---- Communication (SURVEY 8b sketch, 8e): RCCL over xGMI, one communicator per process ------------------
+ * The reference has no communication layer; its only scale-out device is sequential gene batching
+ * (model_wrap.py:241-260).  Here genes are sharded over the GPUs of a node, one process (rank) per GPU:
+ *   rank 0: brie_comm_unique_id(id)  ->  the caller hands `id` (BRIE_COMM_ID_BYTES) to every rank by its own
+ *   means (file, socket, MPI, torch.distributed store)  ->  every rank: brie_comm_init(device, rank, world, id, &c).
+ * librccl.so.1 is bound at run time; without it these calls return BRIE_ERR_COMM and the rest of the library works.
+ *  brie_comm_allgather: every rank contributes `count` floats, recv gets world*count in rank order -- the
+ *                       end-of-fit gather of per-gene vectors [Wc_loc, intercept, sigma, loss_gene] ("RCCL weight
+ *                       all-gather" of BASELINE configs[3]); 60-120 KB per rank, latency-bound.
+ *  brie_comm_allreduce: in place over `count` elements (dtype BRIE_F32 / BRIE_F64, op BRIE_SUM / MAX / MIN) -- the
+ *                       loss-trace windows of the global convergence rule (model_TFProb.py:250), timings.
+ *  Buffers may be host or device pointers; both calls return when the result is visible to the caller.
+ *  brie_attach_comm:    a handle created with sharded=1 (one gene shard of a COUPLED fit, Kg > 0 or
+ *                       intercept_mode 'cell') all-reduces its per-cell statistics INSIDE brie_step /
+ *                       brie_step_end, on the handle's own stream, between the local reduction and the Adam
+ *                       update of Wg_loc / per-cell intercept / sigma -- no host round trip per step.
+ *                       comm == NULL detaches.  The loss trace stays LOCAL (sum it with brie_comm_allreduce). */
+#define BRIE_COMM_ID_BYTES 128
+enum { BRIE_F32 = 0, BRIE_F64 = 1 };
+enum { BRIE_SUM = 0, BRIE_MAX = 1, BRIE_MIN = 2 };
+typedef struct brie_comm brie_comm;
+int brie_comm_unique_id(uint8_t *id_out /* BRIE_COMM_ID_BYTES */);
+int brie_comm_init(int32_t device, int32_t rank, int32_t world, const uint8_t *unique_id, brie_comm **out);
+int brie_comm_destroy(brie_comm *c);
+int brie_comm_rank(const brie_comm *c);
+int brie_comm_world(const brie_comm *c);
+int brie_comm_allgather(brie_comm *c, const float *send, int64_t count, float *recv);
+int brie_comm_allreduce(brie_comm *c, void *buf, int64_t count, int32_t dtype, int32_t op);
+int brie_attach_comm(brie_handle *h, brie_comm *c);
 
 /* model_TFProb.py:261-264: mean over `n_repeats` stochastic evaluations of
  * get_loss(axis=0) with MC_size = 1 -> out[Ng] (host). */

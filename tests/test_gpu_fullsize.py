@@ -236,18 +236,18 @@ def test_full_size_config3_staged_schedule_psi(lib):
     del layers
     torch.cuda.empty_cache()
     o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float64)
+    o32 = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
     Xc_h = Xc.cpu().numpy()
     for lr in LEARNING_RATES:
         sh.reset_optimizer()
-        o.reset_optimizer()
         sh.step(25, lr, 1, trace=False)
-        o.minimize(cnt, Xc_h, 25, lr, 1)
+        for oo in (o, o32):
+            oo.reset_optimizer()
+            oo.minimize(cnt, Xc_h, 25, lr, 1)
     d = np.abs(sh.read(_capi.PSI)[:, g0:g0 + 4] - o.Psi)
-    print("C3 PSI delta after 150 staged steps: max %.3g p99 %.3g p99.9 %.3g"
-          % (d.max(), np.percentile(d, 99), np.percentile(d, 99.9)))
-    # bulk bound + outlier bound: Adam's g/(sqrt(v)+eps) turns an fp32 rounding of a near-zero gradient into an
-    # O(lr) move for isolated (cell, gene) entries, exactly as the fp32 CPU oracle does against fp64
-    assert np.percentile(d, 99) < 1e-4 and np.percentile(d, 99.9) < 3e-4 and d.max() < 5e-3
+    d32 = np.abs(o32.Psi - o.Psi)
+    # the parity rule (tests/util.py): no more entries beyond 1e-4 than the reference's own fp32 precision produces
+    print("C3 PSI delta after 150 staged steps:", psi_parity_assert(d, d32, "C3 staged"))
     np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:g0 + 4], o.Wc_loc, atol=5e-4)
     sh.close()
 

@@ -6,10 +6,10 @@ Tolerances (floating point path; north star: PSI within 1e-4 of the CPU path):
     (Adam's first updates are lr*g/(|g|+eps'): an element whose gradient is
     ~1e-5 amplifies fp32 rounding differences by ~lr*1e-7/|g|, so the max is
     bounded separately from the bulk.)
-  * PSI after a staged fit: max |dPsi| <= 1e-4 vs the fp64 oracle is the
-    target; the fp32 oracle itself sits at ~1e-4 max / ~1e-5 p99 from the fp64
-    oracle (rounding-noise floor of the reference's own precision), so the
-    assertion is p99 <= 1e-4 and max <= 1e-3, and the measured values are printed.
+  * PSI after a staged fit: tests/util.py::psi_parity_assert -- the entries beyond
+    1e-4 of the fp64 oracle are counted and bounded by what the fp32 oracle (the
+    reference's own precision) produces on the same trajectory
+    (evidence: profiles/psi_delta_r02.json).
 """
 import numpy as np
 import pytest
@@ -30,7 +30,7 @@ def assert_states_close(so, sd, bulk=2e-5, worst=1e-3):
 
 
 def test_library_loads(lib):
-    assert lib.brie_abi_version() == 1
+    assert lib.brie_abi_version() == 2
 
 
 @pytest.mark.parametrize("gene_offset", [0, 1024])
@@ -116,9 +116,7 @@ def test_psi_after_staged_fit(lib, Nc, Ng, Kc, L, MC, min_iter):
     d_o32 = np.abs(o32.Psi - o64.Psi)
     print("PSI delta vs fp64 oracle: HIP max %.3g p99 %.3g | fp32 oracle max %.3g p99 %.3g"
           % (d_dev.max(), np.percentile(d_dev, 99), d_o32.max(), np.percentile(d_o32, 99)))
-    assert np.percentile(d_dev, 99) <= 1e-4
-    # worst element: no farther from the fp64 answer than ~the reference's own fp32 precision gets
-    assert d_dev.max() <= max(1e-3, 3 * d_o32.max())
+    util.psi_parity_assert(d_dev, d_o32, "Psi")            # the parity rule, stated once (tests/util.py)
     # same rule for the interval width and the prior width: bulk tight, worst element bounded by
     # what the reference's own precision (fp32 oracle) does on the same trajectory
     for name, dev, ref64, ref32 in (("Psi95CI", sh.read(_capi.PSI95CI), o64.Psi95CI, o32.Psi95CI),
@@ -127,6 +125,30 @@ def test_psi_after_staged_fit(lib, Nc, Ng, Kc, L, MC, min_iter):
         d32 = np.abs(ref32 - ref64)
         assert np.percentile(d, 99) <= max(2e-4, 3 * np.percentile(d32, 99)), (name, float(np.percentile(d, 99)))
         assert d.max() <= max(2e-3, 3 * d32.max()), (name, float(d.max()), float(d32.max()))
+
+
+@pytest.mark.parametrize("Kc", [0, 1])
+def test_psi_after_full_default_schedule(lib, Kc):
+    """configs[0] (200 x 500) through the WHOLE BRIE2.fit default schedule (6 x 166 steps, fresh Adam per stage,
+    model_TFProb.py:234-241), HIP vs the C restatement in fp64 and fp32 (oracle/brie_oracle.c)."""
+    from brie_amd import _capi
+    from oracle.c_oracle import COracle
+    Nc, Ng = 200, 500
+    P = util.problem(Nc, Ng, Kc, 2, theta=3.0)
+    seed = 11
+    o64 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float64)
+    o32 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32)
+    sh = util.device_shard(P, Nc, Ng, Kc, seed)
+    for n, lr in util.staged_schedule(1000):
+        for o in (o64, o32):
+            o.reset_optimizer()
+            o.minimize(n, lr, 1)
+        sh.reset_optimizer()
+        sh.step(n, lr, 1, trace=False)
+    d = np.abs(sh.read(_capi.PSI) - o64.Psi)
+    d32 = np.abs(o32.Psi - o64.Psi)
+    print("996 steps, Kc=%d:" % Kc, util.psi_parity_assert(d, d32, "Psi after 996 steps"))
+    sh.close()
 
 
 def test_loss_gene_matches_oracle(lib):

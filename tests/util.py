@@ -73,14 +73,23 @@ def psi_parity_assert(d, d32, what=""):
     d32 = |Psi_o32 - Psi_o64|   the reference's own precision (fp32 oracle) vs the same answer, same entries
 
     Keras Adam moves every entry by lr * m / (sqrt(v) + eps): where a gradient passes through ~0 the SIGN of an
-    fp32 rounding error decides an O(lr) move, so any two fp32 evaluations of the reference's arithmetic (TF on
-    another CPU included) differ by > 1e-4 on a small fraction of entries (profiles/psi_delta_r02.json).  Hence:
-      1. bulk:        99 % of the entries within 1e-4 (measured: p99 ~ 1e-5);
-      2. exceedances: #(d > 1e-4) <= 2 x #(d32 > 1e-4) + 5e-5 n  -- no more entries beyond the tolerance than the
-                      reference's own fp32 precision produces on this trajectory (factor 2 + a floor for counting noise);
-      3. worst entry: max d <= max(1e-4, 3 max d32)."""
+    fp32 rounding error decides an O(lr) move (a fresh optimiser's first step is +-lr whatever |g| is), so any two
+    fp32 evaluations of the reference's arithmetic -- TF on another CPU included -- differ by more than 1e-4 on a
+    fraction of the entries.  Measured after the full default schedules (profiles/psi_delta_r02.json): that fraction
+    is the same for HIP-vs-fp64 and fp32-oracle-vs-fp64 (C3: 3e-5 vs 1e-5, >90 % of them zero-coverage entries;
+    the 200-cell configs[0]: 6e-3 vs 5e-3 at 996 steps, 2.4e-2 vs 2.4e-2 at 4998), and strict IEEE math on the
+    device does not change it.  So parity = "as close to the precision-independent answer as the reference's own
+    fp32 arithmetic gets on the same trajectory":
+      1. bulk:        p99(d) <= max(1e-4, 1.5 p99(d32));
+      2. exceedances: #(d > 1e-4) <= 2 #(d32 > 1e-4) + 5e-5 n   (factor 2 and a floor for counting noise);
+      3. worst entry: max d <= max(2e-3, 3 max d32)   (a fifth of what ONE flipped +-lr step can do: 0.25 * 2 * 0.02)."""
     d, d32 = np.asarray(d, np.float64).ravel(), np.asarray(d32, np.float64).ravel()
     n, n32 = int((d > 1e-4).sum()), int((d32 > 1e-4).sum())
-    assert np.percentile(d, 99) <= 1e-4, (what, "p99", float(np.percentile(d, 99)))
+    assert np.percentile(d, 99) <= max(1e-4, 1.5 * np.percentile(d32, 99)), \
+        (what, "p99", float(np.percentile(d, 99)), float(np.percentile(d32, 99)))
     assert n <= 2 * n32 + 5e-5 * d.size, (what, "entries beyond 1e-4: HIP %d, fp32 oracle %d of %d" % (n, n32, d.size))
-    assert d.max() <= max(1e-4, 3 * d32.max()), (what, "max", float(d.max()), float(d32.max()))
+    assert d.max() <= max(2e-3, 3 * d32.max()), (what, "max", float(d.max()), float(d32.max()))
+    return {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "p99.9": float(np.percentile(d, 99.9)),
+            "frac_gt_1e-4": n / d.size, "fp32_oracle": {"max": float(d32.max()), "p99": float(np.percentile(d32, 99)),
+                                                         "p99.9": float(np.percentile(d32, 99.9)),
+                                                         "frac_gt_1e-4": n32 / d32.size}}

@@ -106,6 +106,59 @@ def psi_delta_check(seed=11):
     return out
 
 
+def hbm_traffic(args, world, storage):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC counters, collected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE
+    (KiB), FETCH_SIZE x2 on gfx950 for wide coalesced reads.  Measured LIVE by two child runs of this script (the
+    same workload, a few steps); falls back to the committed profile of the same workload when rocprofv3 is not there."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    committed = {}
+    try:
+        committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
+            "%s_%s" % (args.config, {"u8/u16 per gene block": "mixed"}.get(storage, storage))) or {}
+    except (OSError, ValueError):
+        pass
+    eligible = world == 1 and args.mc == 1 and args.kc is None and not args.emulate_shard_of
+    fallback = {"traffic": committed.get("hbm_bytes_per_launch") if eligible else None,
+                "traffic_source": ("committed: " + committed.get("source", "profiles/pmc_traffic.json")) if (eligible and committed)
+                else None}
+    if args.no_pmc or world != 1 or not shutil.which("rocprofv3"):
+        return fallback
+    n_steps, kib = 4, {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            tmp = tempfile.mkdtemp(prefix="brie_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", str(n_steps - 1), "--warmup", "1",
+                   "--config", args.config, "--mc", str(args.mc), "--count-storage", args.count_storage,
+                   "--no-cpu-baseline", "--no-psi-check"]
+            if args.kc is not None:
+                cmd += ["--kc", str(args.kc)]
+            if args.rows_per_chunk:
+                cmd += ["--rows-per-chunk", str(args.rows_per_chunk)]
+            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=600)
+            total = 0.0
+            for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "elbo_adam_step" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        total += float(r["Counter_Value"])
+            shutil.rmtree(tmp, ignore_errors=True)
+            if total <= 0:
+                raise RuntimeError("no %s samples of elbo_adam_step" % counter)
+            kib[counter] = total / n_steps
+        return {"traffic": (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0,
+                "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (%d launches each; "
+                                  "KiB; FETCH_SIZE x2 gfx950 correction)" % n_steps,
+                "FETCH_SIZE_KiB_per_launch": kib["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": kib["WRITE_SIZE"]}
+    except Exception as exc:
+        return dict(fallback, traffic_error=repr(exc))
+
+
 def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank, dev, Xc, size, elapsed_local):
     """What fitBRIE does when the loop is over (brie_amd/models/wrap.py): every rank contributes the per-gene
     vectors [Wc_loc (Kc rows), intercept, sigma, loss_gene] of its gene shard and receives all Ng columns.
@@ -204,6 +257,10 @@ def main():
                          "time of the strong-scaling run without N GPUs); the line is labelled and is not a result")
     ap.add_argument("--count-storage", default="auto", choices=["auto", "f32"],
                     help="auto: integer counts <= 255 are kept as u8 in HBM (bit-identical results); f32: as uploaded")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (N=1 only)")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg with fp32 count storage")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psi-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -319,6 +376,9 @@ def main():
     sh.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    if args.pmc_child:                       # run under rocprofv3 --pmc by the parent bench: the launches are all it needs
+        sh.close()
+        return
     elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -336,6 +396,17 @@ def main():
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last
     psi_dev = sh.read(_capi.PSI) if (rank == 0 and world == 1 and not args.no_psi_check) else None
+    f32_leg = None
+    storage_main, storage_bytes_main = sh.count_storage, sh.step_storage_bytes()
+    if rank == 0 and world == 1 and not args.no_f32_leg and storage_main != "f32":
+        # the same kernel on the fp32 layers as uploaded (compact storage is reported separately)
+        sh.set_count_storage(1)
+        sh.step(args.warmup, lr, args.mc, trace=False)
+        sh.profile_enable(True)
+        sh.step(args.steps, lr, args.mc, trace=False)
+        ms32, n32 = sh.profile_read()
+        sh.profile_enable(False)
+        f32_leg = {"avg_kernel_ms": ms32 / max(n32, 1), "storage_bytes_per_launch": sh.step_storage_bytes()}
     total_elems = Nc * (Ng if args.scaling == "strong" else Ng * world)
     if args.emulate_shard_of:
         total_elems = Nc * ng
@@ -351,16 +422,28 @@ def main():
     out = None
     if rank == 0:
         alg_bytes = sh.step_algorithmic_bytes()
-        traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this workload
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
-                "%s_%s" % (args.config, sh.count_storage))
-            if pmc and world == 1 and args.mc == 1 and args.kc is None:
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, ValueError):
-            pass
         avg_ms = kern_ms / max(n_launch, 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "definition": "achieved = ALGORITHMIC bytes (48 + 4 L per element, fp32 model of SURVEY 8d) / average "
+                              "launch time of the dominant kernel; what the kernel physically moves is hbm_rate_GBs",
+                "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
+                "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
+                "count_storage": storage_main, "storage_bytes_per_launch": storage_bytes_main,
+                # the physical HBM rate: bytes the current storage moves (integer counts are kept as u8 / u16,
+                # bit-identical results) over the same time -- below `achieved` by construction
+                "hbm_rate_GBs": storage_bytes_main / (avg_ms * 1e-3) / 1e9,
+                "hbm_frac_of_peak": storage_bytes_main / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                # ... and against what a pure streaming kernel with the same stream mix and access order reaches
+                # on THIS box (brie_calibrate_stream)
+                "measured_stream_ceiling_GBs": stream_gbs,
+                "frac_of_measured_stream_ceiling": storage_bytes_main / (avg_ms * 1e-3) / 1e9 / stream_gbs}
+        if f32_leg is not None:
+            t32 = f32_leg["avg_kernel_ms"] * 1e-3
+            roof["f32_count_storage"] = dict(f32_leg, achieved=alg_bytes / t32 / 1e9, frac=alg_bytes / t32 / 1e9 / HBM_PEAK_GBS,
+                                             note="same kernel, counts kept as the uploaded fp32 layers: storage bytes "
+                                                  "= algorithmic bytes")
         out = {
             "metric": "ELBO iterations/sec (cells x genes)",
             "value": value,
@@ -373,20 +456,16 @@ def main():
             "config": {"workload": cfg["desc"], "Nc": Nc, "Ng": Ng, "Kc": Kc, "count_layers": L,
                        "MC_size": args.mc, "genes_per_rank": ng, "parallelism": "gene-shard x%d" % world,
                        "inputs": "generated on device, resident in HBM (%.1f s, untimed)" % t_gen},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
-                         "count_storage": sh.count_storage, "storage_bytes_per_launch": sh.step_storage_bytes(),
-                         # what the kernel really moves (compact counts) against what a pure streaming kernel with
-                         # the same stream mix and access order reaches on THIS box (brie_calibrate_stream)
-                         "achieved_storage_GBs": sh.step_storage_bytes() / (avg_ms * 1e-3) / 1e9,
-                         "measured_stream_ceiling_GBs": stream_gbs,
-                         "frac_of_measured_stream_ceiling": sh.step_storage_bytes() / (avg_ms * 1e-3) / 1e9 / stream_gbs},
+            "roofline": roof,
         }
         if gather_info is not None:
             out["allgather"] = gather_info
     sh.close()
+    del sh
+    torch.cuda.empty_cache()
+
+    if rank == 0:
+        out["roofline"].update(hbm_traffic(args, world, storage_main))
 
     if rank == 0 and world == 1 and not args.no_psi_check and q0 + 4 <= ng:
         # PSI delta ON THE HEADLINE WORKLOAD: genes are independent and the noise stream is keyed by the global gene

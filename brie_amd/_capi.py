@@ -29,6 +29,7 @@ EXPORTS = [
     "brie_last_error", "brie_abi_version",
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
+    "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister",
 ]
 COMM_ID_BYTES = 128
 
@@ -112,6 +113,10 @@ def load_library(path=None):
     lib.brie_comm_allgather.argtypes = [vp, vp, i64, vp]
     lib.brie_comm_allreduce.argtypes = [vp, vp, i64, i32, i32]
     lib.brie_attach_comm.argtypes = [vp, vp]
+    lib.brie_read_results_async.argtypes = [vp, vp, vp, vp, vp, i64]
+    lib.brie_read_wait.argtypes = [vp]
+    lib.brie_host_register.argtypes = [vp, i64]
+    lib.brie_host_unregister.argtypes = [vp]
     lib.brie_last_error.restype = ctypes.c_char_p
     lib.brie_abi_version.restype = ctypes.c_int
     for name in EXPORTS:
@@ -226,6 +231,17 @@ def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=
     return out.value
 
 
+def host_register(a):
+    """Page-lock a numpy array in place (hipHostRegister); ctypes drops the GIL for the duration of the call."""
+    lib = load_library()
+    _check(lib, lib.brie_host_register(a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+
+
+def host_unregister(a):
+    lib = load_library()
+    _check(lib, lib.brie_host_unregister(a.ctypes.data_as(ctypes.c_void_p)))
+
+
 def device_memory(device=0):
     """(free, total) HBM bytes of `device`."""
     lib = load_library()
@@ -280,6 +296,7 @@ def simulate_counts(psi, total, effLen=None, seed=0, gene_offset=0, device=0):
 
 class Shard(object):
     """Thin object wrapper over one `brie_handle` (one gene shard on one GPU)."""
+    pins_host = True        # result arrays are page-locked while the fit runs (BRIE2.fit, prefetch_results)
 
     def __init__(self, Nc, Ng, Kc=0, n_layers=2, has_efflen=False, train_intercept=True,
                  train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0, sharded=False):
@@ -406,6 +423,24 @@ class Shard(object):
                                                 shape[0], shape[1], shape[1]))
         return out
 
+    def read_results_async(self, psi=None, z_std=None, psi95ci=None, z_loc=None):
+        """Start the one-pass export of the result matrices into the given C-contiguous (Nc, Ng) float32 arrays
+        (None = skip); returns immediately, `read_wait()` completes them."""
+        ptrs = []
+        for a in (psi, z_std, psi95ci, z_loc):
+            if a is None:
+                ptrs.append(None)
+                continue
+            if a.dtype != np.float32 or a.shape != (self.Nc, self.Ng) or not a.flags.c_contiguous:
+                raise ValueError("destination must be a C-contiguous float32 (%d, %d) array" % (self.Nc, self.Ng))
+            ptrs.append(a.ctypes.data_as(ctypes.c_void_p))
+        self._async_keep = (psi, z_std, psi95ci, z_loc)
+        _check(self.lib, self.lib.brie_read_results_async(self._h, ptrs[0], ptrs[1], ptrs[2], ptrs[3], self.Ng))
+
+    def read_wait(self):
+        _check(self.lib, self.lib.brie_read_wait(self._h))
+        self._async_keep = None
+
     @property
     def draw(self):
         d = ctypes.c_uint32()
@@ -442,4 +477,4 @@ class Shard(object):
 
     @property
     def count_storage(self):
-        return {0: "f32", 1: "u8", 2: "u16"}.get(int(self.lib.brie_get_count_storage(self._h)), "?")
+        return {0: "f32", 1: "u8", 2: "u16", 3: "u8/u16 per gene block"}.get(int(self.lib.brie_get_count_storage(self._h)), "?")

@@ -59,7 +59,12 @@ struct brie_handle {
     // (Nc, ld)
     float *c[3] = {nullptr, nullptr, nullptr};
     void *cu[3] = {nullptr, nullptr, nullptr};      // compact (u8 / u16) count layers, same tiled indexing
-    int cs = brie::kCountF32;       // current count storage
+    int cs = brie::kCountF32;       // current count storage (kCountMixed: u8 or u16 per gene block)
+    // mixed tiers: cu[l] holds the u8 tiles of all u8 gene blocks first, then the u16 tiles
+    std::vector<int32_t> tier_host;         // per gene block
+    int32_t *tier = nullptr, *list8 = nullptr, *list16 = nullptr;     // device: tier per block, block lists per tier
+    int64_t *count_off = nullptr;           // device: element offset of every block's tile (in its tier's elements)
+    int n8 = 0, n16 = 0;
     bool allow_compact = true;      // BRIE_COUNT_STORAGE=f32 / brie_set_count_storage(h, 1) disable it
     bool compact_tried = false;
     float pc = 0.0f;                // pseudo-count applied in registers when cs == kCountU8
@@ -107,6 +112,12 @@ struct brie_handle {
     size_t pack_scratch_bytes = 0;
     float *row_scratch = nullptr;   // scratch for per-gene row sets
     float *io_scratch = nullptr;    // (Nc, ld) staging buffer of brie_read, allocated on first use and kept
+    // asynchronous result read-back (brie_read_results_async): second stream + slab staging
+    hipStream_t io_stream = nullptr;
+    hipEvent_t io_event = nullptr;
+    float *io_slab = nullptr;
+    size_t io_slab_elems = 0;
+    bool io_pending = false;
     float *partials = nullptr;
     size_t partials_elems = 0;
     double *loss_parts = nullptr;
@@ -128,6 +139,15 @@ namespace {
 
 int set_device(const brie_handle *h) {
     HIP_TRY(hipSetDevice(h->p.device));
+    return BRIE_OK;
+}
+
+// an asynchronous read-back still exports the state: let it finish before anything changes the state
+int io_wait(brie_handle *h) {
+    if (h->io_pending) {
+        HIP_TRY(hipStreamSynchronize(h->io_stream));
+        h->io_pending = false;
+    }
     return BRIE_OK;
 }
 
@@ -211,30 +231,84 @@ int grid_1d(int64_t n);
 // Try to switch the count layers to a compact storage: u8 if every value is an integer in [0,255],
 // u16 if in [0,65535], else stay fp32.  Called once, when the counts are final (at the pseudo-count,
 // or at the first step if none is added).
+int free_tier_tables(brie_handle *h) {
+    if (h->tier) HIP_TRY(hipFree(h->tier));
+    if (h->list8) HIP_TRY(hipFree(h->list8));
+    if (h->list16) HIP_TRY(hipFree(h->list16));
+    if (h->count_off) HIP_TRY(hipFree(h->count_off));
+    h->tier = h->list8 = h->list16 = nullptr;
+    h->count_off = nullptr;
+    h->tier_host.clear();
+    h->n8 = h->n16 = 0;
+    return BRIE_OK;
+}
+
+size_t compact_layer_bytes(const brie_handle *h, int cs) {
+    const size_t tile = static_cast<size_t>(h->p.Nc) * brie::kGenesPerBlock;
+    if (cs == brie::kCountU8) return tile * h->gene_blocks;
+    if (cs == brie::kCountU16) return tile * h->gene_blocks * 2;
+    return tile * (static_cast<size_t>(h->n8) + 2 * static_cast<size_t>(h->n16));
+}
+
 int try_compact_counts(brie_handle *h) {
     if (h->compact_tried) return BRIE_OK;
     h->compact_tried = true;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
+    // one flag word per gene block (tiled layout), one for everything otherwise
+    const int n_flags = h->tiled ? h->gene_blocks : 1;
+    const int64_t n4_per_block = h->tiled ? h->p.Nc * brie::kWave : n4;
     int *flag = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), sizeof(int)));
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), n_flags * sizeof(int)));
+    HIP_TRY(hipMemsetAsync(flag, 0, n_flags * sizeof(int), h->stream));
     for (int l = 0; l < h->p.n_layers; ++l)
-        hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4, flag);
-    int bits = 1;
-    hipError_t e = hipMemcpyAsync(&bits, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4, n4_per_block, flag);
+    std::vector<int> bits_g(static_cast<size_t>(n_flags), 1);
+    hipError_t e = hipMemcpyAsync(bits_g.data(), flag, n_flags * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(flag);
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "count range check: %s", hipGetErrorString(e));
+    int bits = 0;
+    for (int b : bits_g) bits |= b;
     if (bits & 4) {                               // the reference would silently produce NaN posteriors
         h->compact_tried = false;                 // checked again (and refused again) on the next attempt
         return fail(BRIE_ERR_INVALID, "count layers contain negative or non-finite values");
     }
     if ((bits & 1) || !h->allow_compact || !h->tiled) return BRIE_OK;     // fractional / huge: stay fp32
-    const int cs = (bits & 2) ? brie::kCountU16 : brie::kCountU8;
-    const size_t bytes = static_cast<size_t>(n) * (cs == brie::kCountU16 ? 2 : 1);
+    int n16 = 0;
+    for (int b : bits_g) n16 += (b & 2) ? 1 : 0;
+    const char *tm = getenv("BRIE_COUNT_TIERS");  // "uniform": one tier for the whole shard (A/B runs)
+    const bool uniform = n16 == 0 || n16 == n_flags || (tm && strcmp(tm, "uniform") == 0);
+    const int cs = uniform ? ((bits & 2) ? brie::kCountU16 : brie::kCountU8) : brie::kCountMixed;
+    const size_t tile = static_cast<size_t>(h->p.Nc) * brie::kGenesPerBlock;
+    if (cs == brie::kCountMixed) {
+        // u8 gene blocks first, then the u16 ones; tables on the device for the kernels
+        std::vector<int32_t> l8, l16;
+        std::vector<int64_t> off(static_cast<size_t>(h->gene_blocks));
+        h->tier_host.assign(static_cast<size_t>(h->gene_blocks), brie::kCountU8);
+        for (int g = 0; g < h->gene_blocks; ++g) {
+            if (bits_g[g] & 2) { h->tier_host[g] = brie::kCountU16; l16.push_back(g); } else l8.push_back(g);
+        }
+        h->n8 = static_cast<int>(l8.size()); h->n16 = static_cast<int>(l16.size());
+        for (size_t k = 0; k < l8.size(); ++k) off[l8[k]] = static_cast<int64_t>(k * tile);                       // bytes = u8 elements
+        for (size_t k = 0; k < l16.size(); ++k) off[l16[k]] = static_cast<int64_t>((l8.size() * tile) / 2 + k * tile);   // u16 elements
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->tier), h->gene_blocks * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->list8), l8.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->list16), l16.size() * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->count_off), h->gene_blocks * sizeof(int64_t)));
+        HIP_TRY(hipMemcpyAsync(h->tier, h->tier_host.data(), h->gene_blocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->list8, l8.data(), l8.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->list16, l16.data(), l16.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipMemcpyAsync(h->count_off, off.data(), h->gene_blocks * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));          // the host vectors go out of scope
+    }
+    const size_t bytes = compact_layer_bytes(h, cs);
     for (int l = 0; l < h->p.n_layers; ++l) {
         HIP_TRY(hipMalloc(&h->cu[l], bytes));
-        hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
+        if (cs == brie::kCountMixed)
+            hipLaunchKernelGGL(brie::count_compact_mixed, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4,
+                               n4_per_block, h->tier, h->count_off);
+        else
+            hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->c[l])); h->c[l] = nullptr; }
@@ -242,17 +316,51 @@ int try_compact_counts(brie_handle *h) {
     return BRIE_OK;
 }
 
+// compact layer l -> fp32 tile layout in `dst`, with (apply_pc) or without the in-register pseudo-count rule
+void launch_expand(brie_handle *h, int l, float *dst, float pc, int apply_pc) {
+    const int64_t n4 = h->p.Nc * h->ld / 4;
+    if (h->cs == brie::kCountMixed)
+        hipLaunchKernelGGL(brie::count_expand_mixed, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
+                           dst, n4, h->p.Nc * static_cast<int64_t>(brie::kWave), h->tier, h->count_off, pc, apply_pc);
+    else
+        hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l], dst,
+                           n4, pc, apply_pc, h->cs);
+}
+
+// Mixed tiers -> one u16 tier for the whole shard (before the gene quads are permuted: a quad may move to a gene
+// block of the other tier).  Values are unchanged.
+int retier_uniform_u16(brie_handle *h) {
+    if (h->cs != brie::kCountMixed) return BRIE_OK;
+    const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
+    float *tmp = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(n) * sizeof(float)));
+    void *fresh[3] = {nullptr, nullptr, nullptr};
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        HIP_TRY(hipMalloc(&fresh[l], static_cast<size_t>(n) * 2));
+        launch_expand(h, l, tmp, 0.0f, 0);
+        hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, tmp, fresh[l], n4,
+                           static_cast<int>(brie::kCountU16));
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipFree(tmp));
+    for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->cu[l])); h->cu[l] = fresh[l]; }
+    h->cs = brie::kCountU16;
+    return free_tier_tables(h);
+}
+
 // Back to fp32 layers (pseudo-count materialised) -- used when counts are modified again.
 int expand_counts(brie_handle *h) {
     if (h->cs == brie::kCountF32) return BRIE_OK;
-    const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
+    const int64_t n = h->p.Nc * h->ld;
     for (int l = 0; l < h->p.n_layers; ++l) {
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->c[l]), static_cast<size_t>(n) * sizeof(float)));
-        hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
-                           h->c[l], n4, h->pc, l < 2 ? 1 : 0, h->cs);
+        launch_expand(h, l, h->c[l], h->pc, l < 2 ? 1 : 0);
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->cu[l])); h->cu[l] = nullptr; }
+    int rc_t = free_tier_tables(h);
+    if (rc_t != BRIE_OK) return rc_t;
     h->cs = brie::kCountF32;
     h->pc = 0.0f;
     h->allow_compact = false;                     // values are no longer integers
@@ -263,6 +371,10 @@ int expand_counts(brie_handle *h) {
 // apply_quad_gather: every gene-indexed array of the shard is re-ordered so that position p holds what
 // was at position from[p].  Matrices go through one scratch buffer (pointer swap), vectors likewise.
 int apply_quad_gather(brie_handle *h, const std::vector<int32_t> &from) {
+    {
+        int rc = retier_uniform_u16(h);
+        if (rc != BRIE_OK) return rc;
+    }
     const int nq = static_cast<int>(h->ld / 4);
     const int Nc = static_cast<int>(h->p.Nc);
     int32_t *d_from = nullptr;
@@ -337,6 +449,10 @@ int upload_quad_ids_and_blocks(brie_handle *h, const std::vector<float> &mask_by
 
 // Back to the identity order (before anything that addresses genes by their original index).
 int ensure_identity(brie_handle *h) {
+    {
+        int rc = io_wait(h);
+        if (rc != BRIE_OK) return rc;
+    }
     if (!h->packed) return BRIE_OK;
     const int nq = static_cast<int>(h->ld / 4);
     std::vector<int32_t> inv(nq);
@@ -545,6 +661,10 @@ int brie_destroy(brie_handle *h) {
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
     if (h->io_scratch) hipFree(h->io_scratch);
+    if (h->io_stream) { hipStreamSynchronize(h->io_stream); hipStreamDestroy(h->io_stream); }
+    if (h->io_event) hipEventDestroy(h->io_event);
+    if (h->io_slab) hipFree(h->io_slab);
+    (void)free_tier_tables(h);
     for (void *q : h->cu)
         if (q) hipFree(q);
     for (hipEvent_t ev : h->ev_pool) hipEventDestroy(ev);
@@ -856,8 +976,15 @@ int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
 
 int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
-    const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
     const int64_t gemm_streams = h->wide ? 8 : 0;        // residual r written by the step, read by wide_design_grad
+    if (h->cs == brie::kCountMixed) {                    // genes of u8 blocks move 1 byte per count, of u16 blocks 2
+        int64_t genes16 = 0;
+        for (int g = 0; g < h->gene_blocks; ++g)
+            if (h->tier_host[g] == brie::kCountU16)
+                genes16 += std::min<int64_t>(brie::kGenesPerBlock, h->p.Ng - static_cast<int64_t>(g) * brie::kGenesPerBlock);
+        return h->p.Nc * (h->p.Ng * (48 + gemm_streams) + static_cast<int64_t>(h->p.n_layers) * (h->p.Ng + genes16));
+    }
+    const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
     return h->p.Nc * h->p.Ng * (48 + per_count * static_cast<int64_t>(h->p.n_layers) + gemm_streams);
 }
 
@@ -934,6 +1061,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (h->wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = io_wait(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const size_t lp_need = static_cast<size_t>(n_steps) * h->fin_blocks * 2;
@@ -1005,7 +1133,19 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        if (h->target == 1) launch_margin(h, cfg, q, a);
+        if (h->cs == brie::kCountMixed) {       // one launch per count tier, each over its own gene blocks
+            const int tiers[2] = {brie::kCountU8, brie::kCountU16};
+            for (int ti = 0; ti < 2; ++ti) {
+                brie::LaunchCfg c2 = cfg;
+                brie::StepScalars a2 = a;
+                c2.cs = tiers[ti];
+                c2.grid.x = ti == 0 ? h->n8 : h->n16;
+                a2.block_list = ti == 0 ? h->list8 : h->list16;
+                a2.count_off = h->count_off;
+                if (h->target == 1) launch_margin(h, c2, q, a2);
+                else launch_step(h, c2, q, a2, cp);
+            }
+        } else if (h->target == 1) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
@@ -1143,7 +1283,16 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     h->draw += static_cast<uint32_t>(n_repeats);
-    launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
+    if (h->cs == brie::kCountMixed) {
+        const int tiers[2] = {brie::kCountU8, brie::kCountU16};
+        for (int ti = 0; ti < 2; ++ti) {
+            a.block_list = ti == 0 ? h->list8 : h->list16;
+            a.count_off = h->count_off;
+            launch_loss_gene(h, brie::LaunchCfg{h->mode, tiers[ti], dim3(ti == 0 ? h->n8 : h->n16, h->n_chunks), h->stream,
+                                                h->coupled ? 1 : 0}, a);
+        }
+    } else
+        launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
     hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
                        h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));
     HIP_TRY(hipGetLastError());
@@ -1205,10 +1354,8 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         if (rows != Nc || cols != Ng)
             return fail(BRIE_ERR_INVALID, "array %d is (%lld, %lld)", which, (long long)Nc, (long long)Ng);
         float *tmp = nullptr;
-        const int64_t n4 = Nc * h->ld / 4;
         if ((rc = io_buffer(h, &tmp)) != BRIE_OK) return rc;
-        hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
-                           tmp, n4, h->pc, l < 2 ? 1 : 0, h->cs);
+        launch_expand(h, l, tmp, h->pc, l < 2 ? 1 : 0);
         rc = copy_cellgene(h, tmp, nullptr, dst, ld);
         hipError_t e = hipStreamSynchronize(h->stream);
         if (rc != BRIE_OK) return rc;
@@ -1231,6 +1378,84 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
         }
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    return BRIE_OK;
+}
+
+int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi95ci, float *z_loc, int64_t ld) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (!psi && !z_std && !psi95ci && !z_loc) return BRIE_OK;
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;        // also waits for an earlier asynchronous read
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    if (ld < Ng) return fail(BRIE_ERR_INVALID, "ld=%lld < Ng=%lld", (long long)ld, (long long)Ng);
+    if (!h->io_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&h->io_event, hipEventDisableTiming));
+    }
+    float *outs[4] = {psi, z_std, psi95ci, z_loc};
+    // slabs of ~64 M elements per output: the export kernel of a slab (microseconds to milliseconds) and its copies
+    // are enqueued in order on the i/o stream, the copy engine streams while the main stream keeps computing
+    const char *se = getenv("BRIE_IO_SLAB_ELEMS");
+    const int64_t slab_target = se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 26);
+    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(Nc, slab_target / Ng));
+    const size_t need = static_cast<size_t>(slab_rows) * Ng * 4 * 2;            // 4 outputs, double buffered
+    if (need > h->io_slab_elems) {
+        if (h->io_slab) HIP_TRY(hipFree(h->io_slab));
+        h->io_slab = nullptr;
+        h->io_slab_elems = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->io_slab), need * sizeof(float)));
+        h->io_slab_elems = need;
+    }
+    // the state is final once everything enqueued so far on the main stream has run
+    HIP_TRY(hipEventRecord(h->io_event, h->stream));
+    HIP_TRY(hipStreamWaitEvent(h->io_stream, h->io_event, 0));
+    h->io_pending = true;
+    int k = 0;
+    for (int64_t r0 = 0; r0 < Nc; r0 += slab_rows, ++k) {
+        const int64_t rows = std::min(slab_rows, Nc - r0);
+        float *base = h->io_slab + static_cast<size_t>(k & 1) * slab_rows * Ng * 4;
+        brie::ExportSlabArgs a{};
+        a.mu = h->mu; a.rho = h->rho;
+        float *slabs[4];
+        for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i) * slab_rows * Ng : nullptr;
+        a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
+        a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+        a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
+        a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
+        hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
+                           dim3(256), 0, h->io_stream, a);
+        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < 4; ++i) {
+            if (!outs[i]) continue;
+            if (ld == Ng)
+                HIP_TRY(hipMemcpyAsync(outs[i] + r0 * ld, slabs[i], static_cast<size_t>(rows) * Ng * sizeof(float),
+                                       hipMemcpyDefault, h->io_stream));
+            else
+                HIP_TRY(hipMemcpy2DAsync(outs[i] + r0 * ld, ld * sizeof(float), slabs[i], Ng * sizeof(float),
+                                         Ng * sizeof(float), rows, hipMemcpyDefault, h->io_stream));
+        }
+    }
+    return BRIE_OK;
+}
+
+int brie_read_wait(brie_handle *h) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    return io_wait(h);
+}
+
+int brie_host_register(void *ptr, int64_t bytes) {
+    if (!ptr || bytes <= 0) return fail(BRIE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipHostRegister(ptr, static_cast<size_t>(bytes), hipHostRegisterPortable));
+    return BRIE_OK;
+}
+
+int brie_host_unregister(void *ptr) {
+    if (!ptr) return fail(BRIE_ERR_INVALID, "null argument");
+    HIP_TRY(hipHostUnregister(ptr));
     return BRIE_OK;
 }
 

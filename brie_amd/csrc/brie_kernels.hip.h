@@ -247,6 +247,11 @@ struct StepScalars {
     // After freezing, the active gene quads are packed to the front (gather_quads); quad_ids[position]
     // is the quad's original index, which keys the noise stream -- results do not depend on the packing.
     const int32_t *quad_ids;
+    // Mixed count tiers (kCountMixed on the host): the launch covers only the gene blocks of ONE tier --
+    // block_list[blockIdx.x] is the gene block, count_off[gene block] the element offset of its count tile in
+    // the tier-packed layer (null: every gene block, count tiles laid out like the state tiles).
+    const int32_t *block_list;
+    const int64_t *count_off;
 };
 
 // Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
@@ -296,7 +301,8 @@ __device__ __forceinline__ float wave_sum8(const float (&t)[8], int lane) {
 // (4 genes = one dword per lane) and model_wrap.py:113-117's pseudo-count is applied in registers;
 // the fp32 values entering the arithmetic are bit-identical, the count traffic drops from 4L to L bytes.
 // kCountU16: same with two bytes per element for integers up to 65535 (4 genes = 8 B per lane).
-enum : int { kCountF32 = 0, kCountU8 = 1, kCountU16 = 2 };
+enum : int { kCountF32 = 0, kCountU8 = 1, kCountU16 = 2,
+             kCountMixed = 3 };   // host-side state only: u8 or u16 per gene block, two launches per pass
 
 template <int CS> struct CountRegs;
 template <> struct CountRegs<kCountF32> { F4 c1, c2, c3; };
@@ -403,20 +409,21 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int quad = blockIdx.x * kWave + lane;          // local gene quad
+    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);   // gene block (uniform)
+    const int quad = gb * kWave + lane;                  // local gene quad
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
-    if (a.block_active[blockIdx.x] == 0) return;         // whole gene block frozen (workgroup-uniform)
+    if (a.block_active[gb] == 0) return;                 // whole gene block frozen (workgroup-uniform)
     if constexpr (WIDE) {
         for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
-            wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
+            wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
         __syncthreads();
     }
     if constexpr (GW) {
         for (int i = threadIdx.x; i < cp.kgp * kGenesPerBlock; i += kBlock)
-            xlds[i] = cp.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
+            xlds[i] = cp.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
         __syncthreads();
     }
 
@@ -471,7 +478,8 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
-        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
+        const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
+        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
         bool on[kVec];
         {
             const F4 t = ld4(a.gene_active + j0);
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.cb = cp.cb[r];
                 rs.clam = cp.clam[r];
             }
-            load_counts<CS, MODE>(c1p, c2p, c3p, off, R.cnt);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt);
             if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
                 R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
             R.mu = ld4s(mu_p + off);
@@ -621,7 +629,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 if constexpr (WIDE) st4s(rbuf + off, R.mp);
             }
             if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
-                float *chunk = cp.row_partials + static_cast<int64_t>(blockIdx.x) * (cp.kgp + 2) * a.Nc;
+                float *chunk = cp.row_partials + static_cast<int64_t>(gb) * (cp.kgp + 2) * a.Nc;
                 if constexpr (GW) {
                     // sum_j r_j Xg[j, k] for 8 features at a time; lane l ends up with feature 8 (l & 7) + (l >> 3)
                     float mine = 0.0f;
@@ -828,6 +836,8 @@ struct LossGeneArgs {
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
     const float *mbuf;      // wide designs: Xc.Wc_loc from the GEMM (KC == 0 instantiation), else null
+    const int32_t *block_list;      // mixed count tiers, see StepScalars
+    const int64_t *count_off;
     CoupledArgs cp;
 };
 
@@ -836,7 +846,8 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
     __shared__ float red[(kWavesPerBlock - 1) * 2 * kGenesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int quad = blockIdx.x * kWave + lane;
+    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
@@ -884,7 +895,8 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
         }
         const bool cell = a.coupled && a.cp.cell_mode != 0;
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
-        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
+        const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
+        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             float wg[kKgMax] = {0.f, 0.f, 0.f, 0.f}, cbr = 0.f, clamr = 0.f;
@@ -898,7 +910,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             }
             const float row_isig2 = f_exp(-2.0f * clamr);
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(a.c1, a.c2, a.c3, off, cr);
+            load_counts<CS, MODE>(a.c1, a.c2, a.c3, cbase + static_cast<int64_t>(r) * a.row_stride, cr);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
@@ -985,7 +997,8 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int quad = blockIdx.x * kWave + lane;
+    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
@@ -1024,12 +1037,11 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
-        const int64_t mbase = static_cast<int64_t>(blockIdx.x) * a.gb_stride + lane * kVec;
+        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
         const float log_mc = f_log(static_cast<float>(a.mc));
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
-            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(c1p, c2p, c3p, off, cr);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, cr);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             float xc[KCX], m[kVec];
@@ -1389,20 +1401,39 @@ __global__ void scatter_sparse(const int64_t *indptr, const int32_t *indices, co
     }
 }
 
-// flag bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255
-__global__ void count_range_check(const float *c, int64_t n4, int *flag) {
-    int bad = 0;
+// flag[gene block]: bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255; bit 2: some
+// value is negative / NaN / inf.  n4_per_block = float4 per gene block of the tiled layer (Nc * 64); one flag
+// (n4_per_block >= n4) for the row-major layout.
+__global__ void count_range_check(const float *c, int64_t n4, int64_t n4_per_block, int *flag) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const F4 a = ld4(c + 4 * i);
+        int bad = 0;
 #pragma unroll
         for (int v = 0; v < kVec; ++v) {
             bad |= !(a.v[v] >= 0.0f && a.v[v] <= 65535.0f && a.v[v] == truncf(a.v[v]));
             bad |= (a.v[v] > 255.0f) ? 2 : 0;
             bad |= !(a.v[v] >= 0.0f && a.v[v] < __builtin_inff()) ? 4 : 0;      // negative, NaN or inf: not a count
         }
+        if (bad) atomicOr(flag + i / n4_per_block, bad);
     }
-    if (bad) atomicOr(flag, bad);
+}
+// Mixed tiers: gene block g of the tiled fp32 layer -> its tile in the tier-packed layer (u8 or u16 per block);
+// off4[g] = offset of the block's tile in units of 4 count elements (= one lane quad) of ITS tier's element size,
+// i.e. byte offset = off4[g] * 4 * {1, 2}.
+__global__ void count_compact_mixed(const float *c, void *dst, int64_t n4, int64_t n4_per_block, const int32_t *tier,
+                                    const int64_t *off_elems) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t g = i / n4_per_block, inner = i - g * n4_per_block;
+        const F4 a = ld4(c + 4 * i);
+        const uint32_t x0 = static_cast<uint32_t>(a.v[0]), x1 = static_cast<uint32_t>(a.v[1]),
+                       x2 = static_cast<uint32_t>(a.v[2]), x3 = static_cast<uint32_t>(a.v[3]);
+        if (tier[g] == kCountU8)
+            reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(dst) + off_elems[g])[inner] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+        else
+            reinterpret_cast<uint2 *>(static_cast<uint16_t *>(dst) + off_elems[g])[inner] = make_uint2(x0 | (x1 << 16), x2 | (x3 << 16));
+    }
 }
 // fp32 layer -> compact layer (same element index; 4 genes per thread)
 __global__ void count_compact(const float *c, void *dst, int64_t n4, int cs) {
@@ -1419,6 +1450,29 @@ __device__ __forceinline__ float compact_get(const void *p, int64_t i, int v, in
     if (cs == kCountU8) return static_cast<float>((static_cast<const uint32_t *>(p)[i] >> (8 * v)) & 0xFFu);
     const uint2 u = static_cast<const uint2 *>(p)[i];
     return u16_lane(u, v);
+}
+__device__ __forceinline__ float mixed_get(const void *p, int64_t g, int64_t inner, int v, const int32_t *tier,
+                                           const int64_t *off_elems) {
+    if (tier[g] == kCountU8)
+        return static_cast<float>((reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p) + off_elems[g])[inner] >> (8 * v)) & 0xFFu);
+    return u16_lane(reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(p) + off_elems[g])[inner], v);
+}
+__global__ void count_expand_mixed(const void *u1, const void *u2, const void *self, float *dst, int64_t n4,
+                                   int64_t n4_per_block, const int32_t *tier, const int64_t *off_elems, float pc,
+                                   int apply_pc) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t g = i / n4_per_block, inner = i - g * n4_per_block;
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            const float tot = mixed_get(u1, g, inner, v, tier, off_elems) + mixed_get(u2, g, inner, v, tier, off_elems);
+            float val = mixed_get(self, g, inner, v, tier, off_elems);
+            if (apply_pc && tot > 0.0f) val += pc;
+            o.v[v] = val;
+        }
+        st4(dst + 4 * i, o);
+    }
 }
 // inverse, with the pseudo-count rule of the compact storage (apply_pc for the two unique layers)
 __global__ void count_expand(const void *u1, const void *u2, const void *self, float *dst, int64_t n4, float pc,
@@ -1481,6 +1535,48 @@ __global__ void export_rowmajor(const float *mu, const float *rho, float *out, i
         if (vec_ok) st4(dst, o);
         else
             for (int v = 0; v < kVec && j0 + v < Ng; ++v) dst[v] = o.v[v];
+    }
+}
+
+// Result export in ONE pass over the state (BRIE_RV reads Psi, Z_std, Psi95CI and Z_loc, model_wrap.py:28-35):
+// rows [r0, r0 + rows) of up to four derived arrays -> row-major (rows, Ng) slabs; a null output is skipped.
+// mu and rho are read once instead of once per array.
+struct ExportSlabArgs {
+    const float *mu, *rho;
+    float *psi, *zstd, *ci, *zloc;
+    int64_t row_stride, gb_stride;
+    int32_t Ng, gene_blocks, r0, rows;
+};
+__global__ void export_slab(const ExportSlabArgs a) {
+    constexpr float kZ975 = 1.959963984540054f;     // ndtri(0.975)
+    const int64_t total = static_cast<int64_t>(a.gene_blocks) * a.rows * kWave;
+    const bool vec_ok = (a.Ng % kVec) == 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int lane = static_cast<int>(i % kWave);
+        const int g = static_cast<int>((i / kWave) % a.gene_blocks);      // gene blocks fastest: one slab row is
+        const int rl = static_cast<int>(i / (static_cast<int64_t>(kWave) * a.gene_blocks));   // written contiguously
+        const int j0 = (g * kWave + lane) * kVec;
+        if (j0 >= a.Ng) continue;
+        const int64_t off = g * a.gb_stride + static_cast<int64_t>(a.r0 + rl) * a.row_stride + lane * kVec;
+        const F4 m = ld4(a.mu + off), q = ld4(a.rho + off);
+        F4 o_psi, o_std, o_ci;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            const float sd = expf(q.v[v]);
+            o_psi.v[v] = sigmoid_acc(m.v[v]);
+            o_std.v[v] = sd;
+            o_ci.v[v] = sigmoid_acc(m.v[v] + kZ975 * sd) - sigmoid_acc(m.v[v] - kZ975 * sd);
+        }
+        const int64_t dst = static_cast<int64_t>(rl) * a.Ng + j0;
+        const int nv = vec_ok ? kVec : min(kVec, a.Ng - j0);
+        auto put = [&](float *out, const F4 &val) {
+            if (!out) return;
+            if (vec_ok) st4(out + dst, val);
+            else
+                for (int v = 0; v < nv; ++v) out[dst + v] = val.v[v];
+        };
+        put(a.psi, o_psi); put(a.zstd, o_std); put(a.ci, o_ci); put(a.zloc, m);
     }
 }
 

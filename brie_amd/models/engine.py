@@ -161,6 +161,34 @@ class BRIE2(object):
         return refs is not None and len(refs) == len(layers) and all(r is not None and r() is c
                                                                      for r, c in zip(refs, layers))
 
+    def _result(self, which):
+        """A cell x gene result matrix: the copy fit() streamed out while loss_gene ran, else a fresh read."""
+        cached = getattr(self, "_results", None)
+        if cached is not None and which in cached:
+            return cached[which]
+        return self._need().read(which)
+
+    def _start_result_buffers(self, sh):
+        """Host destinations of Psi / Z_std / Psi95CI / Z_loc (what BRIE_RV reads, model_wrap.py:28-35), allocated
+        when the fit starts and page-locked by a background thread while the GPU optimises: the first-touch page
+        faults and the pinning (1.6 s for 16 GB at configs[2] when done inside the read) leave the critical path."""
+        import threading
+        bufs = {w: np.empty((self.Nc, self.Ng), np.float32) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
+        pinned = []
+
+        def pin():
+            for a in bufs.values():
+                try:
+                    _capi.host_register(a)
+                    pinned.append(a)
+                except Exception:                    # locked-memory limit: at least take the page faults now
+                    a.fill(0)
+        th = None
+        if getattr(sh, "pins_host", False):
+            th = threading.Thread(target=pin, daemon=True)
+            th.start()
+        return bufs, pinned, th
+
     def _need(self):
         if self._shard is None:
             raise RuntimeError("BRIE2 state lives on the GPU and is created by fit()/get_loss()")
@@ -169,7 +197,7 @@ class BRIE2(object):
     # ------------------------------------------------------------------ properties (model_TFProb.py:87-116)
     @property
     def Z_loc(self):
-        return _wrap(self._need().read(_capi.Z_LOC))
+        return _wrap(self._result(_capi.Z_LOC))
 
     @property
     def Z_std_log(self):
@@ -177,17 +205,17 @@ class BRIE2(object):
 
     @property
     def Z_std(self):
-        return _wrap(self._need().read(_capi.Z_STD))
+        return _wrap(self._result(_capi.Z_STD))
 
     @property
     def Psi(self):
         """sigmoid(Z_loc) (model_TFProb.py:92-95)"""
-        return _wrap(self._need().read(_capi.PSI))
+        return _wrap(self._result(_capi.PSI))
 
     @property
     def Psi95CI(self):
         """Width of the 95% interval of the logit-normal posterior (model_TFProb.py:102-106); plain ndarray."""
-        return self._need().read(_capi.PSI95CI)
+        return np.asarray(self._result(_capi.PSI95CI))
 
     @property
     def sigma(self):
@@ -237,7 +265,7 @@ class BRIE2(object):
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
             min_iter=1000, max_iter=5000, add_iter=500, epsilon_conv=1e-2, verbose=True,
             n_loss_gene=500, pseudo_count=None, trace_reduce=None, conv_batch_genes=None, loss_gene_draw=None,
-            n_iter_schedule=None, conv_total_genes=None, **kwargs):
+            n_iter_schedule=None, conv_total_genes=None, prefetch_results=True, **kwargs):
         """Fit the model's parameters; returns the loss trace like the reference.
 
         `optimizer` / `learn_rate` are accepted and ignored exactly as in the
@@ -253,6 +281,9 @@ class BRIE2(object):
         n_iter_schedule: iteration counts of an earlier fit (its `n_iter_batch`, or `[n_iter]`) to be repeated
         instead of taking new convergence decisions -- the companion fits of a common-noise LRT stop where the base
         model stopped, so both evaluate the same stretch of the noise stream.
+        prefetch_results: stream Psi, Z_std, Psi95CI and Z_loc to the host while the final 500-draw loss_gene pass
+        runs (one export pass, page-locked destinations prepared during the fit); the attributes then return those
+        arrays.  False: nothing is read until an attribute is asked for.
         """
         start_time = time.time()
         if target not in ("ELBO", "marginLik"):
@@ -264,6 +295,8 @@ class BRIE2(object):
         self._pseudo_count = pseudo_count
         sh = self._ensure_shard(count_layers, Xc, Xg)
         sh.set_target(target)
+        self._results = None
+        staging = self._start_result_buffers(sh) if (prefetch_results and hasattr(sh, "read_results_async")) else None
 
         native = None
         if self._comm is not None:
@@ -338,7 +371,17 @@ class BRIE2(object):
 
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
+        if staging is not None:              # results stream out on a second stream while loss_gene computes
+            bufs, pinned, th = staging
+            if th is not None:
+                th.join()
+            sh.read_results_async(bufs[_capi.PSI], bufs[_capi.Z_STD], bufs[_capi.PSI95CI], bufs[_capi.Z_LOC])
         self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
+        if staging is not None:
+            sh.read_wait()
+            for a in pinned:
+                _capi.host_unregister(a)
+            self._results = bufs
         self.losses = _wrap(losses)
         self.n_iter = n_iter
         if verbose:

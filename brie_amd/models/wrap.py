@@ -140,7 +140,8 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
         design = np.delete(Xc, feat, 1) if full_base else np.append(Xc_base, Xc[:, feat:(feat + 1)], axis=1)
         # the reference builds these models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always with
         # the 'gene' default, whatever the base model uses -- mirrored
-        other = run(design, seed if common_noise else seed + 1 + col, mode='gene', **repeat)
+        # only loss_gene (and the last weight row) of these models is read: no result matrices
+        other = run(design, seed if common_noise else seed + 1 + col, mode='gene', prefetch_results=False, **repeat)
         other_loss = _host(other.loss_gene)
         if full_base:
             gain[:, col] = other_loss - result.loss_gene

@@ -200,6 +200,19 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out);
 int brie_read(brie_handle *h, int which, float *dst,
               int64_t rows, int64_t cols, int64_t ld);
 
+/* BRIE_RV.__init__ reads Psi, Z_std, Psi95CI and Z_loc one after the other (model_wrap.py:28-35): 16 GB at
+ * configs[2].  brie_read_results_async exports all four in ONE pass over the state (any destination may be NULL),
+ * slab by slab on a second stream, and returns at once: the copies run while the caller goes on with
+ * brie_loss_gene (which only reads the state).  brie_read_wait blocks until the destinations are complete; any
+ * call that changes the state waits for a pending read first.  Destinations: (Nc, Ng) row-major, `ld` elements
+ * between rows, host or device.  For host destinations the copy engine only reaches PCIe speed into page-locked
+ * memory: brie_host_register / brie_host_unregister pin / unpin a caller-owned buffer (hipHostRegister) -- callable
+ * from another host thread while the fit runs, which also takes the first-touch page faults off the critical path. */
+int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi95ci, float *z_loc, int64_t ld);
+int brie_read_wait(brie_handle *h);
+int brie_host_register(void *ptr, int64_t bytes);
+int brie_host_unregister(void *ptr);
+
 /* Noise-draw counter (one draw id per loss evaluation). */
 int brie_get_draw(brie_handle *h, uint32_t *draw);
 int brie_set_draw(brie_handle *h, uint32_t draw);
@@ -224,7 +237,8 @@ int64_t brie_step_storage_bytes(const brie_handle *h);
 /* Count-layer storage (the reference densifies to fp32, model_wrap.py:108-111).
  * mode 0 = auto (default): integer counts in [0,255] are kept as u8, in [0,65535] as u16; the
  * pseudo-count of model_wrap.py:113-117 is then applied in registers; mode 1 = always fp32.
- * brie_get_count_storage: 0 = fp32, 1 = u8, 2 = u16 (decided at brie_add_pseudo_count / first step). */
+ * brie_get_count_storage: 0 = fp32, 1 = u8, 2 = u16, 3 = u8 or u16 per 256-gene block (decided at
+ * brie_add_pseudo_count / first step; a gene block holding a count > 255 takes u16, the others stay u8). */
 int brie_set_count_storage(brie_handle *h, int32_t mode);
 int brie_get_count_storage(const brie_handle *h);
 

@@ -142,6 +142,15 @@ class OracleShard(object):
 
     draw = property(lambda s: s.o.draw, lambda s, v: setattr(s.o, "draw", int(v)))
 
+    def read_results_async(self, psi=None, z_std=None, psi95ci=None, z_loc=None):
+        from brie_amd import _capi
+        for dst, which in ((psi, _capi.PSI), (z_std, _capi.Z_STD), (psi95ci, _capi.PSI95CI), (z_loc, _capi.Z_LOC)):
+            if dst is not None:
+                dst[...] = self.read(which)
+
+    def read_wait(self):
+        pass
+
     def close(self):
         pass
 

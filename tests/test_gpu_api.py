@@ -265,3 +265,53 @@ def test_count_layers_in_any_container_give_the_same_fit(lib):
             ref = got
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b, err_msg=name)
+
+
+@pytest.mark.parametrize("Ng", [300, 1028])
+def test_async_result_export_equals_the_plain_reads(lib, Ng, monkeypatch):
+    """brie_read_results_async: one pass over the state, slab by slab on a second stream, overlapping loss_gene;
+    the four matrices equal brie_read's, a state-changing call waits for the pending export first."""
+    from brie_amd import _capi
+    from tests import util
+    Nc, Kc = 70, 1
+    P = util.problem(Nc, Ng, Kc, 2, seed=5)
+    sh = util.device_shard(P, Nc, Ng, Kc, 3)
+    sh.step(7, 0.01, 1)
+    monkeypatch.setenv("BRIE_IO_SLAB_ELEMS", str(Ng * 16))            # 16-row slabs: 5 slabs, the last one ragged
+    want = {w: sh.read(w) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
+    got = {w: np.full((Nc, Ng), np.nan, np.float32) for w in want}
+    _capi.host_register(got[_capi.PSI])                                # one page-locked destination, three pageable
+    sh.read_results_async(got[_capi.PSI], got[_capi.Z_STD], got[_capi.PSI95CI], got[_capi.Z_LOC])
+    lg = sh.loss_gene(3)
+    sh.step(2, 0.01, 1)                                                # must not run before the export has finished
+    sh.read_wait()
+    _capi.host_unregister(got[_capi.PSI])
+    for w in want:
+        np.testing.assert_array_equal(got[w], want[w])
+    assert np.all(np.isfinite(lg)) and not np.array_equal(sh.read(_capi.PSI), want[_capi.PSI])
+    only = np.empty((Nc, Ng), np.float32)
+    sh.read_results_async(psi95ci=only)                                # any subset
+    sh.read_wait()
+    np.testing.assert_array_equal(only, sh.read(_capi.PSI95CI))
+    with pytest.raises(ValueError):
+        sh.read_results_async(psi=np.empty((Nc, Ng + 1), np.float32))
+    sh.close()
+
+
+def test_BRIE2_fit_streams_results_out(lib):
+    import brie_amd
+    from brie_amd import _capi
+    Nc, Ng = 80, 200
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=3)
+    m = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=9)
+    m.fit(P["counts"], Xc=P["Xc"], min_iter=60, max_iter=60, n_loss_gene=5, pseudo_count=0.01, verbose=False)
+    assert m._results is not None
+    for attr, which in (("Psi", _capi.PSI), ("Z_std", _capi.Z_STD), ("Psi95CI", _capi.PSI95CI), ("Z_loc", _capi.Z_LOC)):
+        np.testing.assert_array_equal(np.asarray(getattr(m, attr)), m._shard.read(which))
+    m2 = brie_amd.BRIE2(Nc, Ng, Kc=1, seed=9)
+    m2.fit(P["counts"], Xc=P["Xc"], min_iter=60, max_iter=60, n_loss_gene=5, pseudo_count=0.01, verbose=False,
+           prefetch_results=False)
+    assert m2._results is None
+    np.testing.assert_array_equal(np.asarray(m2.Psi), np.asarray(m.Psi))
+    np.testing.assert_array_equal(m2.loss_gene, m.loss_gene)
+    m.close(); m2.close()

@@ -318,6 +318,49 @@ def test_count_storage_tiers(lib):
     np.testing.assert_allclose(tr, o.minimize(P["counts"], P["Xc"], 3, 0.01, 1), rtol=2e-5)
 
 
+@pytest.mark.parametrize("L,MC,Kg", [(2, 1, 0), (3, 3, 0), (2, 1, 2), (2, 1, 6)])
+def test_mixed_count_tiers_per_gene_block(lib, L, MC, Kg):
+    """Several 256-gene blocks, only some holding a count > 255: those take u16, the others stay u8 (two launches
+    per pass over disjoint gene blocks).  Bit-identical to fp32 storage for steps, loss_gene, per-batch packing
+    (which first re-tiers to one u16 tier) and the count read-back; close to the oracle."""
+    from brie_amd import _capi
+    Nc, Ng, Kc = 70, 1100, 2                # 5 gene blocks, the last partly filled
+    P = util.problem(Nc, Ng, Kc, L, seed=41)
+    P["counts"] = [c.copy() for c in P["counts"]]
+    P["counts"][0][3, 300] = 999.0          # block 1
+    P["counts"][1][69, 1099] = 40000.0      # block 4 (the ragged one)
+    P["counts_pc"] = util.add_pseudo_count(P["counts"], 0.01)
+    if Kg:
+        P["Xg"] = np.random.default_rng(3).normal(size=(Ng, Kg)).astype(np.float32)
+    sh = util.device_shard(P, Nc, Ng, Kc, 31, Kg=Kg)
+    ref = util.device_shard(P, Nc, Ng, Kc, 31, storage="f32", Kg=Kg)
+    tr = sh.step(4, 0.01, MC)
+    assert sh.count_storage == "u8/u16 per gene block"
+    assert sh.step_storage_bytes() == Nc * (Ng * 48 + L * (Ng + 256 + (Ng - 1024)))
+    np.testing.assert_array_equal(tr, ref.step(4, 0.01, MC))
+    np.testing.assert_array_equal(sh.loss_gene(5), ref.loss_gene(5))
+    for l in range(L):
+        np.testing.assert_array_equal(sh.read(_capi.COUNT1 + l), P["counts_pc"][l])
+    if Kg == 0:
+        o = util.oracle_model(P, Nc, Ng, Kc, 31, np.float32)
+        np.testing.assert_allclose(tr, o.minimize(P["counts_pc"], P["Xc"], 4, 0.01, MC), rtol=2e-5)
+        # freeze most genes: packing permutes quads across gene blocks -> one u16 tier, still bit-identical
+        mask = np.zeros(Ng, bool)
+        mask[290:310] = True
+        mask[1090:] = True
+        for s_ in (sh, ref):
+            s_.set_gene_mask(mask)
+        np.testing.assert_array_equal(sh.step(3, 0.005, MC), ref.step(3, 0.005, MC))
+        assert sh.count_storage == "u16"
+        for s_ in (sh, ref):
+            s_.set_gene_mask(None)
+    np.testing.assert_array_equal(sh.step(2, 0.005, MC), ref.step(2, 0.005, MC))
+    for k, a in util.device_state(sh).items():
+        np.testing.assert_array_equal(a, util.device_state(ref)[k], err_msg=k)
+    sh.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("mode,Kg,Kc,L,MC", [("cell", 0, 1, 2, 1), ("gene", 2, 1, 2, 1), ("cell", 4, 2, 3, 3),
                                              ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1),
                                              # Kg > 4: Xg tile in LDS, Wg_loc row broadcast with v_readlane

@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (N=1 only)")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg with fp32 count storage")
+    ap.add_argument("--no-e2e", action="store_true",
+                    help="skip the PCIe-inclusive leg: one whole BRIE2.fit + BRIE_RV from host arrays to host results")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psi-check", action="store_true")
@@ -352,6 +354,9 @@ def main():
     quad_layers = [layers[l][:, q0:q0 + 4].cpu().numpy() for l in range(L)] if rank == 0 else None
     quad_eff = eff_all[q0:q0 + 4].cpu().numpy() if (L == 3 and rank == 0) else None
     Xc_host = Xc.cpu().numpy()
+    e2e_inputs = None
+    if rank == 0 and world == 1 and not (args.no_e2e or args.pmc_child or args.emulate_shard_of):
+        e2e_inputs = [x.cpu().numpy() for x in layers]          # the API hands over HOST buffers
     del layers
     torch.cuda.empty_cache()
     sh.init_state()
@@ -466,6 +471,24 @@ def main():
 
     if rank == 0:
         out["roofline"].update(hbm_traffic(args, world, storage_main))
+    if e2e_inputs is not None:
+        # Secondary, PCIe-inclusive figure (never `value`): the reference's unit of work through the public API --
+        # host count layers in, BRIE2.fit with the default schedule (996 staged steps + 500-draw loss_gene), host
+        # Psi / Z_std / Psi95CI / Z_loc out (model_wrap.py:138-146) -- upload, compaction and read-back included.
+        import brie_amd
+        t0 = time.perf_counter()
+        mdl = brie_amd.BRIE2(Nc, Ng, Kc=Kc, effLen=eff_all.cpu().numpy() if L == 3 else None, seed=seed, device=local_rank)
+        mdl.fit(e2e_inputs, Xc=Xc_host, min_iter=1000, max_iter=1000, MC_size=args.mc, pseudo_count=0.01, verbose=False)
+        rv = brie_amd.BRIE_RV(mdl)
+        total = time.perf_counter() - t0
+        assert np.isfinite(rv.Psi).all()
+        out["pcie_inclusive"] = {"it_per_s_pcie_inclusive": 996 / total, "total_s": total, "steps": 996,
+                                 "breakdown_s": {k: v for k, v in mdl.timing.items() if k.endswith("_s")},
+                                 "what": "host numpy count layers -> BRIE2.fit (6 x 166 steps, 500-draw loss_gene) -> "
+                                         "BRIE_RV with Psi, Z_std, Psi95CI, Z_loc on the host; result matrices stream "
+                                         "out while loss_gene runs"}
+        mdl.close()
+        del e2e_inputs, rv
 
     if rank == 0 and world == 1 and not args.no_psi_check and q0 + 4 <= ng:
         # PSI delta ON THE HEADLINE WORKLOAD: genes are independent and the noise stream is keyed by the global gene

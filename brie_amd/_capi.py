@@ -29,7 +29,8 @@ EXPORTS = [
     "brie_last_error", "brie_abi_version",
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
-    "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister",
+    "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
+    "brie_loglik_mc",
 ]
 COMM_ID_BYTES = 128
 
@@ -115,6 +116,8 @@ def load_library(path=None):
     lib.brie_attach_comm.argtypes = [vp, vp]
     lib.brie_read_results_async.argtypes = [vp, vp, vp, vp, vp, i64]
     lib.brie_read_wait.argtypes = [vp]
+    lib.brie_loglik_mc.argtypes = [vp, i32, vp, i64]
+    lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
     lib.brie_last_error.restype = ctypes.c_char_p
@@ -341,6 +344,12 @@ class Shard(object):
         _check(self.lib, self.lib.brie_upload(self._h, which, ptr, rows, cols, ld))
         del keep
 
+    def reconfigure(self, Kc, seed, train_intercept=True, train_sigma=True):
+        """Next model on the same count layers (brie_reconfigure): new design width and seed, counts stay in HBM."""
+        _check(self.lib, self.lib.brie_reconfigure(self._h, int(Kc), int(seed) & (2 ** 64 - 1),
+                                                   int(bool(train_intercept)), int(bool(train_sigma))))
+        self.Kc = int(Kc)
+
     def add_pseudo_count(self, pc):
         _check(self.lib, self.lib.brie_add_pseudo_count(self._h, float(pc)))
 
@@ -421,6 +430,12 @@ class Shard(object):
         if out.size:
             _check(self.lib, self.lib.brie_read(self._h, which, out.ctypes.data_as(ctypes.c_void_p),
                                                 shape[0], shape[1], shape[1]))
+        return out
+
+    def loglik_mc(self, size=10):
+        """(Nc, Ng) Monte-Carlo log-likelihood of every entry under the current target (brie_loglik_mc)."""
+        out = np.empty((self.Nc, self.Ng), np.float32)
+        _check(self.lib, self.lib.brie_loglik_mc(self._h, int(size), out.ctypes.data_as(ctypes.c_void_p), self.Ng))
         return out
 
     def read_results_async(self, psi=None, z_std=None, psi95ci=None, z_loc=None):

@@ -102,9 +102,9 @@ def quant(in_file, cell_file=None, gene_file=None, out_file=None, LRT_index=[],
         hit, Xc, Xc_ids = _match_features(adata.obs.index, _load_table(cell_file), "cells")
         adata = adata[hit, :]
     print("layers:", layer_keys)
-    adata = filter_genes(adata, min_counts=min_counts, min_counts_uniq=min_counts_uniq,
-                         min_cells_uniq=min_cells_uniq, min_MIF_uniq=min_MIF_uniq,
-                         uniq_layers=layer_keys[:2], ambg_layers=layer_keys[2:], copy=True)
+    filter_genes(adata, min_counts=min_counts, min_counts_uniq=min_counts_uniq,          # in place, as quant.py:70-75
+                 min_cells_uniq=min_cells_uniq, min_MIF_uniq=min_MIF_uniq,
+                 uniq_layers=layer_keys[:2], ambg_layers=layer_keys[2:])
     if gene_file is not None:                       # likewise for genes (quant.py:78-95)
         hit, Xg, Xg_ids = _match_features(adata.var.index, _load_table(gene_file), "genes")
         adata = adata[:, hit]

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -118,6 +119,11 @@ struct brie_handle {
     float *io_slab = nullptr;
     size_t io_slab_elems = 0;
     bool io_pending = false;
+    // the slab loop runs on a worker thread: a copy into PAGEABLE host memory blocks its caller (the runtime stages
+    // it), and the caller of brie_read_results_async wants to go on with brie_loss_gene
+    std::thread io_thread;
+    int io_rc = 0;
+    std::string io_err;
     float *partials = nullptr;
     size_t partials_elems = 0;
     double *loss_parts = nullptr;
@@ -145,8 +151,14 @@ int set_device(const brie_handle *h) {
 // an asynchronous read-back still exports the state: let it finish before anything changes the state
 int io_wait(brie_handle *h) {
     if (h->io_pending) {
-        HIP_TRY(hipStreamSynchronize(h->io_stream));
+        if (h->io_thread.joinable()) h->io_thread.join();
         h->io_pending = false;
+        HIP_TRY(hipStreamSynchronize(h->io_stream));
+        if (h->io_rc != BRIE_OK) {
+            const int rc = h->io_rc;
+            h->io_rc = BRIE_OK;
+            return fail(rc, "asynchronous read-back: %s", h->io_err.c_str());
+        }
     }
     return BRIE_OK;
 }
@@ -644,6 +656,49 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     return BRIE_OK;
 }
 
+// The next model of a likelihood-ratio test on the SAME counts (model_wrap.py:155-187 builds a fresh BRIE2 per tested
+// feature and hands it the same count layers): keep the count layers as they sit in HBM (uploaded, pseudo-counted,
+// compacted once), replace everything that depends on the design width and the seed.
+int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_intercept, int32_t train_sigma) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (Kc < 0 || Kc > BRIE_MAX_KC_WIDE) return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", Kc, BRIE_MAX_KC_WIDE);
+    if (h->step_open) return fail(BRIE_ERR_STATE, "a step is open");
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const bool wide = Kc > BRIE_MAX_KC;
+    if (wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
+    const size_t vec = static_cast<size_t>(h->ld), mat = static_cast<size_t>(h->p.Nc) * h->ld;
+    float **drop[] = {&h->Xc, &h->W, &h->m_W, &h->v_W, &h->Rbuf, &h->Gpart, &h->Mbuf};
+    for (float **q : drop) {
+        if (*q) HIP_TRY(hipFree(*q));
+        *q = nullptr;
+    }
+#define A(ptr, n) if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) return rc;
+    A(h->Xc, static_cast<size_t>(h->p.Nc) * Kc);
+    A(h->W, vec * Kc); A(h->m_W, vec * Kc); A(h->v_W, vec * Kc);
+    h->n_gchunks = 0;
+    if (wide) {
+        h->n_gchunks = static_cast<int>((h->p.Nc + h->gchunk_rows - 1) / h->gchunk_rows);
+        A(h->Rbuf, mat);
+        A(h->Gpart, vec * Kc * h->n_gchunks);
+    }
+#undef A
+    h->p.Kc = Kc; h->p.seed = seed; h->p.train_intercept = train_intercept; h->p.train_sigma = train_sigma;
+    h->wide = wide;
+    h->kernel_kc = wide ? 0 : Kc;
+    h->S = h->kernel_kc + 4;
+    if (h->row_scratch) { HIP_TRY(hipFree(h->row_scratch)); h->row_scratch = nullptr; }   // sized by max(ring, Kc)
+    h->have_xc = false;
+    h->have_state = false;
+    h->draw = 0; h->t = 0; h->ring_pos = 0;
+    h->target = 0;
+    HIP_TRY(hipMemsetAsync(h->ring_kl, 0, vec * brie::kLossRing * sizeof(float), h->stream));
+    HIP_TRY(hipMemsetAsync(h->ring_ll, 0, vec * brie::kLossRing * sizeof(float), h->stream));
+    return brie_set_gene_mask(h, nullptr);
+}
+
 int brie_destroy(brie_handle *h) {
     if (!h) return BRIE_OK;
     hipSetDevice(h->p.device);
@@ -661,6 +716,7 @@ int brie_destroy(brie_handle *h) {
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
     if (h->io_scratch) hipFree(h->io_scratch);
+    if (h->io_thread.joinable()) h->io_thread.join();
     if (h->io_stream) { hipStreamSynchronize(h->io_stream); hipStreamDestroy(h->io_stream); }
     if (h->io_event) hipEventDestroy(h->io_event);
     if (h->io_slab) hipFree(h->io_slab);
@@ -953,8 +1009,6 @@ int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out) {
 int brie_set_target(brie_handle *h, int32_t target) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (target != 0 && target != 1) return fail(BRIE_ERR_INVALID, "target %d (0 = ELBO, 1 = marginLik)", target);
-    if (target == 1 && (h->coupled || h->wide))
-        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts is not built");
     h->target = target;
     return BRIE_OK;
 }
@@ -1055,9 +1109,6 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (split == 0 && h->coupled && h->p.sharded != 0 && !lib_reduce)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: attach a communicator "
                     "(brie_attach_comm) or use brie_step_begin / all-reduce brie_rowstat_buffer / brie_step_end");
-    if (h->target == 1 && (h->coupled || h->wide))
-        return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with gene features / cell intercepts / Kc > %d is not built",
-                    BRIE_MAX_KC);
     if (h->wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
@@ -1098,6 +1149,9 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
     cfg.rbuf = h->Rbuf;
+    // target="marginLik": uncoupled models with Kc <= 8 have their own light kernel, the others the MARGIN variants
+    const bool simple_margin = h->target == 1 && !h->coupled && !h->wide;
+    cfg.margin = (h->target == 1 && !simple_margin) ? 1 : 0;
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
     cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0; cp.kgp = h->kgp;
@@ -1142,10 +1196,10 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                 c2.grid.x = ti == 0 ? h->n8 : h->n16;
                 a2.block_list = ti == 0 ? h->list8 : h->list16;
                 a2.count_off = h->count_off;
-                if (h->target == 1) launch_margin(h, c2, q, a2);
+                if (simple_margin) launch_margin(h, c2, q, a2);
                 else launch_step(h, c2, q, a2, cp);
             }
-        } else if (h->target == 1) launch_margin(h, cfg, q, a);
+        } else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
@@ -1265,7 +1319,6 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.margin = h->target == 1 ? 1 : 0;
     a.mbuf = nullptr;
     if (h->wide) {
-        if (h->target == 1) return fail(BRIE_ERR_UNSUPPORTED, "target='marginLik' with Kc > %d is not built", BRIE_MAX_KC);
         if ((rc = wide_forward_mean(h)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
@@ -1381,6 +1434,62 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
     return BRIE_OK;
 }
 
+int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld) {
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (size < 1 || !out) return fail(BRIE_ERR_INVALID, "size=%d out=%p", size, (void *)out);
+    if (ld < h->p.Ng) return fail(BRIE_ERR_INVALID, "ld=%lld < Ng", (long long)ld);
+    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "logLik_MC needs the tiled layout");
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    const size_t mat = static_cast<size_t>(Nc) * h->ld;
+    // fp32 views of the count layers (pseudo-count included), expanded into temporaries when stored compactly
+    float *tmp[3] = {nullptr, nullptr, nullptr};
+    float *res = nullptr;
+    auto cleanup = [&]() { for (float *q : tmp) if (q) hipFree(q); if (res) hipFree(res); };
+    brie::LogLikArgs a{};
+    const float *layers[3] = {nullptr, nullptr, nullptr};
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        if (h->cs == brie::kCountF32) { layers[l] = h->c[l]; continue; }
+        if (hipMalloc(reinterpret_cast<void **>(&tmp[l]), mat * sizeof(float)) != hipSuccess) {
+            cleanup();
+            return fail(BRIE_ERR_HIP, "hipMalloc count view");
+        }
+        launch_expand(h, l, tmp[l], h->pc, l < 2 ? 1 : 0);
+        layers[l] = tmp[l];
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(Nc) * Ng * sizeof(float)) != hipSuccess) {
+        cleanup();
+        return fail(BRIE_ERR_HIP, "hipMalloc result");
+    }
+    a.c1 = layers[0]; a.c2 = layers[1]; a.c3 = layers[2];
+    a.mu = h->mu; a.rho = h->rho; a.b = h->b; a.lam = h->lam; a.cb = h->cb; a.clam = h->clam; a.effL = h->effL;
+    a.prior_m = nullptr;
+    a.margin = h->target == 1 ? 1 : 0;
+    if (a.margin && (h->p.Kc > 0 || h->p.Kg > 0)) {            // prior mean Xc.Wc_loc (+ Wg_loc.Xg^T) into Mbuf
+        if (h->p.Kc > 0 && (rc = wide_forward_mean(h)) != BRIE_OK) { cleanup(); return rc; }
+        if (h->p.Kg > 0 && (rc = gwide_forward_mean(h, h->p.Kc > 0)) != BRIE_OK) { cleanup(); return rc; }
+        a.prior_m = h->Mbuf;
+    }
+    a.out = res; a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+    a.Nc = static_cast<int32_t>(Nc); a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
+    a.mode = h->mode; a.cell_mode = h->cell_mode ? 1 : 0; a.n_mc = size;
+    a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
+    a.draw = h->draw++; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    hipLaunchKernelGGL(brie::loglik_mc_export, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * Nc * brie::kWave)),
+                       dim3(256), 0, h->stream, a);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpy2DAsync(out, ld * sizeof(float), res, Ng * sizeof(float), Ng * sizeof(float), Nc, hipMemcpyDefault,
+                             h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "logLik_MC: %s", hipGetErrorString(e));
+    return BRIE_OK;
+}
+
 int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi95ci, float *z_loc, int64_t ld) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (!psi && !z_std && !psi95ci && !z_loc) return BRIE_OK;
@@ -1412,31 +1521,44 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
     HIP_TRY(hipEventRecord(h->io_event, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->io_stream, h->io_event, 0));
     h->io_pending = true;
-    int k = 0;
-    for (int64_t r0 = 0; r0 < Nc; r0 += slab_rows, ++k) {
-        const int64_t rows = std::min(slab_rows, Nc - r0);
-        float *base = h->io_slab + static_cast<size_t>(k & 1) * slab_rows * Ng * 4;
-        brie::ExportSlabArgs a{};
-        a.mu = h->mu; a.rho = h->rho;
-        float *slabs[4];
-        for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i) * slab_rows * Ng : nullptr;
-        a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
-        a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
-        a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
-        a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
-        hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
-                           dim3(256), 0, h->io_stream, a);
-        HIP_TRY(hipGetLastError());
-        for (int i = 0; i < 4; ++i) {
-            if (!outs[i]) continue;
-            if (ld == Ng)
-                HIP_TRY(hipMemcpyAsync(outs[i] + r0 * ld, slabs[i], static_cast<size_t>(rows) * Ng * sizeof(float),
-                                       hipMemcpyDefault, h->io_stream));
-            else
-                HIP_TRY(hipMemcpy2DAsync(outs[i] + r0 * ld, ld * sizeof(float), slabs[i], Ng * sizeof(float),
-                                         Ng * sizeof(float), rows, hipMemcpyDefault, h->io_stream));
+    h->io_rc = BRIE_OK;
+    const int device = h->p.device;
+    h->io_thread = std::thread([h, Nc, Ng, ld, slab_rows, device, psi, z_std, psi95ci, z_loc]() {
+        float *outs[4] = {psi, z_std, psi95ci, z_loc};
+        auto bad = [h](const char *what, hipError_t e) {
+            h->io_rc = BRIE_ERR_HIP;
+            h->io_err = std::string(what) + ": " + hipGetErrorString(e);
+            (void)hipGetLastError();
+        };
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { bad("hipSetDevice", e); return; }
+        int k = 0;
+        for (int64_t r0 = 0; r0 < Nc; r0 += slab_rows, ++k) {
+            const int64_t rows = std::min(slab_rows, Nc - r0);
+            float *base = h->io_slab + static_cast<size_t>(k & 1) * slab_rows * Ng * 4;
+            brie::ExportSlabArgs a{};
+            a.mu = h->mu; a.rho = h->rho;
+            float *slabs[4];
+            for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i) * slab_rows * Ng : nullptr;
+            a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
+            a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+            a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
+            a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
+            hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
+                               dim3(256), 0, h->io_stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) { bad("export_slab", e); return; }
+            for (int i = 0; i < 4; ++i) {
+                if (!outs[i]) continue;
+                if (ld == Ng)
+                    e = hipMemcpyAsync(outs[i] + r0 * ld, slabs[i], static_cast<size_t>(rows) * Ng * sizeof(float),
+                                       hipMemcpyDefault, h->io_stream);
+                else
+                    e = hipMemcpy2DAsync(outs[i] + r0 * ld, ld * sizeof(float), slabs[i], Ng * sizeof(float),
+                                         Ng * sizeof(float), rows, hipMemcpyDefault, h->io_stream);
+                if (e != hipSuccess) { bad("copy", e); return; }
+            }
         }
-    }
+    });
     return BRIE_OK;
 }
 

@@ -30,8 +30,25 @@ void step_launch_gw(const LaunchCfg &c, const StepPointers &q, const StepScalars
                        q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr);
 }
 
+// target="marginLik" for the coupled variants (the uncoupled ones use margin_step)
+template <int MODE, int CS>
+void step_launch_margin(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    if (c.gw_lds_bytes > 0) {
+        auto kern = elbo_adam_step<BRIE_KC, MODE, 0, CS, true, false, true, true>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
+        hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), c.gw_lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu,
+                           q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr);
+    } else {
+        hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, 0, CS, true, false, false, true>), c.grid, dim3(kBlock), 0,
+                           c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam,
+                           q.effL, q.partials, a, cp, nullptr);
+    }
+}
+
 template <int MODE, int CS>
 void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
+    if (c.coupled && c.margin) { step_launch_margin<MODE, CS>(c, q, a, cp); return; }
     // coupled modes (gene features / per-cell intercept): one variant with run-time MC_size
     if (c.coupled && c.gw_lds_bytes > 0) { step_launch_gw<MODE, CS>(c, q, a, cp); return; }
     if (c.coupled) { step_launch<MODE, 0, CS, true>(c, q, a, cp); return; }
@@ -104,10 +121,21 @@ void BRIE_CAT(launch_loss_gene_kc, BRIE_KC)(const LaunchCfg &c, const LossGeneAr
 namespace {
 template <int MODE, int CS>
 void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
-#define BRIE_WIDE(MC, CPL, GW, LDS)                                                                              \
-    hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, CPL, true, GW>), c.grid, dim3(kBlock), LDS, c.stream, q.c1, \
+#define BRIE_WIDE_M(MC, CPL, GW, MRG, LDS)                                                                         \
+    hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, CPL, true, GW, MRG>), c.grid, dim3(kBlock), LDS, c.stream, q.c1, \
                        q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, \
                        q.partials, a, cp, c.rbuf)
+#define BRIE_WIDE(MC, CPL, GW, LDS) BRIE_WIDE_M(MC, CPL, GW, false, LDS)
+    if (c.margin) {                                  // target="marginLik": prior samples, residual q into rbuf
+        if (c.coupled && c.gw_lds_bytes > 0) {
+            auto kern = elbo_adam_step<0, MODE, 0, CS, true, true, true, true>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
+            BRIE_WIDE_M(0, true, true, true, c.gw_lds_bytes);
+        } else if (c.coupled) BRIE_WIDE_M(0, true, false, true, 0);
+        else BRIE_WIDE_M(0, false, false, true, 0);
+        return;
+    }
     if (c.coupled && c.gw_lds_bytes > 0) {          // wide cell design + Kg > 4: W tile (static) + Xg tile (dynamic) in LDS
         auto kern = elbo_adam_step<0, MODE, 0, CS, true, true, true>;
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -118,6 +146,7 @@ void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
     else if (a.mc == 3) BRIE_WIDE(3, false, false, 0);
     else BRIE_WIDE(0, false, false, 0);
 #undef BRIE_WIDE
+#undef BRIE_WIDE_M
 }
 template <int MODE>
 void wide_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {

@@ -389,7 +389,11 @@ constexpr float kAdamEps = 1e-7f;
 // is Kc LDS reads + 4 Kc FMAs per lane.  Backward: the residual r = (mu - m)/sigma^2 is written to `rbuf`
 // (one extra 4-B/element stream) and G = Xc^T . r is reduced over cells on the matrix cores by
 // wide_design_grad (v_mfma_f32_32x32x2_f32), which reads it back once.
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false>
+// MARGIN: target="marginLik" (model_TFProb.py:156-157,188-189,202-205) for the coupled / wide variants: z is sampled
+// from the PRIOR N(m, sigma), the samples are combined with an online log-mean-exp, q = sum_k w_k dl/dz_k takes the
+// place of the residual r in every prior-parameter statistic (and -q_eps sigma that of the sigma statistic), there is
+// no KL term and the posterior arrays are neither read nor written.  (Uncoupled Kc <= 8 models use margin_step.)
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
@@ -502,12 +506,14 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt);
             if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
                 R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
-            R.mu = ld4s(mu_p + off);
-            R.rho = ld4s(rho_p + off);
-            R.mm = ld4s(mmu_p + off);
-            R.vm = ld4s(vmu_p + off);
-            R.mr = ld4s(mrho_p + off);
-            R.vr = ld4s(vrho_p + off);
+            if constexpr (!MARGIN) {
+                R.mu = ld4s(mu_p + off);
+                R.rho = ld4s(rho_p + off);
+                R.mm = ld4s(mmu_p + off);
+                R.vm = ld4s(vmu_p + off);
+                R.mr = ld4s(mrho_p + off);
+                R.vr = ld4s(vrho_p + off);
+            }
 #pragma unroll
             for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
         };
@@ -541,33 +547,8 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 #pragma unroll
                 for (int v = 0; v < kVec; ++v) R.mp.v[v] = mp[v];
             }
-            float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
-                  ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) s[v] = f_exp(R.rho.v[v]);
-
-            auto sample = [&](uint32_t k) {
-                float e[kVec];
-                normal4(gquad, static_cast<uint32_t>(r), a.draw, k, a.seed_lo, a.seed_hi, e);
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) {
-                    const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
-                    float l, g;
-                    loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
-                                 lL0[v], lL4[v], lL5[v], l, g);
-                    ll[v] += l;
-                    gbar[v] += g;
-                    gse[v] = fmaf(g, e[v], gse[v]);
-                }
-            };
-            if (MC > 0) {
-#pragma unroll
-                for (int k = 0; k < MC; ++k) sample(static_cast<uint32_t>(k));
-            } else {
-                for (int k = 0; k < a.mc; ++k) sample(static_cast<uint32_t>(k));
-            }
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) {
+            // prior mean m = Xc . Wc_loc + Wg_loc . Xg^T + intercept (model_TFProb.py:118-127)
+            auto prior_mean = [&](int v) {
                 float m = cell ? rs.cb : bj[v];
                 if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc (LDS tile)
 #pragma unroll
@@ -577,12 +558,103 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                     for (int k = 0; k < kKgMax; ++k) m = fmaf(rs.wg[k], Xgk[k][v], m);   // + Wg_loc . Xg^T
                 }
                 if constexpr (GW) m += mg[v];
-                const float is2 = cell ? row_isig2 : isig2[v];
-                const float d = R.mu.v[v] - m;
-                const float rr = d * is2;                                          // (mu - m) / sigma^2
-                const float s2r = s[v] * s[v] * is2;                               // s^2 / sigma^2
-                const float dl = R.rho.v[v] - (cell ? rs.clam : lamj[v]);
-                const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;         // KL(q || prior)
+                return m;
+            };
+            float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
+                  ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
+            if constexpr (MARGIN) {
+                // z_k = m + sigma eps_k; online log-sum-exp over the samples (gbar -> q, gse -> q_eps sigma, ll -> lme)
+                float Mx[kVec], Ss[kVec], mpr[kVec];
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    mpr[v] = prior_mean(v);
+                    s[v] = f_exp(cell ? rs.clam : lamj[v]);
+                    Mx[v] = -INFINITY; Ss[v] = 0.0f;
+                }
+                for (int k = 0; k < a.mc; ++k) {
+                    float e[kVec];
+                    normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) {
+                        float l, g;
+                        loglik<MODE>(fmaf(s[v], e[v], mpr[v]), c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                                     lL0[v], lL4[v], lL5[v], l, g);
+                        const float nm = fmaxf(Mx[v], l);
+                        const float so = f_exp(Mx[v] - nm), sn = f_exp(l - nm);
+                        Ss[v] = Ss[v] * so + sn;
+                        gbar[v] = gbar[v] * so + sn * g;
+                        gse[v] = gse[v] * so + sn * g * e[v];
+                        Mx[v] = nm;
+                    }
+                }
+                const float log_mc = f_log(static_cast<float>(a.mc));
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    const float inv = f_rcp(Ss[v]);
+                    gbar[v] *= inv;
+                    gse[v] = gse[v] * inv * s[v];
+                    ll[v] = Mx[v] + f_log(Ss[v]) - log_mc;                         // reduce_logmeanexp
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) s[v] = f_exp(R.rho.v[v]);
+
+                auto sample = [&](uint32_t k) {
+                    float e[kVec];
+                    normal4(gquad, static_cast<uint32_t>(r), a.draw, k, a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) {
+                        const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
+                        float l, g;
+                        loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                                     lL0[v], lL4[v], lL5[v], l, g);
+                        ll[v] += l;
+                        gbar[v] += g;
+                        gse[v] = fmaf(g, e[v], gse[v]);
+                    }
+                };
+                if (MC > 0) {
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) sample(static_cast<uint32_t>(k));
+                } else {
+                    for (int k = 0; k < a.mc; ++k) sample(static_cast<uint32_t>(k));
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                float rr, lamstat, kl, llv;
+                if constexpr (MARGIN) {
+                    rr = gbar[v];                                                  // dL/dm = -q
+                    lamstat = -gse[v];                                             // dL/dlog(sigma) = -q_eps sigma
+                    kl = 0.0f;
+                    llv = ll[v];
+                } else {
+                    const float m = prior_mean(v);
+                    const float is2 = cell ? row_isig2 : isig2[v];
+                    const float d = R.mu.v[v] - m;
+                    rr = d * is2;                                                  // (mu - m) / sigma^2
+                    const float s2r = s[v] * s[v] * is2;                           // s^2 / sigma^2
+                    const float dl = R.rho.v[v] - (cell ? rs.clam : lamj[v]);
+                    kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;                 // KL(q || prior)
+                    lamstat = 1.0f - d * rr - s2r;
+                    llv = ll[v] * a.inv_mc;
+                    const float g_mu = rr - gbar[v] * a.inv_mc;
+                    const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
+                    // Keras Adam (a frozen gene keeps state and moments)
+                    const float n_mm = R.mm.v[v] + (g_mu - R.mm.v[v]) * kOneMinusB1;
+                    const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
+                    const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
+                    const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
+                    float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
+                    nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                          // clip constraint
+                    const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
+                    R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
+                    R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
+                    R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
+                    R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
+                    R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
+                    R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
+                }
                 if constexpr (CPL) {     // padding genes inside the last quad (Ng % 4 != 0) are not part of the cell's sums
                     const bool real = j0 + v < a.Ng;
                     const float rq = real ? rr : 0.0f;
@@ -592,40 +664,26 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                         for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rq, Xgk[k][v], rstat[k]);
                     }
                     rstat[kKgMax] += rq;
-                    rstat[kKgMax + 1] += real ? 1.0f - d * rr - s2r : 0.0f;
+                    rstat[kKgMax + 1] += real ? lamstat : 0.0f;
                 }
-                const float g_mu = rr - gbar[v] * a.inv_mc;
-                const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
-                // Keras Adam (a frozen gene keeps state and moments)
-                const float n_mm = R.mm.v[v] + (g_mu - R.mm.v[v]) * kOneMinusB1;
-                const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
-                const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
-                const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
-                float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
-                nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                              // clip constraint
-                const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
-                R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
-                R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
-                R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
-                R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
-                R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
-                R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
                 if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for wide_design_grad
                 // per-gene sufficient statistics
 #pragma unroll
                 for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
                 acc[KC + 0][v] += rr;
-                acc[KC + 1][v] += 1.0f - d * rr - s2r;
+                acc[KC + 1][v] += lamstat;
                 acc[KC + 2][v] += kl;
-                acc[KC + 3][v] += ll[v] * a.inv_mc;
+                acc[KC + 3][v] += llv;
             }
             if ((!CPL && !WIDE) || active) {
-                st4s(mu_p + off, R.mu);
-                st4s(rho_p + off, R.rho);
-                st4s(mmu_p + off, R.mm);
-                st4s(vmu_p + off, R.vm);
-                st4s(mrho_p + off, R.mr);
-                st4s(vrho_p + off, R.vr);
+                if constexpr (!MARGIN) {
+                    st4s(mu_p + off, R.mu);
+                    st4s(rho_p + off, R.rho);
+                    st4s(mmu_p + off, R.mm);
+                    st4s(vmu_p + off, R.vm);
+                    st4s(mrho_p + off, R.mr);
+                    st4s(vrho_p + off, R.vr);
+                }
                 if constexpr (WIDE) st4s(rbuf + off, R.mp);
             }
             if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
@@ -1577,6 +1635,81 @@ __global__ void export_slab(const ExportSlabArgs a) {
                 for (int v = 0; v < nv; ++v) out[dst + v] = val.v[v];
         };
         put(a.psi, o_psi); put(a.zstd, o_std); put(a.ci, o_ci); put(a.zloc, m);
+    }
+}
+
+// BRIE2.logLik_MC (model_TFProb.py:130-191) as a per-element output: the Monte-Carlo average (ELBO: z ~ q,
+// reduce_mean :191) or log-mean-exp (marginLik: z ~ prior, :188-189) of the log-likelihood of every (cell, gene)
+// entry -> row-major (Nc, Ng).  An accessor, not the hot loop: fp32 count tiles, run-time likelihood mode.
+struct LogLikArgs {
+    const float *c1, *c2, *c3;          // fp32 tiled count layers
+    const float *mu, *rho;              // posterior (ELBO target)
+    const float *prior_m;               // tiled Xc.Wc_loc + Wg_loc.Xg^T or null (marginLik target)
+    const float *b, *lam, *cb, *clam;   // gene-mode / cell-mode intercept and log sigma
+    const float *effL;                  // (6, ld) or null rows unused for kLik2
+    float *out;
+    int64_t ld, row_stride, gb_stride;
+    int32_t Nc, Ng, gene_blocks, mode, margin, cell_mode, n_mc;
+    uint32_t seed_lo, seed_hi, draw, quad_offset;
+};
+__global__ void loglik_mc_export(const LogLikArgs a) {
+    const int64_t total = static_cast<int64_t>(a.gene_blocks) * a.Nc * kWave;
+    const bool vec_ok = (a.Ng % kVec) == 0;
+    const float log_mc = logf(static_cast<float>(a.n_mc)), inv_mc = 1.0f / static_cast<float>(a.n_mc);
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int lane = static_cast<int>(i % kWave);
+        const int r = static_cast<int>((i / kWave) % a.Nc);
+        const int g = static_cast<int>(i / (static_cast<int64_t>(kWave) * a.Nc));
+        const int q = g * kWave + lane, j0 = q * kVec;
+        if (j0 >= a.Ng) continue;
+        const int64_t off = g * a.gb_stride + static_cast<int64_t>(r) * a.row_stride + lane * kVec;
+        const F4 c1 = ld4(a.c1 + off), c2 = ld4(a.c2 + off);
+        F4 c3 = {{0.f, 0.f, 0.f, 0.f}};
+        if (a.mode == kLikEff3) c3 = ld4(a.c3 + off);
+        float loc[kVec], scale[kVec], L[6][kVec];
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            if (a.margin) {
+                loc[v] = (a.prior_m ? a.prior_m[off + v] : 0.0f) + (a.cell_mode ? a.cb[r] : a.b[j0 + v]);
+                scale[v] = expf(a.cell_mode ? a.clam[r] : a.lam[j0 + v]);
+            } else {
+                loc[v] = a.mu[off + v];
+                scale[v] = expf(a.rho[off + v]);
+            }
+            for (int t = 0; t < 6; ++t) L[t][v] = a.mode != kLik2 ? a.effL[t * a.ld + j0 + v] : 0.0f;
+        }
+        float M[kVec], S[kVec];
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) { M[v] = -INFINITY; S[v] = 0.0f; }
+        for (int k = 0; k < a.n_mc; ++k) {
+            float e[kVec];
+            normal4(a.quad_offset + q, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                const float z = fmaf(scale[v], e[v], loc[v]);
+                float l, gr;
+                if (a.mode == kLik2) loglik<kLik2>(z, c1.v[v], c2.v[v], 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, l, gr);
+                else if (a.mode == kLikEff2)
+                    loglik<kLikEff2>(z, c1.v[v], c2.v[v], 0.f, L[0][v], L[1][v], L[2][v], L[3][v], L[4][v], L[5][v], l, gr);
+                else
+                    loglik<kLikEff3>(z, c1.v[v], c2.v[v], c3.v[v], L[0][v], L[1][v], L[2][v], L[3][v], L[4][v], L[5][v], l, gr);
+                if (a.margin) {
+                    const float nm = fmaxf(M[v], l);
+                    S[v] = S[v] * expf(M[v] - nm) + expf(l - nm);
+                    M[v] = nm;
+                } else {
+                    S[v] += l;
+                }
+            }
+        }
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) o.v[v] = a.margin ? M[v] + logf(S[v]) - log_mc : S[v] * inv_mc;
+        float *dst = a.out + static_cast<int64_t>(r) * a.Ng + j0;
+        if (vec_ok) st4(dst, o);
+        else
+            for (int v = 0; v < kVec && j0 + v < a.Ng; ++v) dst[v] = o.v[v];
     }
 }
 

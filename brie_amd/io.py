@@ -54,6 +54,12 @@ class CountData(object):
                          {k: np.asarray(v)[cidx] for k, v in self.varm.items()},
                          {k: np.asarray(v)[ridx] for k, v in self.obsm.items()}, dict(self.uns))
 
+    def _inplace_subset_var(self, mask):
+        """Keep the genes selected by `mask` IN PLACE (the hook filter_genes(copy=False) uses, as on AnnData)."""
+        sub = self[:, np.asarray(mask)]
+        self.X, self.obs, self.var = sub.X, sub.obs, sub.var
+        self.layers, self.varm, self.obsm, self.uns = sub.layers, sub.varm, sub.obsm, sub.uns
+
     def __repr__(self):
         return "CountData n_obs x n_vars = %d x %d; layers: %s; varm: %s" % (
             self.n_obs, self.n_vars, sorted(self.layers), sorted(self.varm))

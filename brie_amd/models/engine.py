@@ -62,7 +62,7 @@ class BRIE2(object):
 
     def __init__(self, Nc, Ng, Kc=0, Kg=0, effLen=None, intercept=None, intercept_mode='gene',
                  sigma=None, tau_prior=[3, 27], name=None, init_obj=None,
-                 seed=0, device=0, gene_offset=0, comm=None):
+                 seed=0, device=0, gene_offset=0, comm=None, reuse=None):
         self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
         self.effLen = effLen                       # (Ng, 3 * 2)
         self.intercept_mode = intercept_mode
@@ -78,6 +78,9 @@ class BRIE2(object):
             raise NotImplementedError("Kg=%d > %d" % (self.Kg, _capi.MAX_KG))
         if self.Kc > _capi.MAX_KC:
             raise NotImplementedError("Kc=%d > %d" % (self.Kc, _capi.MAX_KC))
+        # reuse: a fitted model whose device copy of the count layers this model takes over (the models of one
+        # likelihood-ratio test are fitted to the same counts, model_wrap.py:155-187) -- see _adopt_shard
+        self._reuse = reuse
         self._coupled = self.Kg > 0 or self._cell_mode
         # a gene shard of a coupled fit exchanges per-cell statistics every step through `comm`
         self._comm = comm if (comm is not None and comm.world > 1 and self._coupled) else None
@@ -104,10 +107,13 @@ class BRIE2(object):
             if self.Kg > 0 and Xg is not None:
                 self._shard.upload(_capi.XG, np.ascontiguousarray(Xg, dtype=np.float32))
             return self._shard
-        sh = self._new_shard(n_layers)
-        self._upload_layers(sh, count_layers, n_layers)
-        if self.effLen is not None:
-            sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
+        sh = self._adopt_shard(count_layers, n_layers)
+        if sh is None:
+            sh = self._new_shard(n_layers)
+            sh.owner = self
+            self._upload_layers(sh, count_layers, n_layers)
+            if self.effLen is not None:
+                sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
         if self.Kc > 0:
             if Xc is None:
                 raise ValueError("Kc=%d but Xc is None" % self.Kc)
@@ -140,6 +146,26 @@ class BRIE2(object):
         self._shard, self._n_layers = sh, n_layers
         return sh
 
+    def _adopt_shard(self, count_layers, n_layers):
+        """Take over the handle of `reuse` when it holds exactly this problem's count layers: the counts stay in HBM
+        as uploaded / pseudo-counted / compacted, brie_reconfigure replaces what depends on Kc and the seed."""
+        other, self._reuse = self._reuse, None
+        sh = getattr(other, "_shard", None)
+        if sh is None or not hasattr(sh, "reconfigure"):
+            return None
+        same = (other.Nc == self.Nc and other.Ng == self.Ng and other.Kg == self.Kg and other._n_layers == n_layers
+                and other._cell_mode == self._cell_mode and other.gene_offset == self.gene_offset
+                and other.device == self.device and (other._comm is None) == (self._comm is None)
+                and other.effLen is self.effLen and other._pseudo_count == self._pseudo_count
+                and other._same_layers(count_layers[:n_layers]))
+        if not same:
+            return None
+        other._shard = None                                   # the handle changes owner
+        sh.reconfigure(self.Kc, self.seed, self._intercept_value is None, self._sigma_value is None)
+        sh.owner = self
+        self._layer_refs = other._layer_refs
+        return sh
+
     def _new_shard(self, n_layers):
         """One `brie_handle` (gene shard on one GPU) for this model; the only place a backend is chosen."""
         return _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
@@ -170,22 +196,21 @@ class BRIE2(object):
 
     def _start_result_buffers(self, sh):
         """Host destinations of Psi / Z_std / Psi95CI / Z_loc (what BRIE_RV reads, model_wrap.py:28-35), allocated
-        when the fit starts and page-locked by a background thread while the GPU optimises: the first-touch page
-        faults and the pinning (1.6 s for 16 GB at configs[2] when done inside the read) leave the critical path."""
+        when the fit starts and first-touched by a background thread while the GPU optimises: the page faults of
+        16 GB of fresh host memory (configs[2]) leave the critical path."""
         import threading
         bufs = {w: np.empty((self.Nc, self.Ng), np.float32) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
         pinned = []
 
-        def pin():
+        def touch():
+            # first touch only.  Page-locking them instead (brie_host_register) would let the copy engine write at
+            # PCIe speed, but registering GBs of user memory while kernels run stalls the device queues (measured:
+            # +1.0 s on the 996 steps of configs[2], profiles/r02d_e2e_fit_c3_pinned_while_running.json)
             for a in bufs.values():
-                try:
-                    _capi.host_register(a)
-                    pinned.append(a)
-                except Exception:                    # locked-memory limit: at least take the page faults now
-                    a.fill(0)
+                a.fill(0)
         th = None
         if getattr(sh, "pins_host", False):
-            th = threading.Thread(target=pin, daemon=True)
+            th = threading.Thread(target=touch, daemon=True)
             th.start()
         return bufs, pinned, th
 
@@ -236,6 +261,43 @@ class BRIE2(object):
     @property
     def Wg_loc(self):
         return _wrap(self._need().read(_capi.WG_LOC))
+
+    # ------------------------------------------------------------------ distribution accessors (model_TFProb.py:97-127)
+    @property
+    def Z(self):
+        """Posterior of the logit Psi: Normal(Z_loc, Z_std) (model_TFProb.py:112-116)."""
+        from .dist import Normal
+        return Normal(self.Z_loc, self.Z_std)
+
+    @property
+    def PsiDist(self):
+        """Posterior of Psi: LogitNormal(Z_loc, Z_std) (model_TFProb.py:97-100)."""
+        from .dist import LogitNormal
+        return LogitNormal(self.Z_loc, self.Z_std)
+
+    @property
+    def Z_prior(self):
+        """Prior of the logit Psi: Normal(Xc.Wc_loc + Wg_loc.Xg^T + intercept, sigma) (model_TFProb.py:118-127)."""
+        from .dist import Normal
+        loc = np.zeros((self.Nc, self.Ng), np.float32)
+        if self.Kc > 0 and self.Xc is not None:
+            loc = loc + np.matmul(np.asarray(self.Xc, np.float32), np.asarray(self.Wc_loc))
+        if self.Kg > 0 and self.Xg is not None:
+            loc = loc + np.matmul(np.asarray(self.Wg_loc), np.asarray(self.Xg, np.float32).T)
+        return Normal(loc + np.asarray(self.intercept), np.asarray(self.sigma))
+
+    def logLik_MC(self, count_layers, target="ELBO", size=10):
+        """Monte-Carlo log-likelihood of every (cell, gene) entry, (Nc, Ng) (model_TFProb.py:130-191): mean over
+        `size` samples from the posterior (ELBO) or log-mean-exp over samples from the prior (marginLik)."""
+        if target not in ("ELBO", "marginLik"):
+            raise ValueError("target=%r" % (target,))
+        sh = self._ensure_shard(count_layers, self.Xc, self.Xg)
+        saved = getattr(self, "target", "ELBO")
+        sh.set_target(target)
+        try:
+            return _wrap(sh.loglik_mc(size))
+        finally:
+            sh.set_target(saved)
 
     # ------------------------------------------------------------------ loss (model_TFProb.py:194-211)
     def get_loss(self, count_layers, target="ELBO", axis=None, **kwargs):
@@ -371,16 +433,26 @@ class BRIE2(object):
 
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
+        tm = self.timing = {"optimise_s": time.time() - start_time}
+        t0 = time.time()
         if staging is not None:              # results stream out on a second stream while loss_gene computes
             bufs, pinned, th = staging
             if th is not None:
                 th.join()
+            tm["wait_for_first_touch_s"] = time.time() - t0
             sh.read_results_async(bufs[_capi.PSI], bufs[_capi.Z_STD], bufs[_capi.PSI95CI], bufs[_capi.Z_LOC])
+        t0 = time.time()
         self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
+        tm["loss_gene_s"] = time.time() - t0
         if staging is not None:
+            t0 = time.time()
             sh.read_wait()
+            tm["read_wait_s"] = time.time() - t0
+            t0 = time.time()
             for a in pinned:
                 _capi.host_unregister(a)
+            tm["unpin_s"] = time.time() - t0
+            tm["pinned_arrays"] = len(pinned)
             self._results = bufs
         self.losses = _wrap(losses)
         self.n_iter = n_iter

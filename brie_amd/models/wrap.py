@@ -101,10 +101,10 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     full_base = base_mode.upper() == 'FULL'
     Xc_base = _design_for_base(Xc, LRT_index, base_mode, Nc)
 
-    def run(design, fit_seed, mode=intercept_mode, **extra):
+    def run(design, fit_seed, mode=intercept_mode, reuse=None, **extra):
         mdl = BRIE2(Nc=Nc, Ng=Ng, Kc=design.shape[1], Kg=Xg.shape[1], effLen=effLen, intercept=intercept,
                     intercept_mode=mode, sigma=sigma, tau_prior=tau_prior, seed=fit_seed, device=device,
-                    gene_offset=gene_offset, comm=comm)
+                    gene_offset=gene_offset, comm=comm, reuse=reuse)
         mdl.fit(data, Xc=design, Xg=Xg, pseudo_count=pseudo_count, **dict(fit_args, **extra))
         return mdl
 
@@ -120,11 +120,14 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
     if common_noise:
         sched = getattr(base, 'n_iter_batch', None)
         repeat = dict(n_iter_schedule=np.asarray(sched if sched is not None else [getattr(base, 'n_iter', 0)]))
-    base.close()
 
     tested = np.arange(Xc.shape[1]) if LRT_index is None else LRT_index            # model_wrap.py:149-153
     if len(tested) == 0:
+        base.close()
         return result
+    # every model of the test is fitted to the same count layers: the device copy (uploaded, pseudo-counted,
+    # compacted once) is handed from model to model (brie_reconfigure) instead of being rebuilt per model
+    carrier = base
 
     # ELBO gain per tested feature, in analogy to a likelihood ratio (model_wrap.py:155-187):
     # 'full' base: refit WITHOUT the feature, gain = loss(reduced) - loss(full);
@@ -141,14 +144,17 @@ def fit_BRIE_matrix(data, Xc=None, Xg=None, effLen=None, intercept=None, interce
         # the reference builds these models WITHOUT intercept_mode (model_wrap.py:174-178), i.e. always with
         # the 'gene' default, whatever the base model uses -- mirrored
         # only loss_gene (and the last weight row) of these models is read: no result matrices
-        other = run(design, seed if common_noise else seed + 1 + col, mode='gene', prefetch_results=False, **repeat)
+        other = run(design, seed if common_noise else seed + 1 + col, mode='gene', reuse=carrier,
+                    prefetch_results=False, **repeat)
+        carrier.close()
+        carrier = other
         other_loss = _host(other.loss_gene)
         if full_base:
             gain[:, col] = other_loss - result.loss_gene
         else:
             gain[:, col] = result.loss_gene - other_loss
             result.cell_coeff = np.append(result.cell_coeff, _host(other.Wc_loc)[-1:, :], axis=0)
-        other.close()
+    carrier.close()
 
     result.ELBO_gain = gain
     result.pval = elbo_gain_pval(gain)                                             # chi2.sf(2 gain, 1), :190

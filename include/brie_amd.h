@@ -100,6 +100,14 @@ typedef struct brie_handle brie_handle;
 int brie_create(const brie_problem *problem, brie_handle **out);
 int brie_destroy(brie_handle *h);
 
+/* The next model of a likelihood-ratio test (model_wrap.py:155-187: one fresh BRIE2 per tested feature, all of them
+ * fitted to the SAME count layers): the handle keeps its count layers exactly as they sit in HBM -- uploaded,
+ * pseudo-counted and compacted once -- and everything that depends on the design width and the seed is replaced
+ * (Xc, Wc_loc and its moments, the wide-design buffers; iteration, draw counter, loss ring, gene mask are reset).
+ * Afterwards: brie_upload(BRIE_XC), brie_init_state, fit.  Nc, Ng, the layers, effLen, Kg / Xg and the intercept mode
+ * stay as created. */
+int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_intercept, int32_t train_sigma);
+
 /* Copy a host or device matrix into the shard (densified fp32 layers of
  * model_wrap.py:108-111; Xc of model_TFProb.py:220; init_obj of :62-65). */
 int brie_upload(brie_handle *h, int which, const float *src,
@@ -195,6 +203,11 @@ int brie_attach_comm(brie_handle *h, brie_comm *c);
 /* model_TFProb.py:261-264: mean over `n_repeats` stochastic evaluations of
  * get_loss(axis=0) with MC_size = 1 -> out[Ng] (host). */
 int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out);
+
+/* BRIE2.logLik_MC (model_TFProb.py:130-191) per element: out[Nc][Ng] (host or device, `ld` elements between
+ * rows) = mean over `size` samples z ~ q of the log-likelihood (target ELBO, :159,191), or their log-mean-exp
+ * with z ~ prior (target marginLik, :157,188-189).  Consumes one noise draw id (samples k = 0..size-1). */
+int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld);
 
 /* BRIE_RV.__init__ (model_wrap.py:18-40): copy state / derived arrays out. */
 int brie_read(brie_handle *h, int which, float *dst,

@@ -36,7 +36,7 @@ class OracleBackedBRIE2(object):
 
     def __init__(self, Nc, Ng, Kc=0, Kg=0, effLen=None, intercept=None, intercept_mode='gene',
                  sigma=None, tau_prior=[3, 27], name=None, init_obj=None, seed=0, device=0, gene_offset=0,
-                 comm=None):
+                 comm=None, reuse=None):
         self.Nc, self.Ng, self.Kc, self.Kg = Nc, Ng, Kc, Kg
         self.intercept_mode = intercept_mode
         self.Xc = self.Xg = None
@@ -84,8 +84,11 @@ class OracleShard(object):
     """The `brie_amd._capi.Shard` surface that `BRIE2.fit` drives, answered by the CPU oracle: lets the CPU suite
     run the engine's REAL control flow (stages, per-batch stopping, gene masks, collectives) without a GPU."""
 
+    m = property(lambda self: self.owner)
+
     def __init__(self, model, n_layers):
-        self.m, self.n_layers = model, n_layers
+        self.owner, self.n_layers = model, n_layers
+        self.uploads = 0
         self.layers = [None] * n_layers
         self.Xc = self.Xg = None
         self.pc = None
@@ -97,6 +100,7 @@ class OracleShard(object):
         a = np.asarray(x.toarray() if hasattr(x, "toarray") else x, np.float32)
         if which in (_capi.COUNT1, _capi.COUNT2, _capi.COUNT3):
             self.layers[which - _capi.COUNT1] = a.copy()
+            self.uploads += 1
         elif which == _capi.XC:
             self.Xc = a
         elif which == _capi.XG:
@@ -104,6 +108,9 @@ class OracleShard(object):
 
     def add_pseudo_count(self, pc):
         self.pc = pc
+
+    def reconfigure(self, Kc, seed, train_intercept=True, train_sigma=True):
+        self.Xc, self.o, self.target = None, None, "ELBO"      # counts and pseudo-count stay
 
     def init_state(self, intercept=None, sigma=None):
         m = self.m

@@ -117,6 +117,21 @@ def part_c():
     ref_ids = np.array(["c%03d" % i for i in rng.permutation(50)])
     new_ids = np.array(["c%03d" % i for i in rng.permutation(70)[:40]])
     m = bu.match(ref_ids, new_ids)
+    # duplicated ref ids (uniq_ref_only=True, the default): 12 entries -- numpy's argsort is an insertion sort
+    # below 16 elements, i.e. stable, so the reference's answer is well defined here
+    dup_ref = np.array(["b", "a", "c", "a", "d", "b", "e", "a", "f", "g", "c", "h"])
+    dup_new = np.array(["h", "c", "a", "x", "b", "e"])
+    md = bu.match(dup_ref, dup_new)
+    md_all = bu.match(dup_ref, dup_new, uniq_ref_only=False)
+    # copy=False: in place, returns None
+    st = Stub({k: v.copy() for k, v in layers.items()})
+    ret = pp.filter_genes(st, copy=False, min_counts=50, min_counts_uniq=10, min_cells_uniq=30)
+    assert ret is None
+    inplace = dict(kept=st.kept, n_counts=st.var['n_counts'], n_left=st.layers['isoform1'].shape[1])
+    np.savez_compressed(os.path.join(HERE, "ref_match_dup_inplace.npz"), dup_ref=dup_ref, dup_new=dup_new,
+                        dup_idx=np.array([-1 if x is None else x for x in md], dtype=int),
+                        dup_idx_all=np.array([-1 if x is None else x for x in md_all], dtype=int),
+                        inplace=np.array([inplace], dtype=object))
     np.savez_compressed(os.path.join(HERE, "ref_filter_match.npz"), isoform1=layers['isoform1'],
                         isoform2=layers['isoform2'], ambiguous=layers['ambiguous'],
                         cases=np.array(cases, dtype=object), ref_ids=ref_ids, new_ids=new_ids,

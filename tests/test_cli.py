@@ -39,6 +39,31 @@ def test_filter_genes_and_match_against_reference_fragments():
     np.testing.assert_array_equal(got, g["match_idx"])
 
 
+def test_filter_genes_in_place_and_match_duplicates_against_reference():
+    """filter_genes(copy=False) filters the caller's object in place and returns None
+    (brie/utils/preprocessing.py:37,62,83; used that way at brie/bin/quant.py:70); match() with repeated ref ids
+    (brie/utils/base_utils.py:41-59, uniq_ref_only)."""
+    from brie_amd.preprocessing import filter_genes, match
+    g = np.load(os.path.join(GOLD, "ref_filter_match.npz"), allow_pickle=True)
+    d = np.load(os.path.join(GOLD, "ref_match_dup_inplace.npz"), allow_pickle=True)
+    ad = _count_data({k: g[k].copy() for k in ('isoform1', 'isoform2', 'ambiguous')})
+    names = np.array(ad.var.index)
+    ret = filter_genes(ad, copy=False, min_counts=50, min_counts_uniq=10, min_cells_uniq=30)
+    want = d["inplace"][0]
+    assert ret is None and ad.shape[1] == want["n_left"] and ad.layers['isoform2'].shape[1] == want["n_left"]
+    np.testing.assert_array_equal(np.isin(names, ad.var.index), want["kept"])
+    np.testing.assert_allclose(ad.var['n_counts'].values, want["n_counts"])
+
+    class Bare(object):
+        layers = {k: g[k] for k in ('isoform1', 'isoform2', 'ambiguous')}
+        shape = g['isoform1'].shape
+    with pytest.raises(TypeError):
+        filter_genes(Bare())
+    idx = lambda m: np.array([-1 if x is None else x for x in m], dtype=int)
+    np.testing.assert_array_equal(idx(match(list(d["dup_ref"]), list(d["dup_new"]))), d["dup_idx"])
+    np.testing.assert_array_equal(idx(match(list(d["dup_ref"]), list(d["dup_new"]), uniq_ref_only=False)), d["dup_idx_all"])
+
+
 def test_parser_defaults_match_reference_cli():
     from brie_amd.cli.quant import build_parser, parse_lrt_index
     o = build_parser().parse_args(["-i", "x.npz"])

@@ -315,3 +315,28 @@ def test_BRIE2_fit_streams_results_out(lib):
     np.testing.assert_array_equal(np.asarray(m2.Psi), np.asarray(m.Psi))
     np.testing.assert_array_equal(m2.loss_gene, m.loss_gene)
     m.close(); m2.close()
+
+
+def test_lrt_reuses_the_count_layers_bit_identically(lib, monkeypatch):
+    """LRT with the handle handed from model to model (brie_reconfigure; counts uploaded / compacted once) against
+    the same test with a fresh handle per model: every output bit for bit; also across a change of kernel variant
+    (Kc 9 -> 8: wide LDS path to register path)."""
+    import brie_amd
+    import brie_amd.models.wrap as wrap
+    from brie_amd.models.engine import BRIE2
+
+    class Fresh(BRIE2):                       # ignores `reuse`: one new handle per model, as in round 1
+        def __init__(self, *a, **kw):
+            kw.pop("reuse", None)
+            BRIE2.__init__(self, *a, **kw)
+    for Kc, L in ((2, 3), (9, 2)):
+        Nc, Ng = 120, 300
+        P = make_problem(Nc, Ng, Kc=Kc, L=L, seed=9, effect_frac=0.5, depth=6.0)
+        kw = dict(Xc=P["Xc"], effLen=P["effLen"], LRT_index=[0, Kc - 1], min_iter=120, max_iter=120, n_loss_gene=10,
+                  verbose=False, seed=4)
+        res = brie_amd.fit_BRIE_matrix([sp.csc_matrix(c) for c in P["counts"]], **kw)
+        monkeypatch.setattr(wrap, "BRIE2", Fresh)
+        ref = wrap.fit_BRIE_matrix([sp.csc_matrix(c) for c in P["counts"]], **kw)
+        monkeypatch.setattr(wrap, "BRIE2", BRIE2)
+        for key in ("ELBO_gain", "pval", "fdr", "Psi", "cell_coeff", "loss_gene", "sigma"):
+            np.testing.assert_array_equal(getattr(res, key), getattr(ref, key), err_msg="Kc=%d %s" % (Kc, key))

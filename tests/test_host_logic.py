@@ -260,3 +260,39 @@ def test_gene_shard_alignment():
     assert gene_shard(26, 1, 2, 8) == (16, 26) and gene_shard(26, 1, 2, 28) == (26, 26)
     with pytest.raises(ValueError):
         gene_shard(26, 0, 2, 6)
+
+
+def test_lrt_models_share_one_device_copy_of_the_counts(monkeypatch):
+    """fit_BRIE_matrix hands the count-holding handle from model to model (brie_reconfigure): the layers are uploaded
+    once for base + 2 test models, results equal the fresh-model-per-feature run (model_wrap.py:155-187)."""
+    import brie_amd.models.wrap as wrap
+    from tests.fakes import engine_on_oracle
+    Nc, Ng, Kc = 40, 12, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=2, seed=3)
+    E = engine_on_oracle()
+    monkeypatch.setattr(wrap, "BRIE2", E)
+    res = wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0, 1], **FIT)
+    assert len(E.instances) == 3
+    shards = [m._shard for m in E.instances]
+    assert shards == [None, None, None]                       # all closed / handed on
+    monkeypatch.setattr(wrap, "BRIE2", OracleBackedBRIE2)
+    ref = wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0, 1], **FIT)
+    np.testing.assert_allclose(res.ELBO_gain, ref.ELBO_gain, rtol=1e-5, atol=1e-4)
+    np.testing.assert_array_equal(res.Psi, ref.Psi)
+    # count the uploads on a second run with an instrumented backend
+    E2 = engine_on_oracle()
+    made = []
+    orig = E2._new_shard
+
+    def counting(self, n_layers):
+        sh = orig(self, n_layers)
+        made.append(sh)
+        return sh
+    E2._new_shard = counting
+    monkeypatch.setattr(wrap, "BRIE2", E2)
+    wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0, 1], **FIT)
+    assert len(made) == 1 and made[0].uploads == 2            # ONE handle, each layer uploaded once
+    # a cell-mode base cannot hand its handle to the gene-mode test models: fresh handles, same answers
+    made.clear()
+    wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0], intercept_mode='cell', **FIT)
+    assert len(made) == 2

@@ -45,7 +45,9 @@ philox.py             shared counter-based N(0,1) stream (Philox4x32-10 + Box-Mu
 brie_oracle.py        NumPy restatement with hand-derived gradients (fp32 / fp64)
 brie_oracle_torch.py  eager torch-CPU autograd restatement in the reference's
                       execution shape; also the `cpu_baseline` ("port") of bench.py
-brie_oracle.c         fused C / OpenMP restatement of the step (second implementation; "cpu_baseline_fused")
+brie_oracle.c         fused C / OpenMP restatement of the step (second implementation; "cpu_baseline_fused"); built twice:
+                      fp32 = the reference's precision, -DBRIE_ORACLE_F64 = the same code in double (the
+                      precision-independent answer of profiles/psi_delta.py and the parity rule in tests/util.py)
 c_oracle.py           gcc build + ctypes driver of brie_oracle.c
 sim_oracle.c / .py    count simulator (brie/models/simulator.py): exact binomial / multinomial sampling from the
                       Philox stream; distribution pinned against scipy (tests/test_oracle_sim.py)

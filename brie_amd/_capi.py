@@ -30,7 +30,7 @@ EXPORTS = [
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
-    "brie_loglik_mc",
+    "brie_loglik_mc", "brie_debug_address",
 ]
 COMM_ID_BYTES = 128
 
@@ -116,6 +116,7 @@ def load_library(path=None):
     lib.brie_attach_comm.argtypes = [vp, vp]
     lib.brie_read_results_async.argtypes = [vp, vp, vp, vp, vp, i64]
     lib.brie_read_wait.argtypes = [vp]
+    lib.brie_debug_address.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.brie_loglik_mc.argtypes = [vp, i32, vp, i64]
     lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
@@ -431,6 +432,11 @@ class Shard(object):
             _check(self.lib, self.lib.brie_read(self._h, which, out.ctypes.data_as(ctypes.c_void_p),
                                                 shape[0], shape[1], shape[1]))
         return out
+
+    def debug_address(self, which):
+        a = ctypes.c_uint64()
+        _check(self.lib, self.lib.brie_debug_address(self._h, int(which), ctypes.byref(a)))
+        return a.value
 
     def loglik_mc(self, size=10):
         """(Nc, Ng) Monte-Carlo log-likelihood of every entry under the current target (brie_loglik_mc)."""

@@ -16,9 +16,11 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbrie_amd.so")
-SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip"), os.path.join(CSRC, "brie_comm.hip")]
+SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip"), os.path.join(CSRC, "brie_comm.hip"),
+           os.path.join(CSRC, "brie_tile_inst.hip")]
 HEADERS = [os.path.join(CSRC, "brie_kernels.hip.h"), os.path.join(CSRC, "brie_launch.h"),
-           os.path.join(CSRC, "brie_comm_internal.h"), os.path.join(ROOT, "include", "brie_amd.h")]
+           os.path.join(CSRC, "brie_comm_internal.h"), os.path.join(CSRC, "brie_tile.hip.h"),
+           os.path.join(ROOT, "include", "brie_amd.h")]
 MAX_KC = 8
 
 
@@ -52,6 +54,9 @@ def compile_library(force=False, fast_math=None, verbose=False, out=None, define
     base += ["-D" + d for d in defines]
     units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), []),
              (os.path.join(CSRC, "brie_comm.hip"), os.path.join(obj_dir, "brie_comm.o"), [])]   # RCCL, bound by dlopen
+    for mode in range(3):             # MFMA tile kernel of the wide designs: one unit per likelihood mode
+        units.append((os.path.join(CSRC, "brie_tile_inst.hip"), os.path.join(obj_dir, "brie_tile_mode%d.o" % mode),
+                      ["-DBRIE_TILE_MODE=%d" % mode]))
     for kc in range(MAX_KC + 1):
         units.append((os.path.join(CSRC, "brie_inst.hip"), os.path.join(obj_dir, "brie_inst_kc%d.o" % kc),
                       ["-DBRIE_KC=%d" % kc]))

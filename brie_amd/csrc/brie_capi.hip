@@ -4,6 +4,7 @@
 #include "brie_amd.h"
 #define BRIE_HOST_TU 1
 #include "brie_launch.h"
+#include "brie_tile.hip.h"
 #include "brie_comm_internal.h"
 
 #include <algorithm>
@@ -92,6 +93,12 @@ struct brie_handle {
     // wide cell designs (Kc > BRIE_MAX_KC): W tile in LDS for Xc.W, MFMA kernel for Xc^T.r
     bool wide = false;
     int kernel_kc = 0;              // KC of the kernel instantiation (0 for wide designs)
+    // Wide designs on the matrix cores (brie_tile.hip.h): Kc > 8 and / or Kg > 4 with forward and backward products
+    // fused into the streaming pass.  wide_like = the per-gene statistics carry no Xc rows (S = 4), Wc_loc is updated
+    // from Gpart by wide_w_adam and loss_gene takes Xc.Wc_loc from Mbuf -- true for `wide` and for every tile handle.
+    bool tile = false, wide_like = false;
+    int tile_lds = 0, tile_nacc = 0, tile_njt = 0;
+    size_t gpart_elems = 0, rbuf_elems = 0;
     float *Mbuf = nullptr;          // (Nc, ld) tiled: Xc.Wc_loc for loss_gene_eval (allocated on first use)
     float *Rbuf = nullptr;          // (Nc, ld) tiled: residual r written by the step kernel
     float *Gpart = nullptr;         // (n_gchunks, Kc, ld): per-chunk partial sums of Xc^T . r
@@ -170,6 +177,34 @@ int alloc_f32(float **p, size_t elems, hipStream_t s) {
     return BRIE_OK;
 }
 
+// decide the kernel family of this handle from (Kc, Kg, layout); called at create and at brie_reconfigure
+void setup_paths(brie_handle *h) {
+    const int Kc = h->p.Kc;
+    h->wide = Kc > BRIE_MAX_KC;
+    const char *wp = getenv("BRIE_WIDE_PATH");         // "lds": the round-1 LDS-broadcast variants (A/B runs)
+    const bool want_tile = !(wp && strcmp(wp, "lds") == 0);
+    const int kgp = h->coupled ? h->kgp : 0;
+    h->tile_lds = static_cast<int>(sizeof(float)) *
+                  (brie::kTileRows * brie::kTileStride + Kc * brie::kGenesPerBlock + kgp * brie::kXgStride);
+    h->tile = want_tile && h->tiled && (h->wide || h->gwide) && h->tile_lds <= 160 * 1024;
+    h->wide_like = h->wide || h->tile;
+    h->tile_nacc = Kc == 0 ? 0 : (Kc <= 32 ? 1 : 2);
+    h->tile_njt = !h->coupled ? 0 : (kgp <= 32 ? 1 : 2);
+    h->kernel_kc = h->wide_like ? 0 : Kc;
+    h->S = h->kernel_kc + 4;
+    h->n_gchunks = static_cast<int>((h->p.Nc + h->gchunk_rows - 1) / h->gchunk_rows);
+}
+
+int ensure_f32(float **p, size_t *have, size_t need, hipStream_t s) {
+    if (need <= *have) return BRIE_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    int rc = alloc_f32(p, need, s);
+    if (rc == BRIE_OK) *have = need;
+    return rc;
+}
+
 void configure_tiling(brie_handle *h) {
     const int64_t Nc = h->p.Nc;
     h->gene_blocks = static_cast<int>((h->p.Ng + brie::kGenesPerBlock - 1) / brie::kGenesPerBlock);
@@ -212,12 +247,20 @@ int check_ready(const brie_handle *h) {
 
 void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
                  const brie::StepScalars &a, const brie::CoupledArgs &cp) {
-    if (h->wide) { brie::launch_step_wide(c, q, a, cp); return; }
+    if (h->wide_like) { brie::launch_step_wide(c, q, a, cp); return; }
     switch (h->p.Kc) {
 #define BRIE_CASE(N) case N: brie::launch_step_kc##N(c, q, a, cp); break;
         BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
         default: brie::launch_step_kc8(c, q, a, cp); break;
 #undef BRIE_CASE
+    }
+}
+void launch_tile(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q, const brie::StepScalars &a,
+                 const brie::TileArgs &t) {
+    switch (h->mode) {
+        case brie::kLik2: brie::launch_tile_mode0(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_lds); break;
+        case brie::kLikEff2: brie::launch_tile_mode1(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_lds); break;
+        default: brie::launch_tile_mode2(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_lds); break;
     }
 }
 void launch_margin(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
@@ -587,9 +630,6 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         if (h->tiled) { h->row_stride = brie::kGenesPerBlock; h->gb_stride = p->Nc * brie::kGenesPerBlock; }
         else { h->row_stride = h->ld; h->gb_stride = brie::kGenesPerBlock; }
     }
-    h->wide = p->Kc > BRIE_MAX_KC;
-    h->kernel_kc = h->wide ? 0 : p->Kc;
-    h->S = h->kernel_kc + 4;
     h->mode = !p->has_efflen ? brie::kLik2 : (p->n_layers == 3 ? brie::kLikEff3 : brie::kLikEff2);
     int rc = set_device(h);
     if (rc != BRIE_OK) { delete h; return rc; }
@@ -610,12 +650,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->gene_active, vec);
     A(h->ring_kl, vec * brie::kLossRing);
     A(h->ring_ll, vec * brie::kLossRing);
-    if (h->wide) {
-        if (!h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout"); }
-        h->n_gchunks = static_cast<int>((p->Nc + h->gchunk_rows - 1) / h->gchunk_rows);
-        A(h->Rbuf, mat);
-        A(h->Gpart, vec * p->Kc * h->n_gchunks);
-    }
+    if (p->Kc > BRIE_MAX_KC && !h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout"); }
     h->cell_mode = p->intercept_mode == 1;
     h->coupled = p->Kg > 0 || h->cell_mode;
     if (h->coupled) {
@@ -630,6 +665,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         A(h->rowstat, nc * (h->kgp + 2));
     }
 #undef A
+    setup_paths(h);                 // kernel family: register path, LDS-broadcast wide variants, or the MFMA tile kernel
     configure_tiling(h);
     {
         const char *pk = getenv("BRIE_PACK_ACTIVE");
@@ -669,7 +705,7 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
     HIP_TRY(hipStreamSynchronize(h->stream));
     const bool wide = Kc > BRIE_MAX_KC;
     if (wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
-    const size_t vec = static_cast<size_t>(h->ld), mat = static_cast<size_t>(h->p.Nc) * h->ld;
+    const size_t vec = static_cast<size_t>(h->ld);
     float **drop[] = {&h->Xc, &h->W, &h->m_W, &h->v_W, &h->Rbuf, &h->Gpart, &h->Mbuf};
     for (float **q : drop) {
         if (*q) HIP_TRY(hipFree(*q));
@@ -678,17 +714,10 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
 #define A(ptr, n) if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) return rc;
     A(h->Xc, static_cast<size_t>(h->p.Nc) * Kc);
     A(h->W, vec * Kc); A(h->m_W, vec * Kc); A(h->v_W, vec * Kc);
-    h->n_gchunks = 0;
-    if (wide) {
-        h->n_gchunks = static_cast<int>((h->p.Nc + h->gchunk_rows - 1) / h->gchunk_rows);
-        A(h->Rbuf, mat);
-        A(h->Gpart, vec * Kc * h->n_gchunks);
-    }
 #undef A
+    h->gpart_elems = h->rbuf_elems = 0;
     h->p.Kc = Kc; h->p.seed = seed; h->p.train_intercept = train_intercept; h->p.train_sigma = train_sigma;
-    h->wide = wide;
-    h->kernel_kc = wide ? 0 : Kc;
-    h->S = h->kernel_kc + 4;
+    setup_paths(h);
     if (h->row_scratch) { HIP_TRY(hipFree(h->row_scratch)); h->row_scratch = nullptr; }   // sized by max(ring, Kc)
     h->have_xc = false;
     h->have_state = false;
@@ -963,7 +992,7 @@ int brie_set_gene_mask(brie_handle *h, const uint8_t *active) {
     HIP_TRY(hipMemcpyAsync(h->gene_active, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->mask_host = mask;
-    if (any_frozen && h->allow_pack && !h->wide) {
+    if (any_frozen && h->allow_pack && !h->wide_like) {
         // pack: quads with an active gene first (stable), fully frozen quads after them; whole 256-gene
         // blocks at the tail then hold no active gene and are skipped by the kernels
         const int nq = static_cast<int>(h->ld / 4);
@@ -1030,7 +1059,8 @@ int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
 
 int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
-    const int64_t gemm_streams = h->wide ? 8 : 0;        // residual r written by the step, read by wide_design_grad
+    // LDS-broadcast wide variants: residual r written by the step, read back by wide_design_grad (the tile kernel keeps it on chip)
+    const int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
     if (h->cs == brie::kCountMixed) {                    // genes of u8 blocks move 1 byte per count, of u16 blocks 2
         int64_t genes16 = 0;
         for (int g = 0; g < h->gene_blocks; ++g)
@@ -1109,7 +1139,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (split == 0 && h->coupled && h->p.sharded != 0 && !lib_reduce)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: attach a communicator "
                     "(brie_attach_comm) or use brie_step_begin / all-reduce brie_rowstat_buffer / brie_step_end");
-    if (h->wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
+    if (h->wide_like && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = io_wait(h)) != BRIE_OK) return rc;
@@ -1144,13 +1174,26 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
-    a.kc_wide = h->wide ? h->p.Kc : 0;
+    a.kc_wide = h->wide_like ? h->p.Kc : 0;
     a.pc = h->pc;
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
+    // wide designs: the MFMA tile kernel (ELBO target), else the LDS-broadcast variants + residual buffer
+    const bool use_tile = h->tile && h->target == 0;
+    if (h->wide_like && h->p.Kc > 0) {
+        const size_t chunks = static_cast<size_t>(std::max(use_tile ? h->n_chunks : 0, h->n_gchunks));
+        if ((rc = ensure_f32(&h->Gpart, &h->gpart_elems, chunks * h->p.Kc * h->ld, h->stream)) != BRIE_OK) return rc;
+    }
+    if (h->wide_like && !use_tile &&
+        (rc = ensure_f32(&h->Rbuf, &h->rbuf_elems, static_cast<size_t>(h->p.Nc) * h->ld, h->stream)) != BRIE_OK)
+        return rc;
     brie::LaunchCfg cfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0};
     cfg.rbuf = h->Rbuf;
+    brie::TileArgs ta{};
+    ta.Xc = h->Xc; ta.W = h->W; ta.Xg = h->Xg; ta.Wg = h->Wg; ta.cb = h->cb; ta.clam = h->clam;
+    ta.row_partials = h->row_partials; ta.Gpart = h->Gpart;
+    ta.Kc = h->p.Kc; ta.Kg = h->p.Kg; ta.kgp = h->coupled ? h->kgp : 0; ta.cell_mode = h->cell_mode ? 1 : 0;
     // target="marginLik": uncoupled models with Kc <= 8 have their own light kernel, the others the MARGIN variants
-    const bool simple_margin = h->target == 1 && !h->coupled && !h->wide;
+    const bool simple_margin = h->target == 1 && !h->coupled && !h->wide_like;
     cfg.margin = (h->target == 1 && !simple_margin) ? 1 : 0;
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
@@ -1196,14 +1239,21 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                 c2.grid.x = ti == 0 ? h->n8 : h->n16;
                 a2.block_list = ti == 0 ? h->list8 : h->list16;
                 a2.count_off = h->count_off;
-                if (simple_margin) launch_margin(h, c2, q, a2);
+                if (use_tile) launch_tile(h, c2, q, a2, ta);
+                else if (simple_margin) launch_margin(h, c2, q, a2);
                 else launch_step(h, c2, q, a2, cp);
             }
-        } else if (simple_margin) launch_margin(h, cfg, q, a);
+        } else if (use_tile) launch_tile(h, cfg, q, a, ta);
+        else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
-        if (h->wide && (rc = wide_backward(h, alpha)) != BRIE_OK) return rc;     // G = Xc^T . r (MFMA), Adam on Wc_loc
+        if (use_tile && h->p.Kc > 0) {            // G = Xc^T . r was reduced inside the pass: Adam on Wc_loc
+            const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
+            hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
+                               h->n_chunks, alpha, h->gene_active, h->ld);
+        } else if (h->wide_like && h->p.Kc > 0 && (rc = wide_backward(h, alpha)) != BRIE_OK)
+            return rc;                            // residual buffer -> G = Xc^T . r (MFMA kernel), Adam on Wc_loc
         if (h->coupled && lib_reduce && !split) {
             // gene shard of a coupled fit: local sums -> RCCL all-reduce on this stream -> Adam, all enqueued
             brie::CellFinalizeArgs c1 = cf, c2 = cf;
@@ -1318,12 +1368,13 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.coupled = h->coupled ? 1 : 0;
     a.margin = h->target == 1 ? 1 : 0;
     a.mbuf = nullptr;
-    if (h->wide) {
+    const bool xw_in_mbuf = h->wide_like && h->p.Kc > 0;
+    if (xw_in_mbuf) {
         if ((rc = wide_forward_mean(h)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
     if (h->gwide) {          // after the wide cell design's Xc . Wc_loc, if any (same buffer)
-        if ((rc = gwide_forward_mean(h, h->wide)) != BRIE_OK) return rc;
+        if ((rc = gwide_forward_mean(h, xw_in_mbuf)) != BRIE_OK) return rc;
         a.mbuf = h->Mbuf;
     }
     a.cp.Xg = h->Xg; a.cp.Wg = h->Wg; a.cp.cb = h->cb; a.cp.clam = h->clam; a.cp.row_partials = nullptr;
@@ -1578,6 +1629,25 @@ int brie_host_register(void *ptr, int64_t bytes) {
 int brie_host_unregister(void *ptr) {
     if (!ptr) return fail(BRIE_ERR_INVALID, "null argument");
     HIP_TRY(hipHostUnregister(ptr));
+    return BRIE_OK;
+}
+
+// measurement aid: device address of a cell x gene array (0..2 count layers as stored, 8 Z_loc, 9 Z_std_log,
+// 20..23 the Adam moments m/v of Z_loc, m/v of Z_std_log)
+int brie_debug_address(brie_handle *h, int which, uint64_t *addr) {
+    if (!h || !addr) return fail(BRIE_ERR_INVALID, "null argument");
+    const void *p = nullptr;
+    switch (which) {
+        case 0: case 1: case 2: p = h->cs == brie::kCountF32 ? static_cast<const void *>(h->c[which]) : h->cu[which]; break;
+        case BRIE_Z_LOC: p = h->mu; break;
+        case BRIE_Z_STD_LOG: p = h->rho; break;
+        case 20: p = h->m_mu; break;
+        case 21: p = h->v_mu; break;
+        case 22: p = h->m_rho; break;
+        case 23: p = h->v_rho; break;
+        default: return fail(BRIE_ERR_INVALID, "array %d", which);
+    }
+    *addr = reinterpret_cast<uint64_t>(p);
     return BRIE_OK;
 }
 

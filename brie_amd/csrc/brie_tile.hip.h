@@ -1,0 +1,380 @@
+// brie_tile.hip.h -- the step kernel for WIDE designs: cell features Kc = 9..64 and / or gene features Kg = 5..64.
+//
+// These are the only places of the path with a genuine dense contraction (2 Nc Ng K FLOP per product):
+//   forward   M = Xc . Wc_loc + Wg_loc . Xg^T                 (model_TFProb.py:122-125)
+//   backward  G = Xc^T . R   (gradient of Wc_loc, over cells)  and  P = R . Xg (gradient of Wg_loc, over genes)
+// with R the residual (mu - m) / sigma^2.  All three run on the matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
+// fma chains) INSIDE the streaming pass, so nothing but the state and the counts touches HBM:
+//
+//   a workgroup (4 waves) owns one 256-gene block and one cell chunk and walks it in tiles of 32 cells:
+//     A  forward: every wave computes 2 of the 8 32-gene column blocks of the 32 x 256 prior-mean tile with MFMAs
+//        (B operands from the Wc_loc / Xg tiles of the gene block in LDS, A operands = the tile's design rows
+//        straight from L2) and drops it into the LDS tile T;
+//     B  stream: wave w takes rows w, w+4, ... of the tile exactly like elbo_adam_step (lane owns 4 genes, 16-B
+//        non-temporal loads, next row prefetched under the current row's arithmetic), reads its prior mean from T
+//        (one ds_read_b128) and writes the residual back to the same place;
+//     C  backward: G += Xc^T . T on the wave's 2 column blocks (accumulators live in registers for the whole
+//        chunk), P = T . Xg with the 256 genes of the contraction split over the 4 waves and folded through LDS,
+//        one coalesced store of the tile's 32 x kgp per-cell statistics.
+//
+// Replaces (measured in DESIGN 4.5): the v_readlane + ds_read_b128 + 4 FMA per feature of the LDS-broadcast
+// variants, the 8 B/element residual round trip through HBM and the separate wide_design_grad launch.
+#pragma once
+#include "brie_kernels.hip.h"
+
+namespace brie {
+
+constexpr int kTileRows = 32;
+constexpr int kTileStride = kGenesPerBlock + 4;      // floats per tile row: 16-B aligned rows, column reads 4-way banked
+constexpr int kXgStride = kGenesPerBlock + 1;        // Xg tile rows: conflict-free when lanes walk features
+
+struct TileArgs {
+    const float *Xc;            // (Nc, Kc)
+    const float *W;             // (Kc, ld)
+    const float *Xg;            // (kgp, ld) transposed gene features, zero beyond Kg / Ng
+    const float *Wg;            // (Nc, kgp)
+    const float *cb, *clam;     // (Nc) per-cell intercept / log sigma (cell mode)
+    float *row_partials;        // (gene_blocks, (kgp + 2) * Nc)
+    float *Gpart;               // (n_chunks, Kc, ld) partial sums of Xc^T . R
+    int32_t Kc, Kg, kgp, cell_mode;
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// NACC = 32-feature accumulator sets for Xc^T.R (0: Kc == 0, 1: Kc <= 32, 2: Kc <= 64)
+// NJT  = 32-feature output tiles of R.Xg        (0: Kg == 0, 1: kgp <= 32, 2: kgp <= 64)
+template <int MODE, int CS, int NACC, int NJT>
+__global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
+    const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
+    float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
+    float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
+    const float *__restrict__ bp, const float *__restrict__ lamp, const float *__restrict__ effL,
+    float *__restrict__ partials, const StepScalars a, const TileArgs t) {
+    constexpr int S = 4;
+    constexpr bool CPL = NJT > 0;           // per-cell statistics are only produced with gene features / cell mode
+    // dynamic LDS: [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257]; the cross-wave folds reuse T
+    extern __shared__ __align__(16) float lds[];
+    float *T = lds;
+    float *wl = T + kTileRows * kTileStride;
+    float *xl = wl + t.Kc * kGenesPerBlock;
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int quad = gb * kWave + lane;
+    const int j0 = quad * kVec;
+    const bool active = j0 < a.Ng;
+    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+    if (a.block_active[gb] == 0) return;
+    const bool cell = CPL && t.cell_mode != 0;
+
+    for (int i = threadIdx.x; i < t.Kc * kGenesPerBlock; i += kBlock)
+        wl[i] = t.W[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
+    if constexpr (NJT > 0) {
+        for (int i = threadIdx.x; i < t.kgp * kGenesPerBlock; i += kBlock)
+            xl[(i / kGenesPerBlock) * kXgStride + (i % kGenesPerBlock)] =
+                t.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
+    }
+
+    float acc[S][kVec];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
+    f32x16 G[NACC > 0 ? NACC : 1][2];
+#pragma unroll
+    for (int n = 0; n < (NACC > 0 ? NACC : 1); ++n)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) G[n][c][q] = 0.0f;
+
+    // per-gene parameters of the lane's 4 genes
+    float bj[kVec], lamj[kVec], isig2[kVec];
+    float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+    {
+        const F4 tb = ld4(bp + j0), tl = ld4(lamp + j0);
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            bj[v] = tb.v[v];
+            lamj[v] = tl.v[v];
+            isig2[v] = f_exp(-2.0f * tl.v[v]);
+        }
+    }
+    if (MODE != kLik2) {
+        const F4 t0 = ld4(effL + 0 * a.ld + j0), t1 = ld4(effL + 1 * a.ld + j0), t2 = ld4(effL + 2 * a.ld + j0),
+                 t3 = ld4(effL + 3 * a.ld + j0), t4 = ld4(effL + 4 * a.ld + j0), t5 = ld4(effL + 5 * a.ld + j0);
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
+            lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
+    }
+    const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
+    const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
+    const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
+    bool on[kVec], real[kVec];
+    {
+        const F4 tt = ld4(a.gene_active + j0);
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) { on[v] = tt.v[v] != 0.0f; real[v] = j0 + v < a.Ng; }
+    }
+    __syncthreads();                                       // W / Xg tiles complete
+
+    auto load_row = [&](int r, RowRegs<CS> &R) {
+        const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt);
+        R.mu = ld4s(mu_p + off);
+        R.rho = ld4s(rho_p + off);
+        R.mm = ld4s(mmu_p + off);
+        R.vm = ld4s(vmu_p + off);
+        R.mr = ld4s(mrho_p + off);
+        R.vr = ld4s(vrho_p + off);
+    };
+
+    // one streamed row: prior mean from T[ti], residual back to T[ti]
+    auto process_row = [&](int r, int ti, RowRegs<CS> &R) {
+        const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+        float *trow = T + ti * kTileStride + lane * kVec;
+        const F4 mt = ld4(trow);
+        const float cbr = cell ? t.cb[r] : 0.0f, clamr = cell ? t.clam[r] : 0.0f;
+        const float row_isig2 = cell ? f_exp(-2.0f * clamr) : 0.0f;
+        F4 c1, c2, c3;
+        decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
+        float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f}, ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) s[v] = f_exp(R.rho.v[v]);
+        for (int k = 0; k < a.mc; ++k) {
+            float e[kVec];
+            normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                const float z = fmaf(s[v], e[v], R.mu.v[v]);
+                float l, g;
+                loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
+                ll[v] += l;
+                gbar[v] += g;
+                gse[v] = fmaf(g, e[v], gse[v]);
+            }
+        }
+        F4 res;
+        float srow = 0.0f, lrow = 0.0f;                    // per-cell sums over the lane's real genes
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            const float m = mt.v[v] + (cell ? cbr : bj[v]);
+            const float is2 = cell ? row_isig2 : isig2[v];
+            const float d = R.mu.v[v] - m;
+            const float rr = d * is2;
+            const float s2r = s[v] * s[v] * is2;
+            const float dl = R.rho.v[v] - (cell ? clamr : lamj[v]);
+            const float kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;
+            const float lamstat = 1.0f - d * rr - s2r;
+            const float g_mu = rr - gbar[v] * a.inv_mc;
+            const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
+            const float n_mm = R.mm.v[v] + (g_mu - R.mm.v[v]) * kOneMinusB1;
+            const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
+            const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
+            const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
+            float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
+            nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);
+            const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
+            R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
+            R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
+            R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
+            R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
+            R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
+            R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
+            res.v[v] = real[v] ? rr : 0.0f;                // padding genes are not part of any contraction
+            srow += real[v] ? rr : 0.0f;
+            lrow += real[v] ? lamstat : 0.0f;
+            acc[0][v] += rr;
+            acc[1][v] += lamstat;
+            acc[2][v] += kl;
+            acc[3][v] += ll[v] * a.inv_mc;
+        }
+        st4(trow, res);
+        if (active) {
+            st4s(mu_p + off, R.mu);
+            st4s(rho_p + off, R.rho);
+            st4s(mmu_p + off, R.mm);
+            st4s(vmu_p + off, R.vm);
+            st4s(mrho_p + off, R.mr);
+            st4s(vrho_p + off, R.vr);
+        }
+        if constexpr (CPL) {                                // sum_j r and sum_j (1 - d r - s2r) of this cell over the block
+            float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
+            const float ts = wave_sum(active ? srow : 0.0f), tl2 = wave_sum(active ? lrow : 0.0f);
+            if (lane == 0) {
+                chunk[static_cast<int64_t>(t.kgp) * a.Nc + r] = ts;
+                chunk[static_cast<int64_t>(t.kgp + 1) * a.Nc + r] = tl2;
+            }
+        }
+    };
+
+    const int kc2 = (t.Kc + 1) >> 1, kg2 = (t.kgp + 1) >> 1;
+    RowRegs<CS> cur;
+    load_row(min(row0 + w, row_end - 1), cur);             // (a wave without rows in this chunk loads one and drops it)
+
+    for (int tr0 = row0; tr0 < row_end; tr0 += kTileRows) {
+        // ---- A: prior-mean tile on the matrix cores: T[i][gene] = sum_k X[i][k] W[k][gene] + sum_k Wg[i][k] Xg[gene][k]
+        {
+            f32x16 D[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) D[c][q] = 0.0f;
+            const int ar = tr0 + l31;                       // the lane's A row (cell)
+            const bool arow_ok = ar < row_end;
+            for (int kk = 0; kk < kc2; ++kk) {
+                const int k = 2 * kk + half;
+                const bool ok = arow_ok && k < t.Kc;
+                const float av = ok ? t.Xc[static_cast<int64_t>(ar) * t.Kc + k] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float bv = k < t.Kc ? wl[k * kGenesPerBlock + (2 * w + c) * 32 + l31] : 0.0f;
+                    D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
+                }
+            }
+            if constexpr (NJT > 0) {
+                for (int kk = 0; kk < kg2; ++kk) {
+                    const int k = 2 * kk + half;
+                    const bool ok = arow_ok && k < t.kgp;
+                    const float av = ok ? t.Wg[static_cast<int64_t>(ar) * t.kgp + k] : 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float bv = k < t.kgp ? xl[k * kXgStride + (2 * w + c) * 32 + l31] : 0.0f;
+                        D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                    T[i * kTileStride + (2 * w + c) * 32 + l31] = D[c][q];
+                }
+        }
+        __syncthreads();
+
+        // ---- B: stream the wave's rows of this tile (software-pipelined: next row's loads under this row's math)
+        {
+            const int t_end = min(tr0 + kTileRows, row_end);
+            int r = tr0 + w;
+            while (r < t_end) {
+                const int rn = r + kWavesPerBlock;          // next row of this wave (may belong to the next tile)
+                RowRegs<CS> nxt;
+                // branch-free prefetch (a guarded load would put a join -- and a full vmcnt wait -- right behind it):
+                // past the chunk's end the wave's own row is fetched again, an L2 hit
+                load_row(rn < row_end ? rn : r, nxt);
+                process_row(r, r - tr0, cur);
+                cur = nxt;
+                r = rn;
+            }
+        }
+        __syncthreads();
+
+        // ---- C: backward contractions of the residual tile
+        if constexpr (NACC > 0) {           // G[feature][gene] += sum_cells X[cell][feature] T[cell][gene]
+            for (int kk = 0; kk < kTileRows / 2; ++kk) {
+                const int rr_ = tr0 + 2 * kk + half;
+                const bool ok = rr_ < row_end;
+                float av[NACC];
+#pragma unroll
+                for (int n = 0; n < NACC; ++n) {
+                    const int f = l31 + 32 * n;
+                    av[n] = (ok && f < t.Kc) ? t.Xc[static_cast<int64_t>(rr_) * t.Kc + f] : 0.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const float bv = ok ? T[(2 * kk + half) * kTileStride + (2 * w + c) * 32 + l31] : 0.0f;
+#pragma unroll
+                    for (int n = 0; n < NACC; ++n) G[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv, G[n][c], 0, 0, 0);
+                }
+            }
+        }
+        if constexpr (NJT > 0) {            // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature]; wave w: genes 64w..64w+63
+            f32x16 P[NJT];
+#pragma unroll
+            for (int n = 0; n < NJT; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) P[n][q] = 0.0f;
+            for (int kk = 0; kk < 32; ++kk) {
+                const int g = 64 * w + 2 * kk + half;
+                const float av = T[l31 * kTileStride + g];                // A[i = cell][k = gene]
+#pragma unroll
+                for (int n = 0; n < NJT; ++n) {
+                    const int f = l31 + 32 * n;
+                    const float bv = f < t.kgp ? xl[f * kXgStride + g] : 0.0f;   // B[k = gene][j = feature]
+                    P[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, P[n], 0, 0, 0);
+                }
+            }
+            __syncthreads();                // every wave is done reading T: it now carries the 4 partial P tiles
+            // partial of wave w at T[w * 32*64 ...] as [cell i][feature f] (stride 64)
+#pragma unroll
+            for (int n = 0; n < NJT; ++n)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                    T[w * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
+                }
+            __syncthreads();
+            float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
+            for (int e = threadIdx.x; e < kTileRows * t.kgp; e += kBlock) {
+                const int i = e / t.kgp, f = e - i * t.kgp;
+                if (tr0 + i < row_end) {
+                    const int o = i * 64 + f;
+                    chunk[static_cast<int64_t>(tr0 + i) * t.kgp + f] =
+                        (T[o] + T[kTileRows * 64 + o]) + (T[2 * kTileRows * 64 + o] + T[3 * kTileRows * 64 + o]);
+                }
+            }
+        }
+        __syncthreads();                    // T is free for the next tile's forward product
+    }
+
+    // G accumulators -> this chunk's partial sums (summed over chunks in fp64 by wide_w_adam)
+    if constexpr (NACC > 0) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int f = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * n;
+                    if (f < t.Kc)
+                        t.Gpart[(static_cast<int64_t>(blockIdx.y) * t.Kc + f) * a.ld + gb * kGenesPerBlock + (2 * w + c) * 32 + l31] =
+                            G[n][c][q];
+                }
+    }
+
+    // fold the 4 waves' per-gene partials through LDS (T is free), wave 0 writes the chunk row
+    if (w > 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) T[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
+    }
+    __syncthreads();
+    if (w == 0 && active) {
+        float *dst = partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            F4 o;
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                float tt = acc[s][v];
+#pragma unroll
+                for (int ww = 0; ww < kWavesPerBlock - 1; ++ww) tt += T[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
+                o.v[v] = tt;
+            }
+            st4(dst + s * a.ld, o);
+        }
+    }
+}
+
+}  // namespace brie

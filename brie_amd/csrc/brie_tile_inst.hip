@@ -1,0 +1,47 @@
+// brie_tile_inst.hip -- instantiates elbo_adam_step_tile for ONE likelihood mode (-DBRIE_TILE_MODE=0..2) over
+// count storage {fp32, u8, u16} x accumulator sets NACC {0,1,2} x per-cell output tiles NJT {0,1,2}.
+#include "brie_launch.h"
+#include "brie_tile.hip.h"
+
+#ifndef BRIE_TILE_MODE
+#error "compile with -DBRIE_TILE_MODE=<0..2>"
+#endif
+#define BRIE_CAT2(a, b) a##b
+#define BRIE_CAT(a, b) BRIE_CAT2(a, b)
+
+namespace brie {
+namespace {
+
+template <int CS, int NACC, int NJT>
+void tile_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int lds_bytes) {
+    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
+                       q.m_rho, q.v_rho, q.b, q.lam, q.effL, q.partials, a, t);
+}
+
+template <int CS, int NACC>
+void tile_njt(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int njt, int lds) {
+    if (njt == 0) {
+        if constexpr (NACC > 0) tile_launch<CS, NACC, 0>(c, q, a, t, lds);
+    } else if (njt == 1) tile_launch<CS, NACC, 1>(c, q, a, t, lds);
+    else tile_launch<CS, NACC, 2>(c, q, a, t, lds);
+}
+
+template <int CS>
+void tile_nacc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nacc, int njt, int lds) {
+    if (nacc == 0) tile_njt<CS, 0>(c, q, a, t, njt, lds);
+    else if (nacc == 1) tile_njt<CS, 1>(c, q, a, t, njt, lds);
+    else tile_njt<CS, 2>(c, q, a, t, njt, lds);
+}
+
+}  // namespace
+
+void BRIE_CAT(launch_tile_mode, BRIE_TILE_MODE)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
+                                                const TileArgs &t, int nacc, int njt, int lds_bytes) {
+    if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, lds_bytes);
+    else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, lds_bytes);
+    else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, lds_bytes);
+}
+
+}  // namespace brie

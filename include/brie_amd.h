@@ -238,6 +238,10 @@ int brie_synchronize(brie_handle *h);
 int brie_profile_enable(brie_handle *h, int32_t enable);
 int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launches);
 
+/* Measurement aid: device address of a cell x gene array of the handle (which = 0..2 count layers as stored,
+ * BRIE_Z_LOC, BRIE_Z_STD_LOG, 20..23 = Adam moments m, v of Z_loc and m, v of Z_std_log). */
+int brie_debug_address(brie_handle *h, int which, uint64_t *addr);
+
 /* Tuning knobs of the tiling (0 = library default). */
 int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk);
 

@@ -505,7 +505,8 @@ def test_wide_cell_design_matches_oracle(lib, Kc, L, MC):
     np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
     assert_states_close(util.oracle_state(o), util.device_state(sh), bulk=5e-5)
     np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
-    assert sh.step_storage_bytes() > sh.step_algorithmic_bytes() - Nc * Ng * 4 * L     # + 8 B/element: residual stream
+    # the MFMA tile kernel keeps the residual on chip: a wide design moves no more HBM bytes than a narrow one
+    assert sh.step_storage_bytes() <= sh.step_algorithmic_bytes()
 
 
 def test_sparse_layers_densified_on_device(lib):

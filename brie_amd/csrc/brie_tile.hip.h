@@ -43,14 +43,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // NACC = 32-feature accumulator sets for Xc^T.R (0: Kc == 0, 1: Kc <= 32, 2: Kc <= 64)
 // NJT  = 32-feature output tiles of R.Xg        (0: Kg == 0, 1: kgp <= 32, 2: kgp <= 64)
-template <int MODE, int CS, int NACC, int NJT>
-__global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
+// NW   = waves per workgroup: 4 (two workgroups per CU while the LDS tiles stay under 80 KB) or 8 (one workgroup per CU
+//        with the same 8 waves in flight when they do not)
+template <int MODE, int CS, int NACC, int NJT, int NW>
+__global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ bp, const float *__restrict__ lamp, const float *__restrict__ effL,
     float *__restrict__ partials, const StepScalars a, const TileArgs t) {
     constexpr int S = 4;
+    constexpr int CB = 8 / NW;              // 32-gene column blocks per wave
+    constexpr int NT = NW * kWave;          // threads per workgroup
     constexpr bool CPL = NJT > 0;           // per-cell statistics are only produced with gene features / cell mode
     // dynamic LDS: [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257]; the cross-wave folds reuse T
     extern __shared__ __align__(16) float lds[];
@@ -70,10 +74,10 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
     if (a.block_active[gb] == 0) return;
     const bool cell = CPL && t.cell_mode != 0;
 
-    for (int i = threadIdx.x; i < t.Kc * kGenesPerBlock; i += kBlock)
+    for (int i = threadIdx.x; i < t.Kc * kGenesPerBlock; i += NT)
         wl[i] = t.W[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
     if constexpr (NJT > 0) {
-        for (int i = threadIdx.x; i < t.kgp * kGenesPerBlock; i += kBlock)
+        for (int i = threadIdx.x; i < t.kgp * kGenesPerBlock; i += NT)
             xl[(i / kGenesPerBlock) * kXgStride + (i % kGenesPerBlock)] =
                 t.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
     }
@@ -83,11 +87,11 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
     for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
-    f32x16 G[NACC > 0 ? NACC : 1][2];
+    f32x16 G[NACC > 0 ? NACC : 1][CB];
 #pragma unroll
     for (int n = 0; n < (NACC > 0 ? NACC : 1); ++n)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < CB; ++c)
 #pragma unroll
             for (int q = 0; q < 16; ++q) G[n][c][q] = 0.0f;
 
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
     for (int tr0 = row0; tr0 < row_end; tr0 += kTileRows) {
         // ---- A: prior-mean tile on the matrix cores: T[i][gene] = sum_k X[i][k] W[k][gene] + sum_k Wg[i][k] Xg[gene][k]
         {
-            f32x16 D[2];
+            f32x16 D[CB];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) D[c][q] = 0.0f;
             const int ar = tr0 + l31;                       // the lane's A row (cell)
@@ -235,8 +239,8 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
                 const bool ok = arow_ok && k < t.Kc;
                 const float av = ok ? t.Xc[static_cast<int64_t>(ar) * t.Kc + k] : 0.0f;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float bv = k < t.Kc ? wl[k * kGenesPerBlock + (2 * w + c) * 32 + l31] : 0.0f;
+                for (int c = 0; c < CB; ++c) {
+                    const float bv = k < t.Kc ? wl[k * kGenesPerBlock + (CB * w + c) * 32 + l31] : 0.0f;
                     D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
                 }
             }
@@ -246,18 +250,18 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
                     const bool ok = arow_ok && k < t.kgp;
                     const float av = ok ? t.Wg[static_cast<int64_t>(ar) * t.kgp + k] : 0.0f;
 #pragma unroll
-                    for (int c = 0; c < 2; ++c) {
-                        const float bv = k < t.kgp ? xl[k * kXgStride + (2 * w + c) * 32 + l31] : 0.0f;
+                    for (int c = 0; c < CB; ++c) {
+                        const float bv = k < t.kgp ? xl[k * kXgStride + (CB * w + c) * 32 + l31] : 0.0f;
                         D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
                     }
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-                    T[i * kTileStride + (2 * w + c) * 32 + l31] = D[c][q];
+                    T[i * kTileStride + (CB * w + c) * 32 + l31] = D[c][q];
                 }
         }
         __syncthreads();
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
             const int t_end = min(tr0 + kTileRows, row_end);
             int r = tr0 + w;
             while (r < t_end) {
-                const int rn = r + kWavesPerBlock;          // next row of this wave (may belong to the next tile)
+                const int rn = r + NW;                      // next row of this wave (may belong to the next tile)
                 RowRegs<CS> nxt;
                 // branch-free prefetch (a guarded load would put a join -- and a full vmcnt wait -- right behind it):
                 // past the chunk's end the wave's own row is fetched again, an L2 hit
@@ -291,21 +295,22 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
                     av[n] = (ok && f < t.Kc) ? t.Xc[static_cast<int64_t>(rr_) * t.Kc + f] : 0.0f;
                 }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const float bv = ok ? T[(2 * kk + half) * kTileStride + (2 * w + c) * 32 + l31] : 0.0f;
+                for (int c = 0; c < CB; ++c) {
+                    const float bv = ok ? T[(2 * kk + half) * kTileStride + (CB * w + c) * 32 + l31] : 0.0f;
 #pragma unroll
                     for (int n = 0; n < NACC; ++n) G[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv, G[n][c], 0, 0, 0);
                 }
             }
         }
-        if constexpr (NJT > 0) {            // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature]; wave w: genes 64w..64w+63
+        if constexpr (NJT > 0) {            // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature]; wave w: 256 / NW genes
+            constexpr int GW_ = kGenesPerBlock / NW;
             f32x16 P[NJT];
 #pragma unroll
             for (int n = 0; n < NJT; ++n)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) P[n][q] = 0.0f;
-            for (int kk = 0; kk < 32; ++kk) {
-                const int g = 64 * w + 2 * kk + half;
+            for (int kk = 0; kk < GW_ / 2; ++kk) {
+                const int g = GW_ * w + 2 * kk + half;
                 const float av = T[l31 * kTileStride + g];                // A[i = cell][k = gene]
 #pragma unroll
                 for (int n = 0; n < NJT; ++n) {
@@ -314,18 +319,43 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
                     P[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, P[n], 0, 0, 0);
                 }
             }
-            __syncthreads();                // every wave is done reading T: it now carries the 4 partial P tiles
-            // partial of wave w at T[w * 32*64 ...] as [cell i][feature f] (stride 64)
+            __syncthreads();                // every wave is done reading T: it now carries partial P tiles
+            // partial of wave w at T[(w & 3) * 32*64 ...] as [cell i][feature f] (stride 64); with 8 waves the upper
+            // four park theirs first and the lower four add them to their own before the 4-way fold
+            if constexpr (NW == 8) {
+                if (w >= 4) {
 #pragma unroll
-            for (int n = 0; n < NJT; ++n)
+                    for (int n = 0; n < NJT; ++n)
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-                    T[w * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
+                        for (int q = 0; q < 16; ++q) {
+                            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                            T[(w - 4) * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
+                        }
                 }
+                __syncthreads();
+                if (w < 4) {
+#pragma unroll
+                    for (int n = 0; n < NJT; ++n)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                            P[n][q] += T[w * (kTileRows * 64) + i * 64 + 32 * n + l31];
+                        }
+                }
+                __syncthreads();
+            }
+            if (w < 4) {
+#pragma unroll
+                for (int n = 0; n < NJT; ++n)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                        T[w * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
+                    }
+            }
             __syncthreads();
             float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
-            for (int e = threadIdx.x; e < kTileRows * t.kgp; e += kBlock) {
+            for (int e = threadIdx.x; e < kTileRows * t.kgp; e += NT) {
                 const int i = e / t.kgp, f = e - i * t.kgp;
                 if (tr0 + i < row_end) {
                     const int o = i * 64 + f;
@@ -342,12 +372,12 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
 #pragma unroll
         for (int n = 0; n < NACC; ++n)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int f = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * n;
                     if (f < t.Kc)
-                        t.Gpart[(static_cast<int64_t>(blockIdx.y) * t.Kc + f) * a.ld + gb * kGenesPerBlock + (2 * w + c) * 32 + l31] =
+                        t.Gpart[(static_cast<int64_t>(blockIdx.y) * t.Kc + f) * a.ld + gb * kGenesPerBlock + (CB * w + c) * 32 + l31] =
                             G[n][c][q];
                 }
     }
@@ -369,7 +399,7 @@ __global__ __launch_bounds__(kBlock, 2) void elbo_adam_step_tile(   // 2 waves/S
             for (int v = 0; v < kVec; ++v) {
                 float tt = acc[s][v];
 #pragma unroll
-                for (int ww = 0; ww < kWavesPerBlock - 1; ++ww) tt += T[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
+                for (int ww = 0; ww < NW - 1; ++ww) tt += T[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
                 o.v[v] = tt;
             }
             st4(dst + s * a.ld, o);

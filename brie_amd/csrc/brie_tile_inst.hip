@@ -12,36 +12,43 @@
 namespace brie {
 namespace {
 
-template <int CS, int NACC, int NJT>
+template <int CS, int NACC, int NJT, int NW>
 void tile_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int lds_bytes) {
-    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT>;
+    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT, NW>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
+    hipLaunchKernelGGL(kern, c.grid, dim3(NW * kWave), lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
                        q.m_rho, q.v_rho, q.b, q.lam, q.effL, q.partials, a, t);
 }
 
+template <int CS, int NACC, int NJT>
+void tile_nw(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nw, int lds) {
+    if (nw == 8) tile_launch<CS, NACC, NJT, 8>(c, q, a, t, lds);
+    else tile_launch<CS, NACC, NJT, 4>(c, q, a, t, lds);
+}
+
 template <int CS, int NACC>
-void tile_njt(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int njt, int lds) {
+void tile_njt(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int njt, int nw, int lds) {
     if (njt == 0) {
-        if constexpr (NACC > 0) tile_launch<CS, NACC, 0>(c, q, a, t, lds);
-    } else if (njt == 1) tile_launch<CS, NACC, 1>(c, q, a, t, lds);
-    else tile_launch<CS, NACC, 2>(c, q, a, t, lds);
+        if constexpr (NACC > 0) tile_nw<CS, NACC, 0>(c, q, a, t, nw, lds);
+    } else if (njt == 1) tile_nw<CS, NACC, 1>(c, q, a, t, nw, lds);
+    else tile_nw<CS, NACC, 2>(c, q, a, t, nw, lds);
 }
 
 template <int CS>
-void tile_nacc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nacc, int njt, int lds) {
-    if (nacc == 0) tile_njt<CS, 0>(c, q, a, t, njt, lds);
-    else if (nacc == 1) tile_njt<CS, 1>(c, q, a, t, njt, lds);
-    else tile_njt<CS, 2>(c, q, a, t, njt, lds);
+void tile_nacc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nacc, int njt, int nw,
+               int lds) {
+    if (nacc == 0) tile_njt<CS, 0>(c, q, a, t, njt, nw, lds);
+    else if (nacc == 1) tile_njt<CS, 1>(c, q, a, t, njt, nw, lds);
+    else tile_njt<CS, 2>(c, q, a, t, njt, nw, lds);
 }
 
 }  // namespace
 
 void BRIE_CAT(launch_tile_mode, BRIE_TILE_MODE)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
-                                                const TileArgs &t, int nacc, int njt, int lds_bytes) {
-    if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, lds_bytes);
-    else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, lds_bytes);
-    else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, lds_bytes);
+                                                const TileArgs &t, int nacc, int njt, int nw, int lds_bytes) {
+    if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, nw, lds_bytes);
+    else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, nw, lds_bytes);
+    else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, nw, lds_bytes);
 }
 
 }  // namespace brie

@@ -183,25 +183,32 @@ def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, loca
                     "rank; after the timed region" % (Kc, Ng),
             "backend": dist.get_backend(), "rccl_ranks": world, "bytes_per_rank": int(local.size * 4),
             "allgather_ms": ms_torch}
-    # (b) the C-ABI communicator
-    try:
-        nat = comm.native_comm(local_rank)
-        if nat is None:
-            info["native"] = "no native communicator on backend %s (RCCL needs one GPU per rank)" % dist.get_backend()
-        else:
+    # (b) the C-ABI communicator.  Never exercised between two GPUs by the build (1-GPU boxes only), so it runs in a
+    # watchdog thread: if RCCL set-up or the collective does not come back, the line reports it and the run goes on.
+    import threading
+
+    def native_leg():
+        try:
+            nat = comm.native_comm(local_rank)
+            if nat is None:
+                info["native"] = "no native communicator on backend %s (RCCL needs one GPU per rank)" % dist.get_backend()
+                return
             per = max(b - a for a, b in ranges)
             buf = np.zeros((local.shape[0], per), np.float32)
             buf[:, :local.shape[1]] = local
             nat.allgather(buf)
-            dist.barrier()
-            t0 = time.perf_counter()
+            t1 = time.perf_counter()
             g = nat.allgather(buf).reshape(world, local.shape[0], per)
-            info["allgather_native_ms"] = (time.perf_counter() - t0) * 1e3
+            info["allgather_native_ms"] = (time.perf_counter() - t1) * 1e3
             full_nat = np.concatenate([g[r][:, :b - a] for r, (a, b) in enumerate(ranges)], axis=1)
             info["native_equals_torch"] = bool(np.array_equal(full_nat, full))
-            assert info["native_equals_torch"], "brie_comm_allgather and torch.distributed all_gather disagree"
-    except Exception as exc:                                      # reported, not fatal: the torch path already ran
-        info["native_error"] = repr(exc)
+        except Exception as exc:                                  # reported, not fatal: the torch path already ran
+            info["native_error"] = repr(exc)
+    th = threading.Thread(target=native_leg, daemon=True)
+    th.start()
+    th.join(180.0)
+    if th.is_alive():
+        info["native_error"] = "brie_comm leg did not return within 180 s"
     # every rank's step time (max-over-ranks is what `value` uses)
     t = torch.tensor([elapsed_local / args.steps * 1e3], dtype=torch.float64,
                      device=dev if dist.get_backend() == "nccl" else "cpu")

@@ -441,10 +441,6 @@ def main():
                 "definition": "achieved = ALGORITHMIC bytes (48 + 4 L per element, fp32 model of SURVEY 8d) / average "
                               "launch time of the dominant kernel; what the kernel physically moves is hbm_rate_GBs",
                 "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
-                # counts tiered per gene block: one pass = TWO launches of the same kernel template (the u8 and the u16
-                # gene blocks); avg_kernel_ms is the time of the whole pass (HIP events around both), i.e. the SUM of the
-                # two average durations a rocprofv3 --kernel-trace --stats summary lists for elbo_adam_step
-                "launches_per_pass": 2 if storage_main.startswith("u8/u16") else 1,
                 "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
                 "count_storage": storage_main, "storage_bytes_per_launch": storage_bytes_main,
                 # the physical HBM rate: bytes the current storage moves (integer counts are kept as u8 / u16,

@@ -62,7 +62,8 @@ struct brie_handle {
     float *c[3] = {nullptr, nullptr, nullptr};
     void *cu[3] = {nullptr, nullptr, nullptr};      // compact (u8 / u16) count layers, same tiled indexing
     int cs = brie::kCountF32;       // current count storage (kCountMixed: u8 or u16 per gene block)
-    // mixed tiers: cu[l] holds the u8 tiles of all u8 gene blocks first, then the u16 tiles
+    // tiers per gene block: cu[l] holds the u8 tiles of all u8 gene blocks first, then the u16 tiles; ONE launch, the
+    // workgroup of a gene block picks its tier at run time
     std::vector<int32_t> tier_host;         // per gene block
     int32_t *tier = nullptr, *list8 = nullptr, *list16 = nullptr;     // device: tier per block, block lists per tier
     int64_t *count_off = nullptr;           // device: element offset of every block's tile (in its tier's elements)
@@ -1181,6 +1182,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.kc_wide = h->wide_like ? h->p.Kc : 0;
     a.pc = h->pc;
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
+    if (h->cs == brie::kCountMixed) { a.count_off = h->count_off; a.tier = h->tier; }      // tiers per gene block, one launch
     // wide designs: the MFMA tile kernel (ELBO target), else the LDS-broadcast variants + residual buffer
     const bool use_tile = h->tile && h->target == 0;
     if (h->wide_like && h->p.Kc > 0) {
@@ -1234,20 +1236,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        if (h->cs == brie::kCountMixed) {       // one launch per count tier, each over its own gene blocks
-            const int tiers[2] = {brie::kCountU8, brie::kCountU16};
-            for (int ti = 0; ti < 2; ++ti) {
-                brie::LaunchCfg c2 = cfg;
-                brie::StepScalars a2 = a;
-                c2.cs = tiers[ti];
-                c2.grid.x = ti == 0 ? h->n8 : h->n16;
-                a2.block_list = ti == 0 ? h->list8 : h->list16;
-                a2.count_off = h->count_off;
-                if (use_tile) launch_tile(h, c2, q, a2, ta);
-                else if (simple_margin) launch_margin(h, c2, q, a2);
-                else launch_step(h, c2, q, a2, cp);
-            }
-        } else if (use_tile) launch_tile(h, cfg, q, a, ta);
+        if (use_tile) launch_tile(h, cfg, q, a, ta);
         else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
@@ -1391,16 +1380,8 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     h->draw += static_cast<uint32_t>(n_repeats);
-    if (h->cs == brie::kCountMixed) {
-        const int tiers[2] = {brie::kCountU8, brie::kCountU16};
-        for (int ti = 0; ti < 2; ++ti) {
-            a.block_list = ti == 0 ? h->list8 : h->list16;
-            a.count_off = h->count_off;
-            launch_loss_gene(h, brie::LaunchCfg{h->mode, tiers[ti], dim3(ti == 0 ? h->n8 : h->n16, h->n_chunks), h->stream,
-                                                h->coupled ? 1 : 0}, a);
-        }
-    } else
-        launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
+    if (h->cs == brie::kCountMixed) { a.count_off = h->count_off; a.tier = h->tier; }
+    launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
     hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
                        h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));
     HIP_TRY(hipGetLastError());

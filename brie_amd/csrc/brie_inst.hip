@@ -61,6 +61,7 @@ void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
 template <int MODE>
 void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     if (c.cs == kCountU8) step_mc<MODE, kCountU8>(c, q, a, cp);
+    else if (c.cs == kCountMixed) step_mc<MODE, kCountMixed>(c, q, a, cp);
     else if (c.cs == kCountU16) step_mc<MODE, kCountU16>(c, q, a, cp);
     else step_mc<MODE, kCountF32>(c, q, a, cp);
 }
@@ -73,6 +74,7 @@ void lg_launch(const LaunchCfg &c, const LossGeneArgs &a) {
 template <int MODE>
 void lg_cs(const LaunchCfg &c, const LossGeneArgs &a) {
     if (c.cs == kCountU8) lg_launch<MODE, kCountU8>(c, a);
+    else if (c.cs == kCountMixed) lg_launch<MODE, kCountMixed>(c, a);
     else if (c.cs == kCountU16) lg_launch<MODE, kCountU16>(c, a);
     else lg_launch<MODE, kCountF32>(c, a);
 }
@@ -86,6 +88,7 @@ void margin_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars 
 template <int MODE>
 void margin_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a) {
     if (c.cs == kCountU8) margin_launch<MODE, kCountU8>(c, q, a);
+    else if (c.cs == kCountMixed) margin_launch<MODE, kCountMixed>(c, q, a);
     else if (c.cs == kCountU16) margin_launch<MODE, kCountU16>(c, q, a);
     else margin_launch<MODE, kCountF32>(c, q, a);
 }
@@ -151,6 +154,7 @@ void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
 template <int MODE>
 void wide_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     if (c.cs == kCountU8) wide_mc<MODE, kCountU8>(c, q, a, cp);
+    else if (c.cs == kCountMixed) wide_mc<MODE, kCountMixed>(c, q, a, cp);
     else if (c.cs == kCountU16) wide_mc<MODE, kCountU16>(c, q, a, cp);
     else wide_mc<MODE, kCountF32>(c, q, a, cp);
 }

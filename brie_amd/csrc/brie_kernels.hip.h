@@ -247,11 +247,12 @@ struct StepScalars {
     // After freezing, the active gene quads are packed to the front (gather_quads); quad_ids[position]
     // is the quad's original index, which keys the noise stream -- results do not depend on the packing.
     const int32_t *quad_ids;
-    // Mixed count tiers (kCountMixed on the host): the launch covers only the gene blocks of ONE tier --
-    // block_list[blockIdx.x] is the gene block, count_off[gene block] the element offset of its count tile in
-    // the tier-packed layer (null: every gene block, count tiles laid out like the state tiles).
+    // Count tiers per gene block (kCountMixed): tier[gene block] = kCountU8 / kCountU16, count_off[gene block] = the
+    // element offset (in elements of the block's own tier) of its count tile in the tier-packed layer; both null when
+    // the count tiles are laid out like the state tiles.  block_list (optional): blockIdx.x -> gene block.
     const int32_t *block_list;
     const int64_t *count_off;
+    const int32_t *tier;
 };
 
 // Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
@@ -302,12 +303,13 @@ __device__ __forceinline__ float wave_sum8(const float (&t)[8], int lane) {
 // the fp32 values entering the arithmetic are bit-identical, the count traffic drops from 4L to L bytes.
 // kCountU16: same with two bytes per element for integers up to 65535 (4 genes = 8 B per lane).
 enum : int { kCountF32 = 0, kCountU8 = 1, kCountU16 = 2,
-             kCountMixed = 3 };   // host-side state only: u8 or u16 per gene block, two launches per pass
+             kCountMixed = 3 };   // u8 or u16 per 256-gene block, chosen per workgroup at run time (branch-free loads)
 
 template <int CS> struct CountRegs;
 template <> struct CountRegs<kCountF32> { F4 c1, c2, c3; };
 template <> struct CountRegs<kCountU8> { uint32_t u1, u2, u3; };
 template <> struct CountRegs<kCountU16> { uint2 u1, u2, u3; };
+template <> struct CountRegs<kCountMixed> { uint2 u1, u2, u3; int esz; };    // esz = bytes per count of this gene block
 
 typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 ld_u16x4(const void *p, int64_t off) {
@@ -320,10 +322,31 @@ __device__ __forceinline__ float u16_lane(const uint2 &u, int v) {
     return static_cast<float>((w >> (16 * (v & 1))) & 0xFFFFu);
 }
 
+// Mixed tiers: the lane's 4 counts are one dword (u8 block) or two (u16 block) at byte offset off * esz.  Both cases
+// issue the same two dword loads -- in a u8 block the second one repeats the first address and is ignored -- so the
+// row body stays free of branches (a guarded load would end the software pipeline, see elbo_adam_step).
+__device__ __forceinline__ uint2 ld_mixed(const void *p, int64_t off, int esz) {
+    const char *q = static_cast<const char *>(p) + off * esz;
+    const uint32_t w0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(q));
+    const uint32_t w1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(q + 4 * (esz - 1)));
+    return make_uint2(w0, w1);
+}
+__device__ __forceinline__ float mixed_lane(const uint2 &u, int v, bool bytes) {
+    const uint32_t b8 = (u.x >> (8 * v)) & 0xFFu;
+    const uint32_t b16 = ((v < 2 ? u.x : u.y) >> (16 * (v & 1))) & 0xFFFFu;
+    return static_cast<float>(bytes ? b8 : b16);
+}
+
 template <int CS, int MODE>
 __device__ __forceinline__ void load_counts(const void *__restrict__ p1, const void *__restrict__ p2,
-                                            const void *__restrict__ p3, int64_t off, CountRegs<CS> &C) {
-    if constexpr (CS == kCountF32) {
+                                            const void *__restrict__ p3, int64_t off, CountRegs<CS> &C, int esz = 0) {
+    if constexpr (CS == kCountMixed) {
+        C.esz = esz;
+        C.u1 = ld_mixed(p1, off, esz);
+        C.u2 = ld_mixed(p2, off, esz);
+        if (MODE == kLikEff3) C.u3 = ld_mixed(p3, off, esz);
+        else C.u3 = make_uint2(0u, 0u);
+    } else if constexpr (CS == kCountF32) {
         C.c1 = ld4s(static_cast<const float *>(p1) + off);
         C.c2 = ld4s(static_cast<const float *>(p2) + off);
         if (MODE == kLikEff3) C.c3 = ld4s(static_cast<const float *>(p3) + off);
@@ -345,7 +368,16 @@ __device__ __forceinline__ void load_counts(const void *__restrict__ p1, const v
 // counts of the lane's 4 genes as fp32, pseudo-count rule included for the compact storage
 template <int CS>
 __device__ __forceinline__ void decode_counts(const CountRegs<CS> &C, float pc, F4 &c1, F4 &c2, F4 &c3) {
-    if constexpr (CS == kCountF32) {
+    if constexpr (CS == kCountMixed) {
+        const bool bytes = C.esz == 1;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            float a = mixed_lane(C.u1, v, bytes), b = mixed_lane(C.u2, v, bytes);
+            if (a + b > 0.0f) { a += pc; b += pc; }
+            c1.v[v] = a; c2.v[v] = b;
+            c3.v[v] = mixed_lane(C.u3, v, bytes);
+        }
+    } else if constexpr (CS == kCountF32) {
         c1 = C.c1; c2 = C.c2; c3 = C.c3;
     } else if constexpr (CS == kCountU8) {
 #pragma unroll
@@ -484,6 +516,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
         const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
+        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
         bool on[kVec];
         {
             const F4 t = ld4(a.gene_active + j0);
@@ -503,7 +536,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.cb = cp.cb[r];
                 rs.clam = cp.clam[r];
             }
-            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt, esz);
             if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
                 R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
             if constexpr (!MARGIN) {
@@ -894,8 +927,9 @@ struct LossGeneArgs {
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
     const float *mbuf;      // wide designs: Xc.Wc_loc from the GEMM (KC == 0 instantiation), else null
-    const int32_t *block_list;      // mixed count tiers, see StepScalars
+    const int32_t *block_list;      // count tiers per gene block, see StepScalars
     const int64_t *count_off;
+    const int32_t *tier;
     CoupledArgs cp;
 };
 
@@ -955,6 +989,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
         const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
+        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             float wg[kKgMax] = {0.f, 0.f, 0.f, 0.f}, cbr = 0.f, clamr = 0.f;
@@ -968,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             }
             const float row_isig2 = f_exp(-2.0f * clamr);
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(a.c1, a.c2, a.c3, cbase + static_cast<int64_t>(r) * a.row_stride, cr);
+            load_counts<CS, MODE>(a.c1, a.c2, a.c3, cbase + static_cast<int64_t>(r) * a.row_stride, cr, esz);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
@@ -1096,10 +1131,11 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
+        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
         const float log_mc = f_log(static_cast<float>(a.mc));
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, cr);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, cr, esz);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             float xc[KCX], m[kVec];

@@ -122,6 +122,7 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
     const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
     const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
     const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
+    const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
     bool on[kVec], real[kVec];
     {
         const F4 tt = ld4(a.gene_active + j0);
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
 
     auto load_row = [&](int r, RowRegs<CS> &R) {
         const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt);
+        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt, esz);
         R.mu = ld4s(mu_p + off);
         R.rho = ld4s(rho_p + off);
         R.mm = ld4s(mmu_p + off);

@@ -47,6 +47,7 @@ void tile_nacc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, 
 void BRIE_CAT(launch_tile_mode, BRIE_TILE_MODE)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
                                                 const TileArgs &t, int nacc, int njt, int nw, int lds_bytes) {
     if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, nw, lds_bytes);
+    else if (c.cs == kCountMixed) tile_nacc<kCountMixed>(c, q, a, t, nacc, njt, nw, lds_bytes);
     else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, nw, lds_bytes);
     else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, nw, lds_bytes);
 }

@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT; O=gpurun_out/r02n; mkdir -p $O
+( time python -m pytest tests -q -m gpu ) > $O/pytest_all.log 2>&1
+python bench.py > $O/bench.json 2> $O/bench.err
+bash profiles/run_profile.sh r02n > $O/prof.log 2>&1
+grep -E "passed|failed" $O/pytest_all.log; grep -E "^FAILED" $O/pytest_all.log | head
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r02n/bench.json").read().strip().splitlines()[-1]); r=d["roofline"]
+print(round(d["ms_per_step"],3), round(r["avg_kernel_ms"],3), r["frac"], r["count_storage"], r.get("traffic"), r.get("traffic_source","")[:20], r["measured_stream_ceiling_GBs"], d["pcie_inclusive"]["total_s"])
+PY
+head -4 gpurun_out/prof_r02n/summary.txt; grep -A3 "== counters" gpurun_out/prof_r02n/summary.txt | grep elbo

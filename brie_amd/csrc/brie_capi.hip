@@ -44,6 +44,15 @@ int fail(int code, const char *fmt, ...) {
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// A source in HBM may still be being produced on another stream (e.g. a torch tensor on torch's stream) while the
+// handle's stream is non-blocking: such a copy is ordered after ALL prior device work.  Host sources need no such wait.
+int order_after_device_source(const void *src) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) != hipSuccess) { (void)hipGetLastError(); return BRIE_OK; }   // plain host memory
+    if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) HIP_TRY(hipDeviceSynchronize());
+    return BRIE_OK;
+}
+
 }  // namespace
 
 // brie_comm.hip reports its failures through the same thread-local message
@@ -100,6 +109,8 @@ struct brie_handle {
     bool tile = false, wide_like = false;
     int tile_lds = 0, tile_nacc = 0, tile_njt = 0, tile_nw = 4;
     size_t gpart_elems = 0, rbuf_elems = 0;
+    float *win_scratch = nullptr;   // brie_read_loss_window staging
+    size_t win_elems = 0;
     float *Mbuf = nullptr;          // (Nc, ld) tiled: Xc.Wc_loc for loss_gene_eval (allocated on first use)
     float *Rbuf = nullptr;          // (Nc, ld) tiled: residual r written by the step kernel
     float *Gpart = nullptr;         // (n_gchunks, Kc, ld): per-chunk partial sums of Xc^T . r
@@ -750,6 +761,7 @@ int brie_destroy(brie_handle *h) {
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
     if (h->io_scratch) hipFree(h->io_scratch);
+    if (h->win_scratch) hipFree(h->win_scratch);
     if (h->io_thread.joinable()) h->io_thread.join();
     if (h->io_stream) { hipStreamSynchronize(h->io_stream); hipStreamDestroy(h->io_stream); }
     if (h->io_event) hipEventDestroy(h->io_event);
@@ -769,9 +781,7 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     if (rc != BRIE_OK) return rc;
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
-    // `src` may live in HBM and may still be being produced on another stream (e.g. a torch tensor on
-    // torch's stream); the handle's stream is non-blocking, so order the copy after ALL prior device work.
-    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = order_after_device_source(src)) != BRIE_OK) return rc;
     if (which == BRIE_EFFLEN) {
         if (!h->p.has_efflen) return fail(BRIE_ERR_INVALID, "problem was created without effLen");
         if (rows != h->p.Ng || cols != 6)
@@ -851,7 +861,8 @@ int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t 
     if (rc != BRIE_OK) return rc;
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "sparse upload needs the tiled layout");
-    HIP_TRY(hipDeviceSynchronize());
+    if ((rc = order_after_device_source(data ? static_cast<const void *>(data) : static_cast<const void *>(indptr))) != BRIE_OK)
+        return rc;
     if (h->cs != brie::kCountF32 || h->compact_tried) {
         if ((rc = expand_counts(h)) != BRIE_OK) return rc;
         h->compact_tried = false;
@@ -1028,14 +1039,12 @@ int brie_read_loss_window(brie_handle *h, int32_t n_last, float *out) {
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
-    float *tmp = nullptr;
     const size_t n = static_cast<size_t>(n_last) * h->p.Ng;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), n * sizeof(float)));
+    if ((rc = ensure_f32(&h->win_scratch, &h->win_elems, n, h->stream)) != BRIE_OK) return rc;    // kept: one call per round
     hipLaunchKernelGGL(brie::loss_window, dim3(h->fin_blocks, n_last), dim3(brie::kBlock), 0, h->stream, h->ring_kl,
-                       h->ring_ll, tmp, h->ld, static_cast<int>(h->p.Ng), n_last, h->ring_pos);
-    hipError_t e = hipMemcpyAsync(out, tmp, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+                       h->ring_ll, h->win_scratch, h->ld, static_cast<int>(h->p.Ng), n_last, h->ring_pos);
+    hipError_t e = hipMemcpyAsync(out, h->win_scratch, n * sizeof(float), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    hipFree(tmp);
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "loss window: %s", hipGetErrorString(e));
     return BRIE_OK;
 }

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mc", type=int, default=1)
     ap.add_argument("--common-noise", action="store_true", help="fit_BRIE_matrix(common_noise=True)")
     ap.add_argument("--no-batch-conv", action="store_true", help="one global convergence rule instead of per batch")
+    ap.add_argument("--verbose", action="store_true", help="print every fit's own wall time (stderr-safe: JSON stays the last line)")
     args = ap.parse_args()
     import torch
     import bench
@@ -45,7 +46,7 @@ def main():
     extra = dict(conv_batch_genes=None) if args.no_batch_conv else {}
     t0 = time.perf_counter()
     res = brie_amd.fitBRIE(ad, Xc=Xc.cpu().numpy(), LRT_index=[0], layer_keys=['isoform1', 'isoform2'],
-                           min_iter=args.min_iter, max_iter=args.max_iter, MC_size=args.mc, seed=7, verbose=False,
+                           min_iter=args.min_iter, max_iter=args.max_iter, MC_size=args.mc, seed=7, verbose=args.verbose,
                            common_noise=args.common_noise, **extra)
     wall = time.perf_counter() - t0
     truth = W_true[0] != 0

@@ -18,9 +18,9 @@
  *    count layers (brie/models/model_wrap.py:108-111); no host repack needed.
  *  - `src`/`dst` may be host OR device pointers (hipMemcpyDefault); the
  *    library copies in at upload and out at read and never retains them.
- *    brie_upload first waits for all prior work on the device (a device `src`
- *    may still be being written on another stream); brie_read returns after
- *    the copy has completed.
+ *    brie_upload of a DEVICE `src` first waits for all prior work on the device
+ *    (it may still be being written on another stream; host sources need no
+ *    such wait); brie_read returns after the copy has completed.
  *  - a handle owns one gene shard on one device; a handle is not thread-safe,
  *    distinct handles are independent.
  */

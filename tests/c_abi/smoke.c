@@ -52,6 +52,34 @@ int main(void) {
         if (!(psi[i] > 0.0f && psi[i] < 1.0f)) { fprintf(stderr, "psi[%d] = %g\n", i, psi[i]); return 1; }
         sum += psi[i];
     }
+    /* round-2 entry points from plain C: one-pass asynchronous export, next LRT model on the same counts, RCCL */
+    {
+        static float psi2[NC * NG], zstd[NC * NG], ci[NC * NG], lg2[NG];
+        CHECK(brie_read_results_async(h, psi2, zstd, ci, NULL, NG));
+        CHECK(brie_loss_gene(h, 3, lg2));                        /* overlaps the export */
+        CHECK(brie_read_wait(h));
+        if (memcmp(psi2, psi, sizeof psi) != 0) { fprintf(stderr, "async Psi differs from brie_read\n"); return 1; }
+        for (int i = 0; i < NC * NG; ++i)
+            if (!(zstd[i] > 0.0f && ci[i] > 0.0f && ci[i] < 1.0f)) { fprintf(stderr, "bad Z_std / CI at %d\n", i); return 1; }
+        CHECK(brie_reconfigure(h, 1, 77, 1, 1));                 /* reduced model: feature 0 dropped, counts stay */
+        static float x1[NC];
+        for (int i = 0; i < NC; ++i) x1[i] = xc[i * KC + 1];
+        CHECK(brie_upload(h, BRIE_XC, x1, NC, 1, 1));
+        CHECK(brie_init_state(h, NAN, NAN));
+        float tr2[8];
+        CHECK(brie_step(h, 8, 0.02f, 1, tr2));
+        if (!(tr2[7] < tr2[0])) { fprintf(stderr, "reconfigured model does not descend\n"); return 1; }
+        uint8_t id[BRIE_COMM_ID_BYTES];
+        brie_comm *comm = NULL;
+        float v[4] = {1.0f, 2.0f, 3.0f, 4.0f}, g[4];
+        double d[2] = {0.5, -1.0};
+        CHECK(brie_comm_unique_id(id));
+        CHECK(brie_comm_init(0, 0, 1, id, &comm));
+        CHECK(brie_comm_allgather(comm, v, 4, g));
+        CHECK(brie_comm_allreduce(comm, d, 2, BRIE_F64, BRIE_SUM));
+        if (memcmp(v, g, sizeof v) != 0 || d[0] != 0.5 || brie_comm_world(comm) != 1) { fprintf(stderr, "comm\n"); return 1; }
+        CHECK(brie_comm_destroy(comm));
+    }
     if (brie_step(h, 1, 0.02f, 0, NULL) == BRIE_OK) { fprintf(stderr, "mc_size 0 accepted\n"); return 1; }
     printf("loss %.3f -> %.3f  mean_psi %.6f  loss_gene0 %.3f  last_error \"%s\"\n", trace[0], trace[STEPS - 1],
            sum / (NC * NG), lg[0], brie_last_error());

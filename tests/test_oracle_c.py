@@ -29,3 +29,21 @@ def test_c_oracle_matches_numpy_oracle(L, Kc, MC):
             d = np.abs(got - ref)
             assert np.percentile(d, 99.9) < 2e-5 and d.max() < 1e-3, name
     assert c.draw == o.draw == 12
+
+
+def test_c_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The checker itself under ASan + UBSan on the CPU (GPU sanitizers are unavailable on this pool): both
+    precisions, 2- and 3-layer likelihood, ragged shapes; any finding aborts with a non-zero exit code."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ([], ["-DBRIE_ORACLE_F64"]):
+        exe = str(tmp_path / ("oracle_san" + ("64" if extra else "32")))
+        subprocess.run(["gcc", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-fno-omit-frame-pointer"] + extra +
+                       [os.path.join(root, "tests", "c_abi", "oracle_sanitize.c"), os.path.join(root, "oracle", "brie_oracle.c"),
+                        "-lm", "-o", exe], check=True)
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", OMP_NUM_THREADS="3")
+        r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "clean" in r.stdout

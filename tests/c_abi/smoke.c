@@ -60,7 +60,7 @@ int main(void) {
         CHECK(brie_read_wait(h));
         if (memcmp(psi2, psi, sizeof psi) != 0) { fprintf(stderr, "async Psi differs from brie_read\n"); return 1; }
         for (int i = 0; i < NC * NG; ++i)
-            if (!(zstd[i] > 0.0f && ci[i] > 0.0f && ci[i] < 1.0f)) { fprintf(stderr, "bad Z_std / CI at %d\n", i); return 1; }
+            if (!(zstd[i] > 0.0f && ci[i] >= 0.0f && ci[i] <= 1.0f)) { fprintf(stderr, "bad Z_std / CI at %d\n", i); return 1; }
         CHECK(brie_reconfigure(h, 1, 77, 1, 1));                 /* reduced model: feature 0 dropped, counts stay */
         static float x1[NC];
         for (int i = 0; i < NC; ++i) x1[i] = xc[i * KC + 1];

@@ -400,7 +400,9 @@ class BRIE2(object):
             n_glob = -(-int(conv_total_genes) // cbg) if glob else 0
             batch_on = np.ones(len(starts), bool)
             self.n_iter_batch = np.full(len(starts), n_iter)
+            self.round_log = []                                      # per extension round: where the time goes
             while n_iter < max_iter and len(losses) >= d2 and 0 < d2 <= 128:
+                t_round = time.time()
                 if n_iter_schedule is not None and len(n_iter_schedule) == len(starts):
                     batch_on &= np.asarray(n_iter_schedule) > n_iter                  # repeat the earlier fit's stops
                 else:
@@ -416,10 +418,15 @@ class BRIE2(object):
                     n_on = int(round(float(np.asarray(trace_reduce(np.array([float(n_on)])))[0])))
                 if n_on == 0:
                     break
+                t_dec = time.time()
                 sh.set_gene_mask(np.repeat(batch_on, sizes))
+                t_mask = time.time()
                 n_iter += add_iter
                 self.n_iter_batch[batch_on] = n_iter
                 losses = np.concatenate([losses, run(add_iter, LEARNING_RATES[5])])
+                self.round_log.append({"active_batches": int(batch_on.sum()), "of": len(batch_on),
+                                       "decide_s": t_dec - t_round, "mask_pack_s": t_mask - t_dec,
+                                       "steps_s": time.time() - t_mask})
             sh.set_gene_mask(None)
             conv_batch_genes = True
         else:

@@ -21,4 +21,5 @@ dt = time.perf_counter() - t0
 vals, cnt = np.unique(m.n_iter_batch, return_counts=True)
 print(json.dumps({"config": cfg["desc"], "fit_s": dt, "trace_len": int(len(losses)), "steps_run": int(996 + len(losses) - 166),
                   "n_iter_batch_hist": {int(v): int(c) for v, c in zip(vals, cnt)},
-                  "mean_n_iter": float(m.n_iter_batch.mean())}))
+                  "mean_n_iter": float(m.n_iter_batch.mean()), "timing": {k: v for k, v in m.timing.items()},
+                  "rounds": m.round_log}))

@@ -107,7 +107,7 @@ struct brie_handle {
     // fused into the streaming pass.  wide_like = the per-gene statistics carry no Xc rows (S = 4), Wc_loc is updated
     // from Gpart by wide_w_adam and loss_gene takes Xc.Wc_loc from Mbuf -- true for `wide` and for every tile handle.
     bool tile = false, wide_like = false;
-    int tile_lds = 0, tile_nacc = 0, tile_njt = 0, tile_nw = 4;
+    int tile_lds = 0, tile_nacc = 0, tile_njt = 0, tile_nw = 1;     // tile_nw: 4-wave halves per workgroup (1 or 2)
     size_t gpart_elems = 0, rbuf_elems = 0;
     float *win_scratch = nullptr;   // brie_read_loss_window staging
     size_t win_elems = 0;
@@ -196,13 +196,16 @@ void setup_paths(brie_handle *h) {
     const char *wp = getenv("BRIE_WIDE_PATH");         // "lds": the round-1 LDS-broadcast variants (A/B runs)
     const bool want_tile = !(wp && strcmp(wp, "lds") == 0);
     const int kgp = h->coupled ? h->kgp : 0;
-    h->tile_lds = static_cast<int>(sizeof(float)) *
-                  (brie::kTileRows * brie::kTileStride + Kc * brie::kGenesPerBlock + kgp * brie::kXgStride);
+    // LDS of one workgroup: the read-only Wc_loc / Xg tiles of the gene block + one T tile per 4-wave half.  Two plain
+    // workgroups per CU while that is under 80 KB; else ONE workgroup of two independent halves sharing the tiles.
+    const int tiles = static_cast<int>(sizeof(float)) * (Kc * brie::kGenesPerBlock + kgp * brie::kXgStride);
+    const int ttile = static_cast<int>(sizeof(float)) * brie::kTileRows * brie::kTileStride;
+    const char *nhe = getenv("BRIE_TILE_HALVES");      // 1 / 2: force (A/B runs)
+    h->tile_nw = nhe ? (atoi(nhe) == 2 ? 2 : 1) : (tiles + ttile <= 80 * 1024 ? 1 : 2);
+    h->tile_lds = tiles + h->tile_nw * ttile;
+    if (h->tile_lds > 160 * 1024 - 64 && h->tile_nw == 2) { h->tile_nw = 1; h->tile_lds = tiles + ttile; }   // one half still fits
     // (gene features 5..8 stay on the LDS-broadcast variant: measured 1.06 x vs 1.09 x the narrow model's step time)
-    h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg > 8)) && h->tile_lds <= 160 * 1024;
-    // two 4-wave workgroups per CU while two sets of LDS tiles fit (160 KB per CU), else one 8-wave workgroup
-    const char *nwe = getenv("BRIE_TILE_WAVES");
-    h->tile_nw = nwe ? (atoi(nwe) == 8 ? 8 : 4) : (h->tile_lds <= 80 * 1024 ? 4 : 8);
+    h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg > 8)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
     h->tile_nacc = Kc == 0 ? 0 : (Kc <= 32 ? 1 : 2);
     h->tile_njt = !h->coupled ? 0 : (kgp <= 32 ? 1 : 2);

@@ -14,8 +14,8 @@
 //        non-temporal loads, next row prefetched under the current row's arithmetic), reads its prior mean from T
 //        (one ds_read_b128) and writes the residual back to the same place;
 //     C  backward: G += Xc^T . T on the wave's 2 column blocks (accumulators live in registers for the whole
-//        chunk), P = T . Xg with the 256 genes of the contraction split over the 4 waves and folded through LDS,
-//        one coalesced store of the tile's 32 x kgp per-cell statistics.
+//        chunk); P = T . Xg in 16 x 16 output blocks (v_mfma_f32_16x16x4_f32), each wave contracting its blocks over
+//        all 256 genes itself -- no cross-wave fold -- and storing them straight into the per-cell statistics.
 //
 // Replaces (measured in DESIGN 4.5): the v_readlane + ds_read_b128 + 4 FMA per feature of the LDS-broadcast
 // variants, the 8 B/element residual round trip through HBM and the separate wide_design_grad launch.
@@ -43,33 +43,57 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // NACC = 32-feature accumulator sets for Xc^T.R (0: Kc == 0, 1: Kc <= 32, 2: Kc <= 64)
 // NJT  = 32-feature output tiles of R.Xg        (0: Kg == 0, 1: kgp <= 32, 2: kgp <= 64)
-// NW   = waves per workgroup: 4 (two workgroups per CU while the LDS tiles stay under 80 KB) or 8 (one workgroup per CU
-//        with the same 8 waves in flight when they do not)
-template <int MODE, int CS, int NACC, int NJT, int NW>
-__global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
+// NH   = independent 4-wave halves per workgroup.  1: a plain 4-wave workgroup, two of them per CU while the LDS tiles
+//        stay under 80 KB.  2: when they do not, ONE 8-wave workgroup per CU whose two halves are two virtual workgroups:
+//        each owns its own cell chunk, its own T tile and its own barriers (an LDS counter the 4 waves spin on -- gfx950
+//        has no named barriers), only the read-only Wc_loc / Xg tiles are shared.  While one half is in its MFMA phases
+//        the other keeps streaming, exactly as two real workgroups would, and per-chunk results are the same bit for bit.
+template <int NH>
+__device__ __forceinline__ void tile_sync(int *ctr, int &arrived) {
+    if constexpr (NH == 1) {
+        __syncthreads();
+    } else {                                   // barrier of ONE half (4 waves): monotone arrival counter in LDS
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        arrived += kWavesPerBlock;
+        if ((threadIdx.x & (kWave - 1)) == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrived) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+template <int MODE, int CS, int NACC, int NJT, int NH>
+__global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ bp, const float *__restrict__ lamp, const float *__restrict__ effL,
     float *__restrict__ partials, const StepScalars a, const TileArgs t) {
     constexpr int S = 4;
+    constexpr int NW = kWavesPerBlock;      // waves per half
     constexpr int CB = 8 / NW;              // 32-gene column blocks per wave
-    constexpr int NT = NW * kWave;          // threads per workgroup
+    constexpr int NT = NH * kBlock;         // threads per workgroup
     constexpr bool CPL = NJT > 0;           // per-cell statistics are only produced with gene features / cell mode
-    // dynamic LDS: [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257]; the cross-wave folds reuse T
+    // dynamic LDS: NH x [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257]; the cross-wave folds reuse T
     extern __shared__ __align__(16) float lds[];
-    float *T = lds;
-    float *wl = T + kTileRows * kTileStride;
-    float *xl = wl + t.Kc * kGenesPerBlock;
-
+    __shared__ int bar_ctr[2];
     const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hf = wave / NW;               // which half (virtual workgroup)
+    const int w = wave - hf * NW;           // wave within the half
+    const int tid = threadIdx.x - hf * kBlock;      // thread within the half
+    float *T = lds + hf * (kTileRows * kTileStride);
+    float *wl = lds + NH * (kTileRows * kTileStride);
+    float *xl = wl + t.Kc * kGenesPerBlock;
+    int *ctr = bar_ctr + hf;
+    int arrived = 0;
+    if (threadIdx.x < 2) bar_ctr[threadIdx.x] = 0;
     const int half = lane >> 5, l31 = lane & 31;
     const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
     const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
-    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int chunk_id = blockIdx.y * NH + hf;             // every half owns one cell chunk
+    const int row0 = chunk_id * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
     if (a.block_active[gb] == 0) return;
     const bool cell = CPL && t.cell_mode != 0;
@@ -129,7 +153,8 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
 #pragma unroll
         for (int v = 0; v < kVec; ++v) { on[v] = tt.v[v] != 0.0f; real[v] = j0 + v < a.Ng; }
     }
-    __syncthreads();                                       // W / Xg tiles complete
+    __syncthreads();                                       // W / Xg tiles and the barrier counters complete (whole workgroup)
+    if (row0 >= a.Nc) return;                              // odd number of chunks: this half has none (no later WG-wide barrier)
 
     auto load_row = [&](int r, RowRegs<CS> &R) {
         const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
@@ -211,12 +236,14 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
             st4s(mrho_p + off, R.mr);
             st4s(vrho_p + off, R.vr);
         }
-        if constexpr (CPL) {                                // sum_j r and sum_j (1 - d r - s2r) of this cell over the block
-            float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
-            const float ts = wave_sum(active ? srow : 0.0f), tl2 = wave_sum(active ? lrow : 0.0f);
-            if (lane == 0) {
-                chunk[static_cast<int64_t>(t.kgp) * a.Nc + r] = ts;
-                chunk[static_cast<int64_t>(t.kgp + 1) * a.Nc + r] = tl2;
+        if constexpr (CPL) {        // cell mode only: sum_j r and sum_j (1 - d r - s2r) of this cell over the gene block
+            if (cell) {             // (wave-uniform; the per-cell intercept / sigma are not parameters otherwise)
+                float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
+                const float ts = wave_sum(active ? srow : 0.0f), tl2 = wave_sum(active ? lrow : 0.0f);
+                if (lane == 0) {
+                    chunk[static_cast<int64_t>(t.kgp) * a.Nc + r] = ts;
+                    chunk[static_cast<int64_t>(t.kgp + 1) * a.Nc + r] = tl2;
+                }
             }
         }
     };
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
                     T[i * kTileStride + (CB * w + c) * 32 + l31] = D[c][q];
                 }
         }
-        __syncthreads();
+        tile_sync<NH>(ctr, arrived);
 
         // ---- B: stream the wave's rows of this tile (software-pipelined: next row's loads under this row's math)
         {
@@ -282,7 +309,7 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
                 r = rn;
             }
         }
-        __syncthreads();
+        tile_sync<NH>(ctr, arrived);
 
         // ---- C: backward contractions of the residual tile
         if constexpr (NACC > 0) {           // G[feature][gene] += sum_cells X[cell][feature] T[cell][gene]
@@ -303,69 +330,49 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
                 }
             }
         }
-        if constexpr (NJT > 0) {            // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature]; wave w: 256 / NW genes
-            constexpr int GW_ = kGenesPerBlock / NW;
-            f32x16 P[NJT];
+        if constexpr (NJT > 0) {
+            // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature] (the Wg_loc gradient of the tile's 32 cells over
+            // this gene block).  v_mfma_f32_16x16x4_f32: the 32 x kgp output is cut into 16 x 16 blocks, wave w owns cell
+            // half (w & 1) and feature blocks (w >> 1) + 2 n -- every wave contracts over all 256 genes itself, so there
+            // is no cross-wave fold and the result goes straight to the per-cell statistics in HBM.
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int l15 = lane & 15, kq = lane >> 4;
+            const int ch = w & 1;
+            const float *arow = T + (ch * 16 + l15) * kTileStride + kq;          // A[i = cell][k = gene]
+            f32x4 P[NJT][2];
+            const float *bcol[NJT];
+            bool fok[NJT];
 #pragma unroll
-            for (int n = 0; n < NJT; ++n)
+            for (int n = 0; n < NJT; ++n) {
+                const int f = ((w >> 1) + 2 * n) * 16 + l15;
+                fok[n] = f < t.kgp;
+                bcol[n] = xl + (fok[n] ? f : 0) * kXgStride + kq;                // B[k = gene][j = feature]
 #pragma unroll
-                for (int q = 0; q < 16; ++q) P[n][q] = 0.0f;
-            for (int kk = 0; kk < GW_ / 2; ++kk) {
-                const int g = GW_ * w + 2 * kk + half;
-                const float av = T[l31 * kTileStride + g];                // A[i = cell][k = gene]
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) P[n][u][q] = 0.0f;
+            }
+            for (int g = 0; g < kGenesPerBlock; g += 8) {        // two independent accumulator chains hide the MFMA latency
+                const float a0 = arow[g], a1 = arow[g + 4];
 #pragma unroll
                 for (int n = 0; n < NJT; ++n) {
-                    const int f = l31 + 32 * n;
-                    const float bv = f < t.kgp ? xl[f * kXgStride + g] : 0.0f;   // B[k = gene][j = feature]
-                    P[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, P[n], 0, 0, 0);
+                    const float b0 = fok[n] ? bcol[n][g] : 0.0f, b1 = fok[n] ? bcol[n][g + 4] : 0.0f;
+                    P[n][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, P[n][0], 0, 0, 0);
+                    P[n][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, P[n][1], 0, 0, 0);
                 }
             }
-            __syncthreads();                // every wave is done reading T: it now carries partial P tiles
-            // partial of wave w at T[(w & 3) * 32*64 ...] as [cell i][feature f] (stride 64); with 8 waves the upper
-            // four park theirs first and the lower four add them to their own before the 4-way fold
-            if constexpr (NW == 8) {
-                if (w >= 4) {
-#pragma unroll
-                    for (int n = 0; n < NJT; ++n)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-                            T[(w - 4) * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
-                        }
-                }
-                __syncthreads();
-                if (w < 4) {
-#pragma unroll
-                    for (int n = 0; n < NJT; ++n)
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-                            P[n][q] += T[w * (kTileRows * 64) + i * 64 + 32 * n + l31];
-                        }
-                }
-                __syncthreads();
-            }
-            if (w < 4) {
-#pragma unroll
-                for (int n = 0; n < NJT; ++n)
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-                        T[w * (kTileRows * 64) + i * 64 + 32 * n + l31] = P[n][q];
-                    }
-            }
-            __syncthreads();
             float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
-            for (int e = threadIdx.x; e < kTileRows * t.kgp; e += NT) {
-                const int i = e / t.kgp, f = e - i * t.kgp;
-                if (tr0 + i < row_end) {
-                    const int o = i * 64 + f;
-                    chunk[static_cast<int64_t>(tr0 + i) * t.kgp + f] =
-                        (T[o] + T[kTileRows * 64 + o]) + (T[2 * kTileRows * 64 + o] + T[3 * kTileRows * 64 + o]);
+#pragma unroll
+            for (int n = 0; n < NJT; ++n) {
+                const int f = ((w >> 1) + 2 * n) * 16 + l15;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                    // D[i][j]: j = lane & 15, i = 4 (lane >> 4) + q
+                    const int cellr = tr0 + ch * 16 + 4 * kq + q;
+                    if (fok[n] && cellr < row_end) chunk[static_cast<int64_t>(cellr) * t.kgp + f] = P[n][0][q] + P[n][1][q];
                 }
             }
         }
-        __syncthreads();                    // T is free for the next tile's forward product
+        tile_sync<NH>(ctr, arrived);                    // T is free for the next tile's forward product
     }
 
     // G accumulators -> this chunk's partial sums (summed over chunks in fp64 by wide_w_adam)
@@ -378,7 +385,7 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
                 for (int q = 0; q < 16; ++q) {
                     const int f = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * n;
                     if (f < t.Kc)
-                        t.Gpart[(static_cast<int64_t>(blockIdx.y) * t.Kc + f) * a.ld + gb * kGenesPerBlock + (CB * w + c) * 32 + l31] =
+                        t.Gpart[(static_cast<int64_t>(chunk_id) * t.Kc + f) * a.ld + gb * kGenesPerBlock + (CB * w + c) * 32 + l31] =
                             G[n][c][q];
                 }
     }
@@ -390,9 +397,9 @@ __global__ __launch_bounds__(NW * kWave, 2) void elbo_adam_step_tile(   // 2 wav
 #pragma unroll
             for (int v = 0; v < kVec; ++v) T[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
     }
-    __syncthreads();
+    tile_sync<NH>(ctr, arrived);
     if (w == 0 && active) {
-        float *dst = partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+        float *dst = partials + (static_cast<int64_t>(chunk_id) * S) * a.ld + j0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             F4 o;

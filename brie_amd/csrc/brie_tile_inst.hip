@@ -12,18 +12,20 @@
 namespace brie {
 namespace {
 
-template <int CS, int NACC, int NJT, int NW>
+template <int CS, int NACC, int NJT, int NH>
 void tile_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int lds_bytes) {
-    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT, NW>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, c.grid, dim3(NW * kWave), lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
+    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT, NH>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    dim3 grid = c.grid;
+    grid.y = (grid.y + NH - 1) / NH;           // every half of a workgroup owns one cell chunk
+    hipLaunchKernelGGL(kern, grid, dim3(NH * kBlock), lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
                        q.m_rho, q.v_rho, q.b, q.lam, q.effL, q.partials, a, t);
 }
 
 template <int CS, int NACC, int NJT>
 void tile_nw(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nw, int lds) {
-    if (nw == 8) tile_launch<CS, NACC, NJT, 8>(c, q, a, t, lds);
-    else tile_launch<CS, NACC, NJT, 4>(c, q, a, t, lds);
+    if (nw == 2) tile_launch<CS, NACC, NJT, 2>(c, q, a, t, lds);
+    else tile_launch<CS, NACC, NJT, 1>(c, q, a, t, lds);
 }
 
 template <int CS, int NACC>

@@ -12,8 +12,8 @@ def main():
     layers = [torch.poisson(torch.full((Nc, Ng), 1.5, device=dev), generator=g) for _ in range(2)]
 
     def make(Kc, Kg, nw):
-        if nw: os.environ["BRIE_TILE_WAVES"] = str(nw)
-        else: os.environ.pop("BRIE_TILE_WAVES", None)
+        if nw: os.environ["BRIE_TILE_HALVES"] = str(nw)
+        else: os.environ.pop("BRIE_TILE_HALVES", None)
         sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=1, Kg=Kg)
         for l in range(2): sh.upload(_capi.COUNT1 + l, layers[l])
         sh.add_pseudo_count(0.01)
@@ -31,7 +31,7 @@ def main():
     ref = make(3, 0, 0)
     for cyc in range(3):
         for (Kc, Kg) in ((32, 0), (3, 32)):
-            for nw in (4, 8):
+            for nw in (1, 2):
                 sh = make(Kc, Kg, nw)
                 print(json.dumps({"cycle": cyc, "Kc": Kc, "Kg": Kg, "nw": nw, "tile": blocks(sh), "ref": blocks(ref, 2)}), flush=True)
                 sh.close()

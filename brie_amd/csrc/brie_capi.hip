@@ -205,7 +205,9 @@ void setup_paths(brie_handle *h) {
     h->tile_lds = tiles + h->tile_nw * ttile;
     if (h->tile_lds > 160 * 1024 - 64 && h->tile_nw == 2) { h->tile_nw = 1; h->tile_lds = tiles + ttile; }   // one half still fits
     // (gene features 5..8 stay on the LDS-broadcast variant: measured 1.06 x vs 1.09 x the narrow model's step time)
-    h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg > 8)) && h->tile_lds <= 160 * 1024 - 64;
+    const char *mk = getenv("BRIE_TILE_MIN_KG");       // A/B runs: smallest Kg that takes the tile kernel (default 8)
+    const int min_kg = mk ? atoi(mk) : 8;
+    h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
     h->tile_nacc = Kc == 0 ? 0 : (Kc <= 32 ? 1 : 2);
     h->tile_njt = !h->coupled ? 0 : (kgp <= 32 ? 1 : 2);

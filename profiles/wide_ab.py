@@ -34,6 +34,7 @@ def main():
             os.environ["BRIE_WIDE_PATH"] = "lds"
         else:
             os.environ.pop("BRIE_WIDE_PATH", None)
+            os.environ["BRIE_TILE_MIN_KG"] = "5"           # A/B: also the small gene-feature sets on the tile kernel
         sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=1, Kg=Kg)
         for l in range(2):
             sh.upload(_capi.COUNT1 + l, layers[l])

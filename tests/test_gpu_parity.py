@@ -366,7 +366,7 @@ def test_mixed_count_tiers_per_gene_block(lib, L, MC, Kg):
 @pytest.mark.parametrize("mode,Kg,Kc,L,MC", [("cell", 0, 1, 2, 1), ("gene", 2, 1, 2, 1), ("cell", 4, 2, 3, 3),
                                              ("gene", 1, 0, 2, 2), ("cell", 3, 0, 2, 1),
                                              # Kg > 4: Xg tile in LDS, Wg_loc row broadcast with v_readlane
-                                             ("gene", 5, 1, 2, 1), ("cell", 16, 2, 3, 2), ("gene", 33, 8, 2, 3),
+                                             ("gene", 5, 1, 2, 1), ("gene", 8, 3, 2, 1), ("cell", 16, 2, 3, 2), ("gene", 33, 8, 2, 3),
                                              ("gene", 64, 0, 2, 1),
                                              # wide cell design (Kc > 8) together with the coupled terms
                                              ("cell", 0, 12, 2, 1), ("gene", 3, 20, 3, 2), ("cell", 9, 33, 2, 1)])

@@ -427,7 +427,9 @@ def main():
     # ---- N > 1: the end-of-fit exchange of a gene-sharded fit (BASELINE configs[3]: "RCCL weight all-gather"),
     # untimed by `value` (there is no collective inside the optimisation loop) but executed, checked and reported
     gather_info = None
-    if dist is not None and world > 1 and args.scaling == "strong":
+    # (BRIE_BENCH_FORCE_GATHER=1: run this leg with a world of ONE rank too -- the only way to put the nccl branch and
+    #  the C-ABI communicator through RCCL on a 1-GPU box)
+    if dist is not None and args.scaling == "strong" and (world > 1 or os.environ.get("BRIE_BENCH_FORCE_GATHER")):
         gather_info = end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank, dev, Xc, size,
                                            elapsed_local)
 

@@ -74,7 +74,7 @@ struct brie_handle {
     // tiers per gene block: cu[l] holds the u8 tiles of all u8 gene blocks first, then the u16 tiles; ONE launch, the
     // workgroup of a gene block picks its tier at run time
     std::vector<int32_t> tier_host;         // per gene block
-    int32_t *tier = nullptr, *list8 = nullptr, *list16 = nullptr;     // device: tier per block, block lists per tier
+    int32_t *tier = nullptr;                // device: tier per gene block
     int64_t *count_off = nullptr;           // device: element offset of every block's tile (in its tier's elements)
     int n8 = 0, n16 = 0;
     bool allow_compact = true;      // BRIE_COUNT_STORAGE=f32 / brie_set_count_storage(h, 1) disable it
@@ -309,10 +309,8 @@ int grid_1d(int64_t n);
 // or at the first step if none is added).
 int free_tier_tables(brie_handle *h) {
     if (h->tier) HIP_TRY(hipFree(h->tier));
-    if (h->list8) HIP_TRY(hipFree(h->list8));
-    if (h->list16) HIP_TRY(hipFree(h->list16));
     if (h->count_off) HIP_TRY(hipFree(h->count_off));
-    h->tier = h->list8 = h->list16 = nullptr;
+    h->tier = nullptr;
     h->count_off = nullptr;
     h->tier_host.clear();
     h->n8 = h->n16 = 0;
@@ -368,12 +366,8 @@ int try_compact_counts(brie_handle *h) {
         for (size_t k = 0; k < l8.size(); ++k) off[l8[k]] = static_cast<int64_t>(k * tile);                       // bytes = u8 elements
         for (size_t k = 0; k < l16.size(); ++k) off[l16[k]] = static_cast<int64_t>((l8.size() * tile) / 2 + k * tile);   // u16 elements
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->tier), h->gene_blocks * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->list8), l8.size() * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->list16), l16.size() * sizeof(int32_t)));
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->count_off), h->gene_blocks * sizeof(int64_t)));
         HIP_TRY(hipMemcpyAsync(h->tier, h->tier_host.data(), h->gene_blocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->list8, l8.data(), l8.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->list16, l16.data(), l16.size() * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipMemcpyAsync(h->count_off, off.data(), h->gene_blocks * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));          // the host vectors go out of scope
     }

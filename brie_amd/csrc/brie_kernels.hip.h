@@ -249,8 +249,7 @@ struct StepScalars {
     const int32_t *quad_ids;
     // Count tiers per gene block (kCountMixed): tier[gene block] = kCountU8 / kCountU16, count_off[gene block] = the
     // element offset (in elements of the block's own tier) of its count tile in the tier-packed layer; both null when
-    // the count tiles are laid out like the state tiles.  block_list (optional): blockIdx.x -> gene block.
-    const int32_t *block_list;
+    // the count tiles are laid out like the state tiles.
     const int64_t *count_off;
     const int32_t *tier;
 };
@@ -445,7 +444,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
 
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);   // gene block (uniform)
+    const int gb = static_cast<int>(blockIdx.x);         // gene block (workgroup-uniform)
     const int quad = gb * kWave + lane;                  // local gene quad
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
@@ -927,8 +926,7 @@ struct LossGeneArgs {
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
     const float *mbuf;      // wide designs: Xc.Wc_loc from the GEMM (KC == 0 instantiation), else null
-    const int32_t *block_list;      // count tiers per gene block, see StepScalars
-    const int64_t *count_off;
+    const int64_t *count_off;       // count tiers per gene block, see StepScalars
     const int32_t *tier;
     CoupledArgs cp;
 };
@@ -938,7 +936,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
     __shared__ float red[(kWavesPerBlock - 1) * 2 * kGenesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int gb = static_cast<int>(blockIdx.x);
     const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;
@@ -1090,7 +1088,7 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
     __shared__ float red[(kWavesPerBlock - 1) * S * kGenesPerBlock];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int gb = static_cast<int>(blockIdx.x);
     const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     int arrived = 0;
     if (threadIdx.x < 2) bar_ctr[threadIdx.x] = 0;
     const int half = lane >> 5, l31 = lane & 31;
-    const int gb = a.block_list ? a.block_list[blockIdx.x] : static_cast<int>(blockIdx.x);
+    const int gb = static_cast<int>(blockIdx.x);
     const int quad = gb * kWave + lane;
     const int j0 = quad * kVec;
     const bool active = j0 < a.Ng;

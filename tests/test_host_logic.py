@@ -296,3 +296,31 @@ def test_lrt_models_share_one_device_copy_of_the_counts(monkeypatch):
     made.clear()
     wrap.fit_BRIE_matrix(P["counts"], Xc=P["Xc"], LRT_index=[0], intercept_mode='cell', **FIT)
     assert len(made) == 2
+
+
+def test_c_abi_argument_checks_and_loud_failure_without_a_gpu(built_lib):
+    """No compute without a GPU: argument validation answers first (BRIE_ERR_INVALID / UNSUPPORTED with a message),
+    a well-formed problem fails loudly with BRIE_ERR_HIP on a GPU-less host -- never a CPU fallback."""
+    import ctypes
+    import torch
+    from brie_amd import _capi
+    lib = built_lib
+    h = ctypes.c_void_p()
+
+    def create(**kw):
+        f = dict(abi_version=_capi.ABI_VERSION, device=0, Nc=10, Ng=12, gene_offset=0, Kc=0, Kg=0, n_layers=2, has_efflen=0,
+                 intercept_mode=0, train_intercept=1, train_sigma=1, sharded=0, seed=1)
+        f.update(kw)
+        p = _capi.BrieProblem(*[f[name] for name, _ in _capi.BrieProblem._fields_])
+        return lib.brie_create(ctypes.byref(p), ctypes.byref(h)), lib.brie_last_error().decode()
+    for kw, code, word in ((dict(Nc=0), -1, "bad shape"), (dict(abi_version=1), -1, "abi_version"), (dict(Kc=65), -4, "Kc=65"),
+                           (dict(Kg=65), -4, "Kg=65"), (dict(n_layers=4), -1, "n_layers"), (dict(n_layers=3), -1, "third count layer"),
+                           (dict(gene_offset=6), -1, "multiple of 4"), (dict(intercept_mode=2), -1, "intercept_mode"),
+                           (dict(Kg=2, gene_offset=8), -4, "sharded=1")):
+        rc, msg = create(**kw)
+        assert rc == code and word in msg, (kw, rc, msg)
+    assert lib.brie_destroy(None) == 0 and lib.brie_step(None, 1, ctypes.c_float(0.1), 1, None) < 0
+    assert lib.brie_comm_init(0, 3, 2, None, ctypes.byref(h)) == -1
+    if not torch.cuda.is_available():
+        rc, msg = create()
+        assert rc == -3 and "hipGetDeviceCount" in msg and not h.value

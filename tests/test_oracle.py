@@ -150,6 +150,26 @@ def test_adam_step_matches_keras_formula():
     assert np.all(big.Z_loc == 9.0)                      # clip constraint (model_TFProb.py:81)
 
 
+def test_adam_moments_and_bias_correction_against_an_independent_library():
+    """Keras Adam (epsilon OUTSIDE the bias correction) is torch.optim.Adam with a step-dependent
+    epsilon:  lr sqrt(1-b2^t)/(1-b1^t) m / (sqrt(v) + eps)  ==  lr m_hat / (sqrt(v_hat) + eps / sqrt(1-b2^t)).
+    Ten steps of the oracle's update on random gradients against torch's optimiser with that epsilon pin the moment
+    recursions, both bias corrections and the update formula to an implementation that is not ours (TF itself is absent)."""
+    import torch
+    rng = np.random.default_rng(5)
+    o = OracleBRIE2(3, 8, 0, seed=2, dtype=np.float64)
+    x = torch.tensor(o.Z_std_log.copy(), dtype=torch.float64, requires_grad=True)      # an unconstrained variable
+    opt = torch.optim.Adam([x], lr=0.02, betas=(0.9, 0.999), eps=1e-7)
+    for t in range(1, 11):
+        g = rng.normal(size=(3, 8)) * 10.0 ** rng.integers(-6, 2, size=(3, 8))          # gradients over 8 decades
+        o.adam_step({"Z_loc": np.zeros((3, 8)), "Z_std_log": g, "intercept": np.zeros((1, 8)),
+                     "sigma_log": np.zeros((1, 8))}, 0.02)
+        opt.param_groups[0]["eps"] = 1e-7 / np.sqrt(1.0 - 0.999 ** t)
+        x.grad = torch.tensor(g)
+        opt.step()
+        np.testing.assert_allclose(o.Z_std_log, x.detach().numpy(), rtol=1e-12, atol=1e-15)
+
+
 def test_pseudo_count_rule():
     c1 = np.array([[0, 1, 0, 2]], np.float32)
     c2 = np.array([[0, 0, 3, 2]], np.float32)

@@ -170,6 +170,27 @@ def test_adam_moments_and_bias_correction_against_an_independent_library():
         np.testing.assert_allclose(o.Z_std_log, x.detach().numpy(), rtol=1e-12, atol=1e-15)
 
 
+def test_log_sigmoid_and_logmeanexp_against_independent_libraries():
+    """tf.math.log_sigmoid (model_TFProb.py:163-164) and tfp.math.reduce_logmeanexp (:189) as restated in the oracle,
+    against torch.nn.functional.logsigmoid and scipy.special.logsumexp over the whole clip range and beyond."""
+    import torch
+    from scipy.special import logsumexp
+    from oracle.brie_oracle import log_sigmoid, sigmoid
+    x = np.concatenate([np.linspace(-40, 40, 4001), [-1e-12, 0.0, 1e-12, -9.0, 9.0]])
+    np.testing.assert_allclose(log_sigmoid(x), torch.nn.functional.logsigmoid(torch.tensor(x)).numpy(), rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(sigmoid(x), torch.sigmoid(torch.tensor(x)).numpy(), rtol=1e-13, atol=1e-300)
+    # marginLik: loss_gene = -sum_i logmeanexp_k ll_k, with ll_k the oracle's own per-sample log-likelihood
+    Nc, Ng, MC = 7, 5, 6
+    P = make_problem(Nc, Ng, Kc=1, L=2, seed=3)
+    o = OracleBRIE2(Nc, Ng, 1, seed=4, dtype=np.float64)
+    eps = o.noise(MC)
+    o.draw -= 1
+    out = o.margin_loss_and_grads(P["counts"], P["Xc"], MC, eps=eps, need_grads=False)
+    z = o.prior_mean(P["Xc"])[None] + np.exp(o.sigma_log)[None] * eps
+    ll = np.stack([o.loglik_terms([np.asarray(c, np.float64) for c in P["counts"]], z[k])[0] for k in range(MC)])
+    np.testing.assert_allclose(out["loss_gene"], -(logsumexp(ll, axis=0) - np.log(MC)).sum(axis=0), rtol=1e-12)
+
+
 def test_pseudo_count_rule():
     c1 = np.array([[0, 1, 0, 2]], np.float32)
     c2 = np.array([[0, 0, 3, 2]], np.float32)

@@ -119,7 +119,7 @@ def hbm_traffic(args, world, storage):
     committed = {}
     try:
         committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
-            "%s_%s" % (args.config, {"u8/u16 per gene block": "mixed"}.get(storage, storage))) or {}
+            "%s_%s" % (args.config, {"u8/u16 per gene quad": "mixed"}.get(storage, storage))) or {}
     except (OSError, ValueError):
         pass
     eligible = world == 1 and args.mc == 1 and args.kc is None and not args.emulate_shard_of

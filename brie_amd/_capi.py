@@ -498,4 +498,4 @@ class Shard(object):
 
     @property
     def count_storage(self):
-        return {0: "f32", 1: "u8", 2: "u16", 3: "u8/u16 per gene block"}.get(int(self.lib.brie_get_count_storage(self._h)), "?")
+        return {0: "f32", 1: "u8", 2: "u16", 3: "u8/u16 per gene quad"}.get(int(self.lib.brie_get_count_storage(self._h)), "?")

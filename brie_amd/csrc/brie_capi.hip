@@ -70,13 +70,12 @@ struct brie_handle {
     // (Nc, ld)
     float *c[3] = {nullptr, nullptr, nullptr};
     void *cu[3] = {nullptr, nullptr, nullptr};      // compact (u8 / u16) count layers, same tiled indexing
-    int cs = brie::kCountF32;       // current count storage (kCountMixed: u8 or u16 per gene block)
-    // tiers per gene block: cu[l] holds the u8 tiles of all u8 gene blocks first, then the u16 tiles; ONE launch, the
-    // workgroup of a gene block picks its tier at run time
-    std::vector<int32_t> tier_host;         // per gene block
-    int32_t *tier = nullptr;                // device: tier per gene block
-    int64_t *count_off = nullptr;           // device: element offset of every block's tile (in its tier's elements)
-    int n8 = 0, n16 = 0;
+    int cs = brie::kCountF32;       // current count storage (kCountMixed: u8 or u16 per gene quad)
+    // tiers per gene quad (brie::TierTables): a row of a gene block's count tile is the concatenation of its quads' 4- or
+    // 8-byte pieces; ONE launch, every lane picks up its quad's width and offset at run time
+    std::vector<uint8_t> q_esz_host;        // per quad: 1 or 2 bytes per count
+    brie::TierTables tt{nullptr, nullptr, nullptr, nullptr};     // device tables
+    size_t tier_layer_bytes = 0;            // size of one tiered count layer
     bool allow_compact = true;      // BRIE_COUNT_STORAGE=f32 / brie_set_count_storage(h, 1) disable it
     bool compact_tried = false;
     float pc = 0.0f;                // pseudo-count applied in registers when cs == kCountU8
@@ -308,12 +307,13 @@ int grid_1d(int64_t n);
 // u16 if in [0,65535], else stay fp32.  Called once, when the counts are final (at the pseudo-count,
 // or at the first step if none is added).
 int free_tier_tables(brie_handle *h) {
-    if (h->tier) HIP_TRY(hipFree(h->tier));
-    if (h->count_off) HIP_TRY(hipFree(h->count_off));
-    h->tier = nullptr;
-    h->count_off = nullptr;
-    h->tier_host.clear();
-    h->n8 = h->n16 = 0;
+    if (h->tt.q_esz) HIP_TRY(hipFree(const_cast<uint8_t *>(h->tt.q_esz)));
+    if (h->tt.q_off) HIP_TRY(hipFree(const_cast<int32_t *>(h->tt.q_off)));
+    if (h->tt.row_bytes) HIP_TRY(hipFree(const_cast<int32_t *>(h->tt.row_bytes)));
+    if (h->tt.blk_base) HIP_TRY(hipFree(const_cast<int64_t *>(h->tt.blk_base)));
+    h->tt = brie::TierTables{nullptr, nullptr, nullptr, nullptr};
+    h->q_esz_host.clear();
+    h->tier_layer_bytes = 0;
     return BRIE_OK;
 }
 
@@ -321,62 +321,79 @@ size_t compact_layer_bytes(const brie_handle *h, int cs) {
     const size_t tile = static_cast<size_t>(h->p.Nc) * brie::kGenesPerBlock;
     if (cs == brie::kCountU8) return tile * h->gene_blocks;
     if (cs == brie::kCountU16) return tile * h->gene_blocks * 2;
-    return tile * (static_cast<size_t>(h->n8) + 2 * static_cast<size_t>(h->n16));
+    return h->tier_layer_bytes;
+}
+
+// device tables of the per-quad tiers from q_esz_host
+int build_tier_tables(brie_handle *h) {
+    const int nq = h->gene_blocks * brie::kWave;
+    std::vector<int32_t> q_off(static_cast<size_t>(nq)), row_bytes(static_cast<size_t>(h->gene_blocks));
+    std::vector<int64_t> blk_base(static_cast<size_t>(h->gene_blocks));
+    int64_t base = 0;
+    for (int g = 0; g < h->gene_blocks; ++g) {
+        int32_t off = 0;
+        for (int q = g * brie::kWave; q < (g + 1) * brie::kWave; ++q) { q_off[q] = off; off += 4 * h->q_esz_host[q]; }
+        row_bytes[g] = off;
+        blk_base[g] = base;
+        base += static_cast<int64_t>(off) * h->p.Nc;
+    }
+    h->tier_layer_bytes = static_cast<size_t>(base);
+    uint8_t *d_esz = nullptr; int32_t *d_off = nullptr, *d_row = nullptr; int64_t *d_base = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_esz), nq));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_off), nq * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_row), h->gene_blocks * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_base), h->gene_blocks * sizeof(int64_t)));
+    h->tt = brie::TierTables{d_esz, d_off, d_row, d_base};
+    HIP_TRY(hipMemcpyAsync(d_esz, h->q_esz_host.data(), nq, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_off, q_off.data(), nq * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_row, row_bytes.data(), h->gene_blocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(d_base, blk_base.data(), h->gene_blocks * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));          // the host vectors go out of scope
+    return BRIE_OK;
 }
 
 int try_compact_counts(brie_handle *h) {
     if (h->compact_tried) return BRIE_OK;
     h->compact_tried = true;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
-    // one flag word per gene block (tiled layout), one for everything otherwise
-    const int n_flags = h->tiled ? h->gene_blocks : 1;
-    const int64_t n4_per_block = h->tiled ? h->p.Nc * brie::kWave : n4;
+    // one flag word per gene quad (tiled layout), one for everything otherwise
+    const int n_flags = h->tiled ? h->gene_blocks * brie::kWave : 1;
     int *flag = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), n_flags * sizeof(int)));
     HIP_TRY(hipMemsetAsync(flag, 0, n_flags * sizeof(int), h->stream));
     for (int l = 0; l < h->p.n_layers; ++l)
-        hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4, n4_per_block, flag);
-    std::vector<int> bits_g(static_cast<size_t>(n_flags), 1);
-    hipError_t e = hipMemcpyAsync(bits_g.data(), flag, n_flags * sizeof(int), hipMemcpyDeviceToHost, h->stream);
+        hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4,
+                           h->tiled ? static_cast<int>(h->p.Nc) : 0, flag);
+    std::vector<int> bits_q(static_cast<size_t>(n_flags), 1);
+    hipError_t e = hipMemcpyAsync(bits_q.data(), flag, n_flags * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     hipFree(flag);
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "count range check: %s", hipGetErrorString(e));
     int bits = 0;
-    for (int b : bits_g) bits |= b;
+    for (int b : bits_q) bits |= b;
     if (bits & 4) {                               // the reference would silently produce NaN posteriors
         h->compact_tried = false;                 // checked again (and refused again) on the next attempt
         return fail(BRIE_ERR_INVALID, "count layers contain negative or non-finite values");
     }
     if ((bits & 1) || !h->allow_compact || !h->tiled) return BRIE_OK;     // fractional / huge: stay fp32
     int n16 = 0;
-    for (int b : bits_g) n16 += (b & 2) ? 1 : 0;
+    for (int b : bits_q) n16 += (b & 2) ? 1 : 0;
     const char *tm = getenv("BRIE_COUNT_TIERS");  // "uniform": one tier for the whole shard (A/B runs)
-    const bool uniform = n16 == 0 || n16 == n_flags || (tm && strcmp(tm, "uniform") == 0);
+    const int n_real = static_cast<int>((h->p.Ng + brie::kVec - 1) / brie::kVec);      // the padding quads hold zeros
+    const bool uniform = n16 == 0 || n16 == n_real || (tm && strcmp(tm, "uniform") == 0);
     const int cs = uniform ? ((bits & 2) ? brie::kCountU16 : brie::kCountU8) : brie::kCountMixed;
-    const size_t tile = static_cast<size_t>(h->p.Nc) * brie::kGenesPerBlock;
     if (cs == brie::kCountMixed) {
-        // u8 gene blocks first, then the u16 ones; tables on the device for the kernels
-        std::vector<int32_t> l8, l16;
-        std::vector<int64_t> off(static_cast<size_t>(h->gene_blocks));
-        h->tier_host.assign(static_cast<size_t>(h->gene_blocks), brie::kCountU8);
-        for (int g = 0; g < h->gene_blocks; ++g) {
-            if (bits_g[g] & 2) { h->tier_host[g] = brie::kCountU16; l16.push_back(g); } else l8.push_back(g);
-        }
-        h->n8 = static_cast<int>(l8.size()); h->n16 = static_cast<int>(l16.size());
-        for (size_t k = 0; k < l8.size(); ++k) off[l8[k]] = static_cast<int64_t>(k * tile);                       // bytes = u8 elements
-        for (size_t k = 0; k < l16.size(); ++k) off[l16[k]] = static_cast<int64_t>((l8.size() * tile) / 2 + k * tile);   // u16 elements
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->tier), h->gene_blocks * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->count_off), h->gene_blocks * sizeof(int64_t)));
-        HIP_TRY(hipMemcpyAsync(h->tier, h->tier_host.data(), h->gene_blocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipMemcpyAsync(h->count_off, off.data(), h->gene_blocks * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));          // the host vectors go out of scope
+        h->q_esz_host.resize(static_cast<size_t>(n_flags));
+        for (int q = 0; q < n_flags; ++q) h->q_esz_host[q] = (bits_q[q] & 2) ? 2 : 1;
+        int rc = build_tier_tables(h);
+        if (rc != BRIE_OK) return rc;
     }
     const size_t bytes = compact_layer_bytes(h, cs);
     for (int l = 0; l < h->p.n_layers; ++l) {
         HIP_TRY(hipMalloc(&h->cu[l], bytes));
         if (cs == brie::kCountMixed)
             hipLaunchKernelGGL(brie::count_compact_mixed, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4,
-                               n4_per_block, h->tier, h->count_off);
+                               static_cast<int>(h->p.Nc), h->tt);
         else
             hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
     }
@@ -391,14 +408,14 @@ void launch_expand(brie_handle *h, int l, float *dst, float pc, int apply_pc) {
     const int64_t n4 = h->p.Nc * h->ld / 4;
     if (h->cs == brie::kCountMixed)
         hipLaunchKernelGGL(brie::count_expand_mixed, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l],
-                           dst, n4, h->p.Nc * static_cast<int64_t>(brie::kWave), h->tier, h->count_off, pc, apply_pc);
+                           dst, n4, static_cast<int>(h->p.Nc), h->tt, pc, apply_pc);
     else
         hipLaunchKernelGGL(brie::count_expand, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->cu[0], h->cu[1], h->cu[l], dst,
                            n4, pc, apply_pc, h->cs);
 }
 
-// Mixed tiers -> one u16 tier for the whole shard (before the gene quads are permuted: a quad may move to a gene
-// block of the other tier).  Values are unchanged.
+// Mixed tiers -> one u16 tier for the whole shard (before the gene quads are permuted: the tier tables describe the
+// unpermuted order).  Values are unchanged.
 int retier_uniform_u16(brie_handle *h) {
     if (h->cs != brie::kCountMixed) return BRIE_OK;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
@@ -1074,11 +1091,10 @@ int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
     // LDS-broadcast wide variants: residual r written by the step, read back by wide_design_grad (the tile kernel keeps it on chip)
     const int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
-    if (h->cs == brie::kCountMixed) {                    // genes of u8 blocks move 1 byte per count, of u16 blocks 2
+    if (h->cs == brie::kCountMixed) {                    // genes of u8 quads move 1 byte per count, of u16 quads 2
         int64_t genes16 = 0;
-        for (int g = 0; g < h->gene_blocks; ++g)
-            if (h->tier_host[g] == brie::kCountU16)
-                genes16 += std::min<int64_t>(brie::kGenesPerBlock, h->p.Ng - static_cast<int64_t>(g) * brie::kGenesPerBlock);
+        for (int64_t q = 0; q * brie::kVec < h->p.Ng; ++q)
+            if (h->q_esz_host[static_cast<size_t>(q)] == 2) genes16 += std::min<int64_t>(brie::kVec, h->p.Ng - q * brie::kVec);
         return h->p.Nc * (h->p.Ng * (48 + gemm_streams) + static_cast<int64_t>(h->p.n_layers) * (h->p.Ng + genes16));
     }
     const int64_t per_count = h->cs == brie::kCountU8 ? 1 : (h->cs == brie::kCountU16 ? 2 : 4);
@@ -1190,7 +1206,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.kc_wide = h->wide_like ? h->p.Kc : 0;
     a.pc = h->pc;
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
-    if (h->cs == brie::kCountMixed) { a.count_off = h->count_off; a.tier = h->tier; }      // tiers per gene block, one launch
+    a.tt = h->tt;                    // tiers per gene quad (kCountMixed), one launch
     // wide designs: the MFMA tile kernel (ELBO target), else the LDS-broadcast variants + residual buffer
     const bool use_tile = h->tile && h->target == 0;
     if (h->wide_like && h->p.Kc > 0) {
@@ -1388,7 +1404,7 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.draw0 = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
     h->draw += static_cast<uint32_t>(n_repeats);
-    if (h->cs == brie::kCountMixed) { a.count_off = h->count_off; a.tier = h->tier; }
+    a.tt = h->tt;
     launch_loss_gene(h, brie::LaunchCfg{h->mode, h->cs, dim3(h->gene_blocks, h->n_chunks), h->stream, h->coupled ? 1 : 0}, a);
     hipLaunchKernelGGL(brie::loss_gene_reduce, dim3(h->fin_blocks), dim3(brie::kBlock), 0, h->stream, h->partials,
                        h->gene_tmp, h->ld, a.Ng, h->n_chunks, 1.0f / static_cast<float>(n_repeats));

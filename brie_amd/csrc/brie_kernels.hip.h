@@ -226,6 +226,18 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
 // ----------------------------------------------------------------------------
 // Kernel arguments
 // ----------------------------------------------------------------------------
+// Count storage kCountMixed: every gene quad (the 4 genes of one lane) keeps its counts as 4 bytes or as 4 half-words,
+// whichever its largest count over all cells and layers allows.  A row of a gene block's count tile is then the
+// concatenation of its 64 quads' 4- or 8-byte pieces: row_bytes[block] long, quad q at byte q_off[q] of the row, the
+// tile at blk_base[block] of the layer.  (Per 256-gene block the tier would be decided by the block's one largest
+// count: 45 of the 79 blocks of the synthetic configs[2] hold a count > 255, but only ~100 of its 5000 quads do.)
+struct TierTables {
+    const uint8_t *q_esz;       // (n_quads) bytes per count of the quad: 1 or 2
+    const int32_t *q_off;       // (n_quads) byte offset of the quad's piece inside its block's row
+    const int32_t *row_bytes;   // (gene_blocks)
+    const int64_t *blk_base;    // (gene_blocks) byte offset of the block's tile
+};
+
 // Scalars of one step.  Array pointers are passed as individual __restrict__
 // kernel parameters so that the compiler can prove the read-only inputs are not
 // clobbered by the state stores (wave-uniform Xc rows then go through SMEM).
@@ -247,11 +259,8 @@ struct StepScalars {
     // After freezing, the active gene quads are packed to the front (gather_quads); quad_ids[position]
     // is the quad's original index, which keys the noise stream -- results do not depend on the packing.
     const int32_t *quad_ids;
-    // Count tiers per gene block (kCountMixed): tier[gene block] = kCountU8 / kCountU16, count_off[gene block] = the
-    // element offset (in elements of the block's own tier) of its count tile in the tier-packed layer; both null when
-    // the count tiles are laid out like the state tiles.
-    const int64_t *count_off;
-    const int32_t *tier;
+    // Count tiers per gene QUAD (kCountMixed), see TierTables; unused for the other storages.
+    TierTables tt;
 };
 
 // Coupled modes: gene features Xg with per-cell weights Wg_loc (model_TFProb.py:124-125)
@@ -302,13 +311,13 @@ __device__ __forceinline__ float wave_sum8(const float (&t)[8], int lane) {
 // the fp32 values entering the arithmetic are bit-identical, the count traffic drops from 4L to L bytes.
 // kCountU16: same with two bytes per element for integers up to 65535 (4 genes = 8 B per lane).
 enum : int { kCountF32 = 0, kCountU8 = 1, kCountU16 = 2,
-             kCountMixed = 3 };   // u8 or u16 per 256-gene block, chosen per workgroup at run time (branch-free loads)
+             kCountMixed = 3 };   // u8 or u16 per gene quad (= per lane), branch-free loads
 
 template <int CS> struct CountRegs;
 template <> struct CountRegs<kCountF32> { F4 c1, c2, c3; };
 template <> struct CountRegs<kCountU8> { uint32_t u1, u2, u3; };
 template <> struct CountRegs<kCountU16> { uint2 u1, u2, u3; };
-template <> struct CountRegs<kCountMixed> { uint2 u1, u2, u3; int esz; };    // esz = bytes per count of this gene block
+template <> struct CountRegs<kCountMixed> { uint2 u1, u2, u3; int esz; };    // esz = bytes per count of this lane's quad
 
 typedef unsigned int uintx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint2 ld_u16x4(const void *p, int64_t off) {
@@ -321,11 +330,11 @@ __device__ __forceinline__ float u16_lane(const uint2 &u, int v) {
     return static_cast<float>((w >> (16 * (v & 1))) & 0xFFFFu);
 }
 
-// Mixed tiers: the lane's 4 counts are one dword (u8 block) or two (u16 block) at byte offset off * esz.  Both cases
-// issue the same two dword loads -- in a u8 block the second one repeats the first address and is ignored -- so the
-// row body stays free of branches (a guarded load would end the software pipeline, see elbo_adam_step).
+// Mixed tiers: the lane's 4 counts are one dword (u8 quad) or two (u16 quad) at BYTE offset `off`.  Both cases issue
+// the same two dword loads -- for a u8 quad the second one repeats the first address and is ignored -- so the row body
+// stays free of branches (a guarded load would end the software pipeline, see elbo_adam_step).
 __device__ __forceinline__ uint2 ld_mixed(const void *p, int64_t off, int esz) {
-    const char *q = static_cast<const char *>(p) + off * esz;
+    const char *q = static_cast<const char *>(p) + off;
     const uint32_t w0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(q));
     const uint32_t w1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(q + 4 * (esz - 1)));
     return make_uint2(w0, w1);
@@ -514,8 +523,10 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
-        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
-        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
+        // where the lane's counts live: element offsets for the plain storages, BYTE offsets for the tiered one
+        const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
+        const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad] : mbase;
+        const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
         bool on[kVec];
         {
             const F4 t = ld4(a.gene_active + j0);
@@ -535,7 +546,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.cb = cp.cb[r];
                 rs.clam = cp.clam[r];
             }
-            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt, esz);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
             if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
                 R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
             if constexpr (!MARGIN) {
@@ -926,8 +937,7 @@ struct LossGeneArgs {
     int32_t coupled;        // 1: add the gene-feature / per-cell terms of `cp` to the prior (run-time branch)
     int32_t margin;         // 1: target="marginLik": sample z from the prior, no KL term
     const float *mbuf;      // wide designs: Xc.Wc_loc from the GEMM (KC == 0 instantiation), else null
-    const int64_t *count_off;       // count tiers per gene block, see StepScalars
-    const int32_t *tier;
+    TierTables tt;                  // count tiers per gene quad (kCountMixed)
     CoupledArgs cp;
 };
 
@@ -986,8 +996,9 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
         const bool cell = a.coupled && a.cp.cell_mode != 0;
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
         const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
-        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
-        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
+        const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
+        const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad] : mbase;
+        const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             float wg[kKgMax] = {0.f, 0.f, 0.f, 0.f}, cbr = 0.f, clamr = 0.f;
@@ -1001,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             }
             const float row_isig2 = f_exp(-2.0f * clamr);
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(a.c1, a.c2, a.c3, cbase + static_cast<int64_t>(r) * a.row_stride, cr, esz);
+            load_counts<CS, MODE>(a.c1, a.c2, a.c3, cbase + static_cast<int64_t>(r) * crow, cr, esz);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             const F4 mu = ld4(a.mu + off), rho = ld4(a.rho + off);
@@ -1128,12 +1139,14 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
             for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
         const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
-        const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
-        const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
+        const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
+        const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad]
+                                                : static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
+        const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
         const float log_mc = f_log(static_cast<float>(a.mc));
         for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
             CountRegs<CS> cr;
-            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, cr, esz);
+            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, cr, esz);
             F4 c1, c2, c3;
             decode_counts<CS>(cr, a.pc, c1, c2, c3);
             float xc[KCX], m[kVec];
@@ -1493,10 +1506,9 @@ __global__ void scatter_sparse(const int64_t *indptr, const int32_t *indices, co
     }
 }
 
-// flag[gene block]: bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255; bit 2: some
-// value is negative / NaN / inf.  n4_per_block = float4 per gene block of the tiled layer (Nc * 64); one flag
-// (n4_per_block >= n4) for the row-major layout.
-__global__ void count_range_check(const float *c, int64_t n4, int64_t n4_per_block, int *flag) {
+// flag[gene quad]: bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255; bit 2: some
+// value is negative / NaN / inf.  Nc_tiled = Nc for the tiled layer, 0 (one flag word) for the row-major layout.
+__global__ void count_range_check(const float *c, int64_t n4, int Nc_tiled, int *flag) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const F4 a = ld4(c + 4 * i);
@@ -1507,24 +1519,48 @@ __global__ void count_range_check(const float *c, int64_t n4, int64_t n4_per_blo
             bad |= (a.v[v] > 255.0f) ? 2 : 0;
             bad |= !(a.v[v] >= 0.0f && a.v[v] < __builtin_inff()) ? 4 : 0;      // negative, NaN or inf: not a count
         }
-        if (bad) atomicOr(flag + i / n4_per_block, bad);
+        if (bad) {       // tiled: one flag word per gene quad, i == (gene block * Nc + cell) * 64 + lane
+            int *f = flag + (Nc_tiled ? i / (static_cast<int64_t>(Nc_tiled) * kWave) * kWave + i % kWave : 0);
+            if ((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bad) != bad) atomicOr(f, bad);
+        }
     }
 }
-// Mixed tiers: gene block g of the tiled fp32 layer -> its tile in the tier-packed layer (u8 or u16 per block);
-// off4[g] = offset of the block's tile in units of 4 count elements (= one lane quad) of ITS tier's element size,
-// i.e. byte offset = off4[g] * 4 * {1, 2}.
-__global__ void count_compact_mixed(const float *c, void *dst, int64_t n4, int64_t n4_per_block, const int32_t *tier,
-                                    const int64_t *off_elems) {
+// tiled fp32 layer -> tiered layer (TierTables): one thread per (cell, quad)
+__global__ void count_compact_mixed(const float *c, void *dst, int64_t n4, int Nc, const TierTables tt) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int64_t g = i / n4_per_block, inner = i - g * n4_per_block;
+        const int64_t g = i / (static_cast<int64_t>(Nc) * kWave);
+        const int64_t r = (i / kWave) % Nc;
+        const int64_t quad = g * kWave + (i % kWave);
         const F4 a = ld4(c + 4 * i);
         const uint32_t x0 = static_cast<uint32_t>(a.v[0]), x1 = static_cast<uint32_t>(a.v[1]),
                        x2 = static_cast<uint32_t>(a.v[2]), x3 = static_cast<uint32_t>(a.v[3]);
-        if (tier[g] == kCountU8)
-            reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(dst) + off_elems[g])[inner] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
-        else
-            reinterpret_cast<uint2 *>(static_cast<uint16_t *>(dst) + off_elems[g])[inner] = make_uint2(x0 | (x1 << 16), x2 | (x3 << 16));
+        uint32_t *q = reinterpret_cast<uint32_t *>(static_cast<char *>(dst) + tt.blk_base[g] + r * tt.row_bytes[g] + tt.q_off[quad]);
+        if (tt.q_esz[quad] == 1) q[0] = x0 | (x1 << 8) | (x2 << 16) | (x3 << 24);
+        else { q[0] = x0 | (x1 << 16); q[1] = x2 | (x3 << 16); }
+    }
+}
+__device__ __forceinline__ float mixed_get(const void *p, int64_t g, int64_t r, int64_t quad, int v, const TierTables &tt) {
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(static_cast<const char *>(p) + tt.blk_base[g] + r * tt.row_bytes[g] + tt.q_off[quad]);
+    const bool bytes = tt.q_esz[quad] == 1;
+    return mixed_lane(make_uint2(q[0], bytes ? 0u : q[1]), v, bytes);
+}
+__global__ void count_expand_mixed(const void *u1, const void *u2, const void *self, float *dst, int64_t n4, int Nc,
+                                   const TierTables tt, float pc, int apply_pc) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t g = i / (static_cast<int64_t>(Nc) * kWave);
+        const int64_t r = (i / kWave) % Nc;
+        const int64_t quad = g * kWave + (i % kWave);
+        F4 o;
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) {
+            const float tot = mixed_get(u1, g, r, quad, v, tt) + mixed_get(u2, g, r, quad, v, tt);
+            float val = mixed_get(self, g, r, quad, v, tt);
+            if (apply_pc && tot > 0.0f) val += pc;
+            o.v[v] = val;
+        }
+        st4(dst + 4 * i, o);
     }
 }
 // fp32 layer -> compact layer (same element index; 4 genes per thread)
@@ -1542,29 +1578,6 @@ __device__ __forceinline__ float compact_get(const void *p, int64_t i, int v, in
     if (cs == kCountU8) return static_cast<float>((static_cast<const uint32_t *>(p)[i] >> (8 * v)) & 0xFFu);
     const uint2 u = static_cast<const uint2 *>(p)[i];
     return u16_lane(u, v);
-}
-__device__ __forceinline__ float mixed_get(const void *p, int64_t g, int64_t inner, int v, const int32_t *tier,
-                                           const int64_t *off_elems) {
-    if (tier[g] == kCountU8)
-        return static_cast<float>((reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(p) + off_elems[g])[inner] >> (8 * v)) & 0xFFu);
-    return u16_lane(reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(p) + off_elems[g])[inner], v);
-}
-__global__ void count_expand_mixed(const void *u1, const void *u2, const void *self, float *dst, int64_t n4,
-                                   int64_t n4_per_block, const int32_t *tier, const int64_t *off_elems, float pc,
-                                   int apply_pc) {
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
-         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        const int64_t g = i / n4_per_block, inner = i - g * n4_per_block;
-        F4 o;
-#pragma unroll
-        for (int v = 0; v < kVec; ++v) {
-            const float tot = mixed_get(u1, g, inner, v, tier, off_elems) + mixed_get(u2, g, inner, v, tier, off_elems);
-            float val = mixed_get(self, g, inner, v, tier, off_elems);
-            if (apply_pc && tot > 0.0f) val += pc;
-            o.v[v] = val;
-        }
-        st4(dst + 4 * i, o);
-    }
 }
 // inverse, with the pseudo-count rule of the compact storage (apply_pc for the two unique layers)
 __global__ void count_expand(const void *u1, const void *u2, const void *self, float *dst, int64_t n4, float pc,

@@ -145,8 +145,9 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     }
     const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
     const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
-    const int64_t cbase = (a.count_off ? a.count_off[gb] : static_cast<int64_t>(gb) * a.gb_stride) + lane * kVec;
-    const int esz = CS == kCountMixed ? (a.tier[gb] == kCountU8 ? 1 : 2) : 0;
+    const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
+    const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad] : mbase;
+    const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
     bool on[kVec], real[kVec];
     {
         const F4 tt = ld4(a.gene_active + j0);
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
 
     auto load_row = [&](int r, RowRegs<CS> &R) {
         const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * a.row_stride, R.cnt, esz);
+        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
         R.mu = ld4s(mu_p + off);
         R.rho = ld4s(rho_p + off);
         R.mm = ld4s(mmu_p + off);

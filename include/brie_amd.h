@@ -254,8 +254,8 @@ int64_t brie_step_storage_bytes(const brie_handle *h);
 /* Count-layer storage (the reference densifies to fp32, model_wrap.py:108-111).
  * mode 0 = auto (default): integer counts in [0,255] are kept as u8, in [0,65535] as u16; the
  * pseudo-count of model_wrap.py:113-117 is then applied in registers; mode 1 = always fp32.
- * brie_get_count_storage: 0 = fp32, 1 = u8, 2 = u16, 3 = u8 or u16 per 256-gene block (decided at
- * brie_add_pseudo_count / first step; a gene block holding a count > 255 takes u16, the others stay u8). */
+ * brie_get_count_storage: 0 = fp32, 1 = u8, 2 = u16, 3 = u8 or u16 per gene quad (4 consecutive genes; decided at
+ * brie_add_pseudo_count / first step; a quad holding a count > 255 keeps two bytes per count, the others one). */
 int brie_set_count_storage(brie_handle *h, int32_t mode);
 int brie_get_count_storage(const brie_handle *h);
 

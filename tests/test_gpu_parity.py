@@ -288,7 +288,8 @@ def test_compact_u8_counts_bit_identical_to_fp32(lib, L, Kc, MC):
 
 
 def test_count_storage_tiers(lib):
-    """Counts above 255 use u16 (bit-identical to fp32), above 65535 or fractional keep fp32."""
+    """Counts above 255 use u16 (for the gene quads that hold one; bit-identical to fp32), above 65535 or fractional
+    keep fp32."""
     from brie_amd import _capi
     Nc, Ng, Kc = 40, 64, 1
     P = util.problem(Nc, Ng, Kc, 2, seed=29)
@@ -299,7 +300,10 @@ def test_count_storage_tiers(lib):
     huge["counts"][0][3, 5] = 70000.0
     frac = dict(P, counts=[c.copy() for c in P["counts"]])
     frac["counts"][1][7, 9] += 0.5
-    for Q, want in ((big, "u16"), (huge, "f32"), (frac, "f32")):
+    allbig = dict(P, counts=[c.copy() for c in P["counts"]])
+    allbig["counts"][0][3, ::4] = 300.0           # every gene quad holds a count > 255
+    allbig["counts"][1][11, 63] = 65535.0
+    for Q, want in ((big, "u8/u16 per gene quad"), (allbig, "u16"), (huge, "f32"), (frac, "f32")):
         Q["counts_pc"] = util.add_pseudo_count(Q["counts"], 0.01)
         sh = util.device_shard(Q, Nc, Ng, Kc, 31)
         ref = util.device_shard(Q, Nc, Ng, Kc, 31, storage="f32")
@@ -319,24 +323,30 @@ def test_count_storage_tiers(lib):
 
 
 @pytest.mark.parametrize("L,MC,Kg", [(2, 1, 0), (3, 3, 0), (2, 1, 2), (2, 1, 6)])
-def test_mixed_count_tiers_per_gene_block(lib, L, MC, Kg):
-    """Several 256-gene blocks, only some holding a count > 255: those take u16, the others stay u8 (two launches
-    per pass over disjoint gene blocks).  Bit-identical to fp32 storage for steps, loss_gene, per-batch packing
+def test_mixed_count_tiers_per_gene_quad(lib, L, MC, Kg):
+    """Only some gene quads hold a count > 255: those keep 2 bytes per count, all others 1 (one launch, every lane
+    picks up its quad's width and row offset).  Bit-identical to fp32 storage for steps, loss_gene, per-batch packing
     (which first re-tiers to one u16 tier) and the count read-back; close to the oracle."""
     from brie_amd import _capi
     Nc, Ng, Kc = 70, 1100, 2                # 5 gene blocks, the last partly filled
     P = util.problem(Nc, Ng, Kc, L, seed=41)
     P["counts"] = [c.copy() for c in P["counts"]]
     P["counts"][0][3, 300] = 999.0          # block 1
-    P["counts"][1][69, 1099] = 40000.0      # block 4 (the ragged one)
+    P["counts"][1][69, 1099] = 40000.0      # block 4 (the ragged one), its last quad
+    P["counts"][0][0, 0] = 300.0            # first lane of block 0
+    P["counts"][1][5, 255] = 256.0          # last lane of block 0 ...
+    P["counts"][L - 1][7, 257] = 65535.0    # ... and its neighbour, the first lane of block 1
+    P["counts"][0][11, 702] = 1000.0
+    hot = np.unique(np.concatenate([np.nonzero((c > 255).any(axis=0))[0] // 4 for c in P["counts"]]))
+    assert hot.tolist() == [0, 63, 64, 75, 175, 274]
     P["counts_pc"] = util.add_pseudo_count(P["counts"], 0.01)
     if Kg:
         P["Xg"] = np.random.default_rng(3).normal(size=(Ng, Kg)).astype(np.float32)
     sh = util.device_shard(P, Nc, Ng, Kc, 31, Kg=Kg)
     ref = util.device_shard(P, Nc, Ng, Kc, 31, storage="f32", Kg=Kg)
     tr = sh.step(4, 0.01, MC)
-    assert sh.count_storage == "u8/u16 per gene block"
-    assert sh.step_storage_bytes() == Nc * (Ng * 48 + L * (Ng + 256 + (Ng - 1024)))
+    assert sh.count_storage == "u8/u16 per gene quad"
+    assert sh.step_storage_bytes() == Nc * (Ng * 48 + L * (Ng + 4 * len(hot)))
     np.testing.assert_array_equal(tr, ref.step(4, 0.01, MC))
     # (the forward-only pass is a different template instantiation per storage: fused multiply-adds may be
     # contracted differently, so its sums agree to the last ulp or two, not bit for bit)

@@ -57,8 +57,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-        const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        // one 32x32->64 product each (v_mad_u64_u32) instead of v_mul_hi_u32 + v_mul_lo_u32: 23 % fewer cycles per
+        // round on gfx950 (profiles/micro/philox_mul.hip), same bits
+        const uint64_t p0 = static_cast<uint64_t>(M0) * c0, p1 = static_cast<uint64_t>(M1) * c2;
+        const uint32_t hi0 = static_cast<uint32_t>(p0 >> 32), lo0 = static_cast<uint32_t>(p0);
+        const uint32_t hi1 = static_cast<uint32_t>(p1 >> 32), lo1 = static_cast<uint32_t>(p1);
         const uint32_t n0 = hi1 ^ c1 ^ k0;
         const uint32_t n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
@@ -112,10 +115,31 @@ __device__ __forceinline__ float f_log(float x) {
     return logf(x);
 #endif
 }
+// f_log for the VALU-bound forward passes (loss_gene_eval, margin_step).  Every logarithm on this path takes a normal
+// number >= ~1 (1 + exp(-|z|), a sum of effective lengths, a sum of exp(l - max) >= 1), so the fast build spells out what
+// __logf does for a normal input -- v_log_f32 times ln2 as an extended-precision product -- and leaves away the
+// denormal-input rescue (compare, two selects, ldexp, subtract) and the infinity check (compare, select) it wraps around
+// that: 7 VALU instructions per logarithm that can never fire here.  Bit-identical to __logf for every positive normal
+// fp32 value (all 2.13e9 checked: profiles/micro/fast_log.hip).  The HBM-bound step kernels keep __logf: there the
+// instructions are free and the longer dependent chain costs registers (MC_size 3 fell from 2 waves / SIMD to 1).
+template <bool LEAN>
+__device__ __forceinline__ float f_log_sel(float x) {
+#if BRIE_FAST_MATH
+    if constexpr (LEAN) {
+#pragma clang fp contract(off)                                        // y * c and the final sum stay two roundings
+        const float y = __builtin_amdgcn_logf(x);
+        constexpr float c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;    // ln2 = c + cc
+        const float r = y * c;
+        return r + __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
+    }
+#endif
+    return f_log(x);
+}
+template <bool LEAN = false>
 __device__ __forceinline__ float f_log1p(float x) {
 #if BRIE_FAST_MATH
     // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2
-    return x < 1e-3f ? x * (1.0f - 0.5f * x) : __logf(1.0f + x);
+    return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<LEAN>(1.0f + x);
 #else
     return log1pf(x);
 #endif
@@ -187,7 +211,7 @@ enum : int { kLik2 = 0,      // 2 categories, no effLen   (model_TFProb.py:162-1
              kLikEff3 = 2 }; // effLen, 3 count layers    (model_TFProb.py:184-185)
 
 // Per-sample log-likelihood l(z) and dl/dz for one element.
-template <int MODE>
+template <int MODE, bool LEAN = false>
 __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
                                        float L0, float L4, float L5,
                                        float lL0, float lL4, float lL5,
@@ -202,7 +226,7 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
 #endif
     const float sp = z >= 0.0f ? big : small;     // sigmoid(z)
     const float sn = z >= 0.0f ? small : big;     // sigmoid(-z)
-    const float l1p = f_log1p(e);
+    const float l1p = f_log1p<LEAN>(e);
     const float ls1 = fminf(z, 0.0f) - l1p;       // log_sigmoid(z)
     const float ls2 = fminf(-z, 0.0f) - l1p;      // log_sigmoid(-z)
     if (MODE == kLik2) {
@@ -210,7 +234,7 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
         g = c1 - (c1 + c2) * sp;
     } else {
         const float D = sp * L0 + sn * L4 + L5;
-        const float lD = f_log(D);
+        const float lD = f_log_sel<LEAN>(D);
         const float iD = f_rcp(D);
         const float phi1 = sp * L0 * iD, phi2 = sn * L4 * iD;
         float N = c1 + c2;
@@ -1045,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
 #pragma unroll
                 for (int v = 0; v < kVec; ++v) {
                     float l, g;
-                    loglik<MODE>(fmaf(s[v], e[v], zc[v]), c1.v[v], c2.v[v], c3.v[v],
+                    loglik<MODE, true>(fmaf(s[v], e[v], zc[v]), c1.v[v], c2.v[v], c3.v[v],
                                  L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
                     lsum[v] += l;
                 }
@@ -1167,7 +1191,7 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
 #pragma unroll
                 for (int v = 0; v < kVec; ++v) {
                     float l, g;
-                    loglik<MODE>(fmaf(sig[v], e[v], m[v]), c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                    loglik<MODE, true>(fmaf(sig[v], e[v], m[v]), c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
                                  lL0[v], lL4[v], lL5[v], l, g);
                     const float nm = fmaxf(M[v], l);                  // online log-sum-exp
                     const float so = f_exp(M[v] - nm), sn = f_exp(l - nm);
@@ -1185,7 +1209,7 @@ __global__ __launch_bounds__(kBlock) void margin_step(const void *__restrict__ c
                 for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], q, acc[k][v]);
                 acc[KC + 0][v] += q;
                 acc[KC + 1][v] -= qe;
-                acc[KC + 3][v] += M[v] + f_log(Ssum[v]) - log_mc;     // reduce_logmeanexp
+                acc[KC + 3][v] += M[v] + f_log_sel<true>(Ssum[v]) - log_mc;     // reduce_logmeanexp
             }
         }
     }

@@ -357,6 +357,7 @@ class BRIE2(object):
         self._pseudo_count = pseudo_count
         sh = self._ensure_shard(count_layers, Xc, Xg)
         sh.set_target(target)
+        upload_s = time.time() - start_time                         # host -> device, tiling, count tiers (blocking)
         self._results = None
         staging = self._start_result_buffers(sh) if (prefetch_results and hasattr(sh, "read_results_async")) else None
 
@@ -440,7 +441,7 @@ class BRIE2(object):
 
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
-        tm = self.timing = {"optimise_s": time.time() - start_time}
+        tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s}
         t0 = time.time()
         if staging is not None:              # results stream out on a second stream while loss_gene computes
             bufs, pinned, th = staging

@@ -385,9 +385,12 @@ class BRIE2(object):
 
         self.n_iter_batch = None
         losses = np.zeros(0, np.float32)
+        stage_s = []
         for i in range(6):                                           # model_TFProb.py:235-241
+            t_stage = time.time()
             sh.reset_optimizer()                                     # fresh Adam per stage
             losses = run(int(min_iter / 6), LEARNING_RATES[i])
+            stage_s.append(time.time() - t_stage)
         n_iter = min_iter + 0                                        # model_TFProb.py:247-258
         d1 = int(min(50, add_iter / 2))
         d2 = d1 * 2
@@ -441,7 +444,7 @@ class BRIE2(object):
 
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
-        tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s}
+        tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s, "stage_s": stage_s}
         t0 = time.time()
         if staging is not None:              # results stream out on a second stream while loss_gene computes
             bufs, pinned, th = staging

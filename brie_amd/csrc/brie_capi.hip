@@ -198,7 +198,8 @@ void setup_paths(brie_handle *h) {
     // LDS of one workgroup: the read-only Wc_loc / Xg tiles of the gene block + one T tile per 4-wave half.  Two plain
     // workgroups per CU while that is under 80 KB; else ONE workgroup of two independent halves sharing the tiles.
     const int tiles = static_cast<int>(sizeof(float)) * (Kc * brie::kGenesPerBlock + kgp * brie::kXgStride);
-    const int ttile = static_cast<int>(sizeof(float)) * brie::kTileRows * brie::kTileStride;
+    // per half: the T tile and the design rows [Xc | Wg_loc] of the tile's 32 cells
+    const int ttile = static_cast<int>(sizeof(float)) * brie::kTileRows * (brie::kTileStride + brie::tile_a_stride(Kc + kgp));
     const char *nhe = getenv("BRIE_TILE_HALVES");      // 1 / 2: force (A/B runs)
     h->tile_nw = nhe ? (atoi(nhe) == 2 ? 2 : 1) : (tiles + ttile <= 80 * 1024 ? 1 : 2);
     h->tile_lds = tiles + h->tile_nw * ttile;

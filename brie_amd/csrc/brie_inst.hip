@@ -1,5 +1,6 @@
 // brie_inst.hip -- instantiates elbo_adam_step / loss_gene_eval for ONE cell-feature count
 // (-DBRIE_KC=N) over likelihood mode x MC_size {1, 3, run-time} x count storage {fp32, u8, u16}.
+#include <cstdlib>
 #include "brie_launch.h"
 
 #ifndef BRIE_KC
@@ -12,11 +13,27 @@ namespace brie {
 
 namespace {
 
+// Two workgroups per CU stream best (2 waves per SIMD).  An instantiation that needs <= 168 VGPRs -- u8 counts with few
+// cell features: 166 -- would be scheduled three deep and then runs 1.6 % slower on a fast box (8.26 vs 8.13 ms at the C3
+// shape, profiles/r03m_occ_ab.log).  Capping it through the register allocator (amdgpu_waves_per_eu) changes the code of
+// every instantiation (MC_size 3 with effLen: 13 % slower, profiles/r03n_ab_max_waves.log), so such a kernel is simply
+// launched with 54 KB of unused dynamic LDS: three workgroups no longer fit the CU's 160 KB.
+template <typename Kern>
+int occupancy_pad(Kern kern) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kern)) != hipSuccess) return 0;
+    const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP");       // "0": leave the occupancy to the hardware (A/B runs)
+    if (e && e[0] == '0') return 0;
+    return at.numRegs <= 168 ? 54 * 1024 : 0;
+}
+
 template <int MODE, int MC, int CS, bool CPL>
 void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
-    hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>), c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2,
+    auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>;
+    static const int pad = occupancy_pad(kern);
+    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
-                       q.partials, a, cp);
+                       q.partials, a, cp, static_cast<float *>(nullptr));
 }
 
 // Kg > 4: coupled variant with the gene block's Xg tile in dynamic LDS (up to 64 KiB on top of the static arrays)

@@ -26,7 +26,10 @@ namespace brie {
 
 constexpr int kTileRows = 32;
 constexpr int kTileStride = kGenesPerBlock + 4;      // floats per tile row: 16-B aligned rows, column reads 4-way banked
-constexpr int kXgStride = kGenesPerBlock + 1;        // Xg tile rows: conflict-free when lanes walk features
+constexpr int kXgStride = kGenesPerBlock + 4;        // Xg tile rows: 16-B aligned; 16 lanes walking features at one gene offset hit
+                                                     // 16 different bank quads (ds_read_b128 in the R.Xg product)
+
+__host__ __device__ constexpr int tile_a_stride(int ka) { return ka | 1; }
 
 struct TileArgs {
     const float *Xc;            // (Nc, Kc)
@@ -40,6 +43,18 @@ struct TileArgs {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// -DBRIE_TILE_PROF=1 (tuning builds only): every wave sums the cycles it spends in the phases of a tile; wave 0 lane 0 of
+// each half adds them to tile_prof[] (read with brie_debug_tile_prof, profiles/tile_phases.py).
+#ifndef BRIE_TILE_PROF
+#define BRIE_TILE_PROF 0
+#endif
+#if BRIE_TILE_PROF
+static __device__ unsigned long long tile_prof[16];
+#define BRIE_PROF_MARK(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_[slot] += now_ - prof_t_; prof_t_ = now_; } while (0)
+#else
+#define BRIE_PROF_MARK(slot) do { } while (0)
+#endif
 
 // NACC = 32-feature accumulator sets for Xc^T.R (0: Kc == 0, 1: Kc <= 32, 2: Kc <= 64)
 // NJT  = 32-feature output tiles of R.Xg        (0: Kg == 0, 1: kgp <= 32, 2: kgp <= 64)
@@ -73,7 +88,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     constexpr int CB = 8 / NW;              // 32-gene column blocks per wave
     constexpr int NT = NH * kBlock;         // threads per workgroup
     constexpr bool CPL = NJT > 0;           // per-cell statistics are only produced with gene features / cell mode
-    // dynamic LDS: NH x [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257]; the cross-wave folds reuse T
+    // dynamic LDS: NH x [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257] NH x [At 32 x (Kc + kgp | 1)]; the cross-wave folds reuse T
     extern __shared__ __align__(16) float lds[];
     __shared__ int bar_ctr[2];
     const int lane = threadIdx.x & (kWave - 1);
@@ -84,6 +99,10 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     float *T = lds + hf * (kTileRows * kTileStride);
     float *wl = lds + NH * (kTileRows * kTileStride);
     float *xl = wl + t.Kc * kGenesPerBlock;
+    // A-operand tile of the half: the design rows [Xc | Wg_loc] of the tile's 32 cells (odd row stride: conflict-free when
+    // the 32 lanes of a half-wave walk cells)
+    const int KA = t.Kc + t.kgp, AS = tile_a_stride(KA);
+    float *At = xl + t.kgp * kXgStride + hf * (kTileRows * AS);
     int *ctr = bar_ctr + hf;
     int arrived = 0;
     if (threadIdx.x < 2) bar_ctr[threadIdx.x] = 0;
@@ -119,30 +138,34 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
 #pragma unroll
             for (int q = 0; q < 16; ++q) G[n][c][q] = 0.0f;
 
-    // per-gene parameters of the lane's 4 genes
+    // Per-gene parameters of the lane's 4 genes.  They are only needed while rows stream (phase B), so every tile fetches
+    // them again (L2 hits, 3 - 9 float4 per lane against the tile's 410 KB) instead of holding 12 - 36 registers through the
+    // MFMA phases, whose operand double buffers need them; the laundered index keeps the loads inside the tile loop.
     float bj[kVec], lamj[kVec], isig2[kVec];
     float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
-    {
-        const F4 tb = ld4(bp + j0), tl = ld4(lamp + j0);
+    auto load_gene_params = [&]() {
+        int jj = j0;
+        asm volatile("" : "+v"(jj));
+        const F4 tb = ld4(bp + jj), tl = ld4(lamp + jj);
 #pragma unroll
         for (int v = 0; v < kVec; ++v) {
             bj[v] = tb.v[v];
             lamj[v] = tl.v[v];
             isig2[v] = f_exp(-2.0f * tl.v[v]);
         }
-    }
-    if (MODE != kLik2) {
-        const F4 t0 = ld4(effL + 0 * a.ld + j0), t1 = ld4(effL + 1 * a.ld + j0), t2 = ld4(effL + 2 * a.ld + j0),
-                 t3 = ld4(effL + 3 * a.ld + j0), t4 = ld4(effL + 4 * a.ld + j0), t5 = ld4(effL + 5 * a.ld + j0);
+        if (MODE != kLik2) {
+            const F4 t0 = ld4(effL + 0 * a.ld + jj), t1 = ld4(effL + 1 * a.ld + jj), t2 = ld4(effL + 2 * a.ld + jj),
+                     t3 = ld4(effL + 3 * a.ld + jj), t4 = ld4(effL + 4 * a.ld + jj), t5 = ld4(effL + 5 * a.ld + jj);
 #pragma unroll
-        for (int v = 0; v < kVec; ++v) {
-            L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
-            lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+            for (int v = 0; v < kVec; ++v) {
+                L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
+                lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
         }
-    } else {
-#pragma unroll
-        for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
-    }
+    };
     const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
     const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
     const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
@@ -249,11 +272,64 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
         }
     };
 
-    const int kc2 = (t.Kc + 1) >> 1, kg2 = (t.kgp + 1) >> 1;
+    // Addresses that only depend on the lane are tile-invariant; hoisted out of the tile loop they would sit in ~20
+    // VGPRs through the streaming phase (the kernel's register peak).  fresh() hides the lane index from that hoisting:
+    // each MFMA phase recomputes its handful of addresses.
+    auto fresh = [](int x) { asm volatile("" : "+v"(x)); return x; };
     RowRegs<CS> cur;
     load_row(min(row0 + w, row_end - 1), cur);             // (a wave without rows in this chunk loads one and drops it)
+#if BRIE_TILE_PROF
+    unsigned long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, prof_t_ = __builtin_readcyclecounter();
+#endif
+
+    // The design rows of a tile are two contiguous runs in memory (32 x Kc of Xc, 32 x kgp of Wg_loc): the half fetches
+    // them with coalesced loads into registers while the previous tile finishes, and drops them into At once that tile's
+    // readers are through.  (Each lane fetching its own A operand inside the MFMA loop -- one 4-byte load per lane, row
+    // and k-step -- cost 64 cache lines per instruction and one L2 round trip per k-step: 17 000 cycles for a forward
+    // product whose MFMAs take 4 400, profiles/r03j_tile_phases.log.)
+    constexpr int NXL = 4 * NACC, NGL = 4 * NJT;            // loads per thread: 32 x 32 NACC (NJT) floats over 256 threads
+    float pre_x[NXL > 0 ? NXL : 1], pre_g[NGL > 0 ? NGL : 1];
+    const float inv_kc = t.Kc > 0 ? 1.0f / static_cast<float>(t.Kc) : 0.0f;
+    const float inv_kg = t.kgp > 0 ? 1.0f / static_cast<float>(t.kgp) : 0.0f;
+    // (the empty asm keeps the per-thread element indices -- tile-invariant -- from being hoisted out of the tile loop,
+    // where 16 addresses + 16 predicates would stay live across the streaming phase, the kernel's register peak)
+    auto fetch_design = [&](int tr0) {
+        const int n_ok = min(kTileRows, row_end - tr0);    // rows of the tile inside the chunk
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            int e = tid + kBlock * i;
+            asm volatile("" : "+v"(e));
+            pre_x[i] = e < n_ok * t.Kc ? t.Xc[static_cast<int64_t>(tr0) * t.Kc + e] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) {
+            int e = tid + kBlock * i;
+            asm volatile("" : "+v"(e));
+            pre_g[i] = e < n_ok * t.kgp ? t.Wg[static_cast<int64_t>(tr0) * t.kgp + e] : 0.0f;
+        }
+    };
+    auto store_design = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            int e = tid + kBlock * i;
+            asm volatile("" : "+v"(e));
+            const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_kc);        // e / Kc (exact: e < 4096)
+            if (e < kTileRows * t.Kc) At[row * AS + (e - row * t.Kc)] = pre_x[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) {
+            int e = tid + kBlock * i;
+            asm volatile("" : "+v"(e));
+            const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_kg);
+            if (e < kTileRows * t.kgp) At[row * AS + t.Kc + (e - row * t.kgp)] = pre_g[i];
+        }
+    };
+    fetch_design(row0);
 
     for (int tr0 = row0; tr0 < row_end; tr0 += kTileRows) {
+        store_design();
+        tile_sync<NH>(ctr, arrived);
+        BRIE_PROF_MARK(6);
         // ---- A: prior-mean tile on the matrix cores: T[i][gene] = sum_k X[i][k] W[k][gene] + sum_k Wg[i][k] Xg[gene][k]
         {
             f32x16 D[CB];
@@ -261,30 +337,45 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int q = 0; q < 16; ++q) D[c][q] = 0.0f;
-            const int ar = tr0 + l31;                       // the lane's A row (cell)
-            const bool arow_ok = ar < row_end;
-            for (int kk = 0; kk < kc2; ++kk) {
-                const int k = 2 * kk + half;
-                const bool ok = arow_ok && k < t.Kc;
-                const float av = ok ? t.Xc[static_cast<int64_t>(ar) * t.Kc + k] : 0.0f;
+            // Operands are read from LDS four k-steps at a time, one batch ahead of the MFMAs that use them (a
+            // read-wait-MFMA sequence per step would expose one LDS latency per 64 MFMA cycles); k beyond K reads row
+            // K - 1 and contributes a zero A operand -- no branch in the loop.  (Pinning "reads of the next batch, then
+            // the MFMAs" with sched_group_barrier was measured and is slower: profiles/r03r_tile_phases.log.)
+            const int l31 = fresh(lane) & 31, half = fresh(lane) >> 5;
+            const float *arow_l = At + l31 * AS;            // the lane's A row (cell); rows past the chunk hold zeros
+            auto forward = [&](const float *arow, const float *btile, int bstride, int K) {
+                if (K <= 0) return;
+                const float *bl = btile + (CB * w) * 32 + l31;
+                auto fetch = [&](int k0, float (&av)[4], float (&bv)[4][CB]) {   // MFMA step j contracts k0 + 2 j + {0, 1}
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const float bv = k < t.Kc ? wl[k * kGenesPerBlock + (CB * w + c) * 32 + l31] : 0.0f;
-                    D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
-                }
-            }
-            if constexpr (NJT > 0) {
-                for (int kk = 0; kk < kg2; ++kk) {
-                    const int k = 2 * kk + half;
-                    const bool ok = arow_ok && k < t.kgp;
-                    const float av = ok ? t.Wg[static_cast<int64_t>(ar) * t.kgp + k] : 0.0f;
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = k0 + 2 * j + half, kc = min(k, K - 1);
+                        const float x = arow[kc];
+                        av[j] = k < K ? x : 0.0f;
 #pragma unroll
-                    for (int c = 0; c < CB; ++c) {
-                        const float bv = k < t.kgp ? xl[k * kXgStride + (CB * w + c) * 32 + l31] : 0.0f;
-                        D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D[c], 0, 0, 0);
+                        for (int c = 0; c < CB; ++c) bv[j][c] = bl[kc * bstride + c * 32];
+                    }
+                };
+                float av[4], bv[4][CB];
+                fetch(0, av, bv);
+#pragma unroll 1
+                for (int k0 = 0; k0 < K; k0 += 8) {
+                    float nav[4], nbv[4][CB];
+                    fetch(k0 + 8, nav, nbv);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int c = 0; c < CB; ++c) D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j][c], D[c], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        av[j] = nav[j];
+#pragma unroll
+                        for (int c = 0; c < CB; ++c) bv[j][c] = nbv[j][c];
                     }
                 }
-            }
+            };
+            forward(arow_l, wl, kGenesPerBlock, t.Kc);
+            if constexpr (NJT > 0) forward(arow_l + t.Kc, xl, kXgStride, t.kgp);
 #pragma unroll
             for (int c = 0; c < CB; ++c)
 #pragma unroll
@@ -293,10 +384,13 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
                     T[i * kTileStride + (CB * w + c) * 32 + l31] = D[c][q];
                 }
         }
+        BRIE_PROF_MARK(0);
         tile_sync<NH>(ctr, arrived);
+        BRIE_PROF_MARK(1);
 
         // ---- B: stream the wave's rows of this tile (software-pipelined: next row's loads under this row's math)
         {
+            load_gene_params();
             const int t_end = min(tr0 + kTileRows, row_end);
             int r = tr0 + w;
             while (r < t_end) {
@@ -310,36 +404,66 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
                 r = rn;
             }
         }
+        BRIE_PROF_MARK(2);
         tile_sync<NH>(ctr, arrived);
+        BRIE_PROF_MARK(3);
 
         // ---- C: backward contractions of the residual tile
         if constexpr (NACC > 0) {           // G[feature][gene] += sum_cells X[cell][feature] T[cell][gene]
-            for (int kk = 0; kk < kTileRows / 2; ++kk) {
-                const int rr_ = tr0 + 2 * kk + half;
-                const bool ok = rr_ < row_end;
-                float av[NACC];
+            const int l31 = fresh(lane) & 31, half = fresh(lane) >> 5;
+            const float *tl = T + (CB * w) * 32 + l31;
+            const int n_ok = min(kTileRows, row_end - tr0);      // rows of the tile inside the chunk (At is zero beyond)
+            auto fetch = [&](int k0, float (&av)[4][NACC], float (&bv)[4][CB]) {     // four MFMA steps (cell pairs)
 #pragma unroll
-                for (int n = 0; n < NACC; ++n) {
-                    const int f = l31 + 32 * n;
-                    av[n] = (ok && f < t.Kc) ? t.Xc[static_cast<int64_t>(rr_) * t.Kc + f] : 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const int ti = (k0 + 2 * j + half) & (kTileRows - 1);
+#pragma unroll
+                    for (int n = 0; n < NACC; ++n) {
+                        const int f = l31 + 32 * n;
+                        const float x = At[ti * AS + min(f, t.Kc - 1)];
+                        av[j][n] = f < t.Kc ? x : 0.0f;
+                    }
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) {
+                        const float y = tl[ti * kTileStride + c * 32];
+                        bv[j][c] = ti < n_ok ? y : 0.0f;        // (T rows past the chunk hold the forward product, not a residual)
+                    }
                 }
+            };
+            float av[4][NACC], bv[4][CB];
+            fetch(0, av, bv);
+#pragma unroll 1
+            for (int k0 = 0; k0 < kTileRows; k0 += 8) {
+                float nav[4][NACC], nbv[4][CB];
+                fetch(k0 + 8, nav, nbv);                        // (the last batch reads batch 0 again and drops it)
 #pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const float bv = ok ? T[(2 * kk + half) * kTileStride + (CB * w + c) * 32 + l31] : 0.0f;
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int n = 0; n < NACC; ++n) G[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[n], bv, G[n][c], 0, 0, 0);
+                    for (int c = 0; c < CB; ++c)
+#pragma unroll
+                        for (int n = 0; n < NACC; ++n)
+                            G[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][n], bv[j][c], G[n][c], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int n = 0; n < NACC; ++n) av[j][n] = nav[j][n];
+#pragma unroll
+                    for (int c = 0; c < CB; ++c) bv[j][c] = nbv[j][c];
                 }
             }
         }
+        BRIE_PROF_MARK(4);
         if constexpr (NJT > 0) {
             // P[cell][feature] = sum_genes T[cell][gene] Xg[gene][feature] (the Wg_loc gradient of the tile's 32 cells over
             // this gene block).  v_mfma_f32_16x16x4_f32: the 32 x kgp output is cut into 16 x 16 blocks, wave w owns cell
             // half (w & 1) and feature blocks (w >> 1) + 2 n -- every wave contracts over all 256 genes itself, so there
             // is no cross-wave fold and the result goes straight to the per-cell statistics in HBM.
+            // Lane (l15, kq) contracts genes 16 G + 4 kq + j in MFMA step j of gene group G, so its A operands of four
+            // steps are ONE ds_read_b128 of the residual row and its B operands one ds_read_b128 of the Xg row.
             typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const int l15 = lane & 15, kq = lane >> 4;
+            const int l15 = fresh(lane) & 15, kq = fresh(lane) >> 4;
             const int ch = w & 1;
-            const float *arow = T + (ch * 16 + l15) * kTileStride + kq;          // A[i = cell][k = gene]
+            const float *arow = T + (ch * 16 + l15) * kTileStride + 4 * kq;      // A[i = cell][k = gene]
             f32x4 P[NJT][2];
             const float *bcol[NJT];
             bool fok[NJT];
@@ -347,19 +471,39 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             for (int n = 0; n < NJT; ++n) {
                 const int f = ((w >> 1) + 2 * n) * 16 + l15;
                 fok[n] = f < t.kgp;
-                bcol[n] = xl + (fok[n] ? f : 0) * kXgStride + kq;                // B[k = gene][j = feature]
+                bcol[n] = xl + (fok[n] ? f : 0) * kXgStride + 4 * kq;            // B[k = gene][j = feature]
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) P[n][u][q] = 0.0f;
             }
-            for (int g = 0; g < kGenesPerBlock; g += 8) {        // two independent accumulator chains hide the MFMA latency
-                const float a0 = arow[g], a1 = arow[g + 4];
+            // (a feature block past kgp reads feature 0: its columns of P are garbage of its own and are not stored)
+            auto fetch = [&](int g, F4 (&av)[2], F4 (&bv)[2][NJT]) {             // two gene groups per batch of LDS reads
 #pragma unroll
-                for (int n = 0; n < NJT; ++n) {
-                    const float b0 = fok[n] ? bcol[n][g] : 0.0f, b1 = fok[n] ? bcol[n][g + 4] : 0.0f;
-                    P[n][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, P[n][0], 0, 0, 0);
-                    P[n][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, P[n][1], 0, 0, 0);
+                for (int u = 0; u < 2; ++u) {
+                    av[u] = ld4(arow + g + 16 * u);
+#pragma unroll
+                    for (int n = 0; n < NJT; ++n) bv[u][n] = ld4(bcol[n] + g + 16 * u);
+                }
+            };
+            F4 av[2], bv[2][NJT];
+            fetch(0, av, bv);
+#pragma unroll 1
+            for (int g = 0; g < kGenesPerBlock; g += 32) {
+                F4 nav[2], nbv[2][NJT];
+                fetch((g + 32) & (kGenesPerBlock - 1), nav, nbv);                // (the last batch reads batch 0 again and drops it)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int n = 0; n < NJT; ++n)            // two accumulator chains per block hide the MFMA latency
+                            P[n][j & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u].v[j], bv[u][n].v[j], P[n][j & 1], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    av[u] = nav[u];
+#pragma unroll
+                    for (int n = 0; n < NJT; ++n) bv[u][n] = nbv[u][n];
                 }
             }
             float *chunk = t.row_partials + static_cast<int64_t>(gb) * (t.kgp + 2) * a.Nc;
@@ -373,8 +517,17 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
                 }
             }
         }
-        tile_sync<NH>(ctr, arrived);                    // T is free for the next tile's forward product
+        if (tr0 + kTileRows < row_end) fetch_design(tr0 + kTileRows);    // lands while the half gathers at the barrier
+        BRIE_PROF_MARK(5);
+        tile_sync<NH>(ctr, arrived);                    // T and At are free for the next tile
     }
+#if BRIE_TILE_PROF
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(&tile_prof[w == 0 ? i : 8 + i], prof_[i]);
+        if (w == 0) atomicAdd(&tile_prof[7], static_cast<unsigned long long>((row_end - row0 + kTileRows - 1) / kTileRows));
+    }
+#endif
 
     // G accumulators -> this chunk's partial sums (summed over chunks in fp64 by wide_w_adam)
     if constexpr (NACC > 0) {

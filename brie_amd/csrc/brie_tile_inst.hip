@@ -55,3 +55,15 @@ void BRIE_CAT(launch_tile_mode, BRIE_TILE_MODE)(const LaunchCfg &c, const StepPo
 }
 
 }  // namespace brie
+
+#if BRIE_TILE_PROF && BRIE_TILE_MODE == 0
+// tuning builds only: cycles per phase summed over the waves 0 (slots 0..6, slot 7 = tiles) and the other waves (8..14)
+extern "C" int brie_debug_tile_prof(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(brie::tile_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(brie::tile_prof), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

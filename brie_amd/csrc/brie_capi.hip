@@ -339,12 +339,17 @@ int build_tier_tables(brie_handle *h) {
         base += static_cast<int64_t>(off) * h->p.Nc;
     }
     h->tier_layer_bytes = static_cast<size_t>(base);
+    // (each table is entered into the handle as soon as it exists, so a failure further down leaves nothing behind that
+    // free_tier_tables / brie_destroy would not release)
     uint8_t *d_esz = nullptr; int32_t *d_off = nullptr, *d_row = nullptr; int64_t *d_base = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_esz), nq));
+    h->tt.q_esz = d_esz;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_off), nq * sizeof(int32_t)));
+    h->tt.q_off = d_off;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_row), h->gene_blocks * sizeof(int32_t)));
+    h->tt.row_bytes = d_row;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_base), h->gene_blocks * sizeof(int64_t)));
-    h->tt = brie::TierTables{d_esz, d_off, d_row, d_base};
+    h->tt.blk_base = d_base;
     HIP_TRY(hipMemcpyAsync(d_esz, h->q_esz_host.data(), nq, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_off, q_off.data(), nq * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(d_row, row_bytes.data(), h->gene_blocks * sizeof(int32_t), hipMemcpyHostToDevice, h->stream));

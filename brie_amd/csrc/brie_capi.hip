@@ -1726,9 +1726,26 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     a.n4 = bytes_per_stream / 16;
     std::vector<void *> bufs;
     auto cleanup = [&]() { for (void *q : bufs) hipFree(q); };
+    const char *il = getenv("BRIE_CALIB_INTERLEAVE");          // "1": all streams interleaved in one buffer (StreamArgs)
+    const char *ct = getenv("BRIE_CALIB_CONTIGUOUS");          // "1": physically contiguous buffers
+    auto alloc = [&](void **q, size_t bytes) {
+        if (ct && ct[0] == '1') return hipExtMallocWithFlags(q, bytes, hipDeviceMallocContiguous);
+        return hipMalloc(q, bytes);
+    };
+    if (il && il[0] == '1') {
+        a.n4 = (a.n4 / 64) * 64;
+        void *q = nullptr;
+        const size_t bytes = static_cast<size_t>(n_read + n_write) * a.n4 * 16;
+        if (alloc(&q, bytes) != hipSuccess) return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer");
+        hipMemset(q, 0, bytes);
+        bufs.push_back(q);
+        for (int i = 0; i < n_read; ++i) a.in[i] = static_cast<const float *>(q);
+        for (int i = 0; i < n_write; ++i) a.out[i] = static_cast<float *>(q);
+        a.ns_interleave = n_read + n_write;
+    } else
     for (int i = 0; i < n_read + n_write; ++i) {
         void *q = nullptr;
-        if (hipMalloc(&q, a.n4 * 16) != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer"); }
+        if (alloc(&q, a.n4 * 16) != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer"); }
         hipMemset(q, 0, a.n4 * 16);
         bufs.push_back(q);
         if (i < n_read) a.in[i] = static_cast<const float *>(q); else a.out[i - n_read] = static_cast<float *>(q);

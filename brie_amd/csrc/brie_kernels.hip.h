@@ -1940,7 +1940,13 @@ struct StreamArgs {
     const float *in[12];
     float *out[12];
     int64_t n4;          // float4 elements per stream
+    // > 0: all streams live in ONE buffer, interleaved in 1-KiB pieces (piece p of stream s at ((p * ns + s) * 64) float4) --
+    // the layout question of DESIGN 4.3a: are 14 separate arrays slower than one array of 14-KiB rows?
+    int32_t ns_interleave;
 };
+__device__ __forceinline__ int64_t sm_at(const StreamArgs &a, int s, int64_t i) {
+    return a.ns_interleave ? ((((i >> 6) * a.ns_interleave + s) << 6) | (i & 63)) : i;
+}
 template <int NR, int NW, bool NT, int U = 1>
 __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
     // U independent 16-B vectors per thread and iteration, all NR*U loads issued before the first store
@@ -1959,7 +1965,7 @@ __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
                     const int64_t i = i0 + u * kBlock;
                     if (i < end) {
 #pragma unroll
-                        for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * i) : ld4(a.in[r] + 4 * i);
+                        for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * sm_at(a, r, i)) : ld4(a.in[r] + 4 * sm_at(a, r, i));
                     }
                 }
 #pragma unroll
@@ -1973,8 +1979,8 @@ __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
                             for (int v = 0; v < kVec; ++v) acc.v[v] += t[u][r].v[v];
 #pragma unroll
                         for (int w = 0; w < NW; ++w) {
-                            if (NT) st4s(a.out[w] + 4 * i, acc);
-                            else st4(a.out[w] + 4 * i, acc);
+                            if (NT) st4s(a.out[w] + 4 * sm_at(a, NR + w, i), acc);
+                            else st4(a.out[w] + 4 * sm_at(a, NR + w, i), acc);
                         }
                     }
                 }
@@ -1990,7 +1996,7 @@ __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
             const int64_t i = i0 + u * stride;
             if (i < a.n4) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * i) : ld4(a.in[r] + 4 * i);
+                for (int r = 0; r < NR; ++r) t[u][r] = NT ? ld4s(a.in[r] + 4 * sm_at(a, r, i)) : ld4(a.in[r] + 4 * sm_at(a, r, i));
             }
         }
 #pragma unroll
@@ -2004,8 +2010,8 @@ __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
                     for (int v = 0; v < kVec; ++v) acc.v[v] += t[u][r].v[v];
 #pragma unroll
                 for (int w = 0; w < NW; ++w) {
-                    if (NT) st4s(a.out[w] + 4 * i, acc);
-                    else st4(a.out[w] + 4 * i, acc);
+                    if (NT) st4s(a.out[w] + 4 * sm_at(a, NR + w, i), acc);
+                    else st4(a.out[w] + 4 * sm_at(a, NR + w, i), acc);
                 }
             }
         }

@@ -10,15 +10,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def smi():
     try:
-        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True,
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp", "--showperflevel", "--json"], capture_output=True, text=True,
                              timeout=10).stdout
         d = json.loads(out)
         c = d[sorted(d)[0]]
         keep = {}
         for k, v in c.items():
             kl = k.lower()
-            if "sclk" in kl or "mclk" in kl or "fclk" in kl or "power" in kl or "junction" in kl or "hbm" in kl or "socclk" in kl:
-                keep[k] = v
+            if "level" in kl:
+                continue
+            for tag in ("sclk", "mclk", "fclk", "socclk", "power", "junction", "memory) (c"):
+                if tag in kl:
+                    keep[tag.replace(") (c", "_temp")] = str(v).strip("()")
         return keep
     except Exception as e:          # noqa
         return {"smi_error": str(e)[:80]}
@@ -45,7 +48,10 @@ def main():
     def t(sh, n=8):
         t0 = time.perf_counter(); sh.step(n, 0.005, 1, trace=False); sh.synchronize()
         return round((time.perf_counter() - t0) / n * 1e3, 3)
-    narrow, tile, f32 = make(3), make(9), make(3, "f32")
+    if os.environ.get("WATCH_ORDER") == "f32_first":       # does the order of creation (= where the arrays land) matter?
+        f32 = make(3, "f32"); tile = make(9); narrow = make(3)
+    else:
+        narrow, tile, f32 = make(3), make(9), make(3, "f32")
     print(json.dumps({"storage": [narrow.count_storage, tile.count_storage, f32.count_storage]}), flush=True)
     t_end = time.time() + float(os.environ.get("WATCH_SECONDS", "70"))
     i = 0

@@ -24,8 +24,20 @@ def main():
             row.append(round(3 * 2 * b.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9))
         rates.append(row)
         print(json.dumps({"sweep": sweep, "GBs": row}), flush=True)
+    # three streams at once (two reads, one write) over neighbouring buffers: does a REGION stream slower?
+    for sweep in range(2):
+        row = []
+        for i in range(n - 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                torch.add(bufs[i], bufs[i + 1], out=bufs[i + 2])
+            e1.record()
+            torch.cuda.synchronize()
+            row.append(round(3 * 3 * bufs[i].numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9))
+        print(json.dumps({"three_stream_sweep": sweep, "GBs": row}), flush=True)
     import numpy as np
-    r = np.array(rates, float)
+    r = np.array(rates[1:], float)
     print(json.dumps({"per_buffer_mean_min": float(r.mean(0).min()), "per_buffer_mean_max": float(r.mean(0).max()),
                       "spread_between_buffers_pct": float((r.mean(0).max() / r.mean(0).min() - 1) * 100),
                       "mean_spread_within_buffer_pct": float(((r.max(0) / r.min(0)) - 1).mean() * 100),

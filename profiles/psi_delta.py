@@ -112,10 +112,12 @@ def summary(a, b, covered):
     return out
 
 
-def build_variants():
+def build_variants(names=None):
     from brie_amd.build import compile_library, LIB_DIR
     paths = {}
     for name, defs in VARIANTS.items():
+        if names is not None and name not in names:
+            continue
         if not defs:
             paths[name] = compile_library()
             continue
@@ -141,7 +143,7 @@ def main():
     if args.worker:
         run_hip_worker(args.worker, args.worker_out)
         return
-    libs = build_variants()
+    libs = build_variants([v for v in args.variants.split(",") if v])
     if args.build_only:
         print(libs)
         return

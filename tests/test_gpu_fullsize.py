@@ -177,6 +177,56 @@ def test_full_size_config3(lib):
     part.close()
 
 
+def test_full_size_config3_wide_design_on_the_tile_kernel(lib):
+    """configs[2] shape with 48 cell features: the MFMA tile kernel at full size (two 4-wave halves per workgroup, 196
+    cell chunks of 8 tiles, ragged last tile).  Genes stay independent (no gene features), so scattered gene quads are
+    checked against the oracle over all 50k cells, and a 2500-gene shard must repeat the full fit bit for bit."""
+    import torch
+    import bench
+    from brie_amd import _capi
+    from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
+    dev = torch.device("cuda", 0)
+    cfg = dict(bench.CONFIGS["c3"], Kc=48)
+    Nc, Ng, Kc = cfg["Nc"], cfg["Ng"], cfg["Kc"]
+    seed = 515151
+    Xc, layers = _generate(torch, dev, cfg, seed)
+    Xc = Xc * 0.3                                       # 48 N(0,1) features: keep the prior mean inside the clip range
+    sh = _capi.Shard(Nc, Ng, Kc, n_layers=2, seed=seed)
+    for l in range(2):
+        sh.upload(_capi.COUNT1 + l, layers[l])
+    sh.add_pseudo_count(0.01)
+    sh.upload(_capi.XC, Xc)
+    sh.init_state()
+    trace = sh.step(STEPS, 0.01, 1)
+    assert np.all(np.isfinite(trace)) and trace[-1] < trace[0]
+    zloc, zsl = sh.read(_capi.Z_LOC), sh.read(_capi.Z_STD_LOG)
+    W, b, lam = sh.read(_capi.WC_LOC), sh.read(_capi.INTERCEPT), sh.read(_capi.SIGMA_LOG)
+    Xc_h = Xc.cpu().numpy()
+    for g0 in (0, 9904, 19996):
+        cols = slice(g0, g0 + 4)
+        cnt = add_pseudo_count([layers[l][:, cols].cpu().numpy() for l in range(2)])
+        o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
+        tr = o.minimize(cnt, Xc_h, STEPS, 0.01, 1)
+        for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
+                                   ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
+                                   ("sigma_log", lam[:, cols], o.sigma_log)):
+            d = np.abs(dev_arr - ref)
+            assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (g0, name, float(d.max()))
+    s0, s1 = 7500, 10000
+    part = _capi.Shard(Nc, s1 - s0, Kc, n_layers=2, seed=seed, gene_offset=s0)
+    for l in range(2):
+        part.upload(_capi.COUNT1 + l, layers[l][:, s0:s1])
+    part.add_pseudo_count(0.01)
+    part.upload(_capi.XC, Xc)
+    part.init_state()
+    part.step(STEPS, 0.01, 1)
+    np.testing.assert_array_equal(part.read(_capi.Z_LOC), zloc[:, s0:s1])
+    np.testing.assert_array_equal(part.read(_capi.WC_LOC), W[:, s0:s1])
+    np.testing.assert_array_equal(part.read(_capi.SIGMA_LOG), lam[:, s0:s1])
+    sh.close()
+    part.close()
+
+
 def test_max_size_config5_single_gpu(lib):
     """BASELINE configs[4] whole on ONE GPU (100k cells x 30k genes, Kc=5: 3e9 elements, 97 GB of
     state) -- the largest shape: exercises 64-bit offsets; the last gene quad is checked against the

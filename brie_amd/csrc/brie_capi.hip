@@ -1569,7 +1569,6 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&h->io_event, hipEventDisableTiming));
     }
-    float *outs[4] = {psi, z_std, psi95ci, z_loc};
     // slabs of ~64 M elements per output: the export kernel of a slab (microseconds to milliseconds) and its copies
     // are enqueued in order on the i/o stream, the copy engine streams while the main stream keeps computing
     const char *se = getenv("BRIE_IO_SLAB_ELEMS");

@@ -935,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
     sh[threadIdx.x] = t;
     __syncthreads();
     for (int st = kBlock / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        if (static_cast<int>(threadIdx.x) < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) a.loss_parts[2 * blockIdx.x + (s - a.Kc - 2)] = sh[0];

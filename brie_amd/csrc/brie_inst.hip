@@ -22,15 +22,22 @@ template <typename Kern>
 int occupancy_pad(Kern kern) {
     hipFuncAttributes at;
     if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kern)) != hipSuccess) return 0;
-    const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP");       // "0": leave the occupancy to the hardware (A/B runs)
-    if (e && e[0] == '0') return 0;
     return at.numRegs <= 168 ? 54 * 1024 : 0;
+}
+// BRIE_STEP_OCCUPANCY_CAP=0 leaves the occupancy to the hardware (A/B runs); read at every launch only when
+// BRIE_STEP_OCCUPANCY_CAP_DYNAMIC is set (profiles/occ_ab.py toggles it on one handle), else once
+inline bool occupancy_cap_on() {
+    static const bool dynamic = getenv("BRIE_STEP_OCCUPANCY_CAP_DYNAMIC") != nullptr;
+    auto on = []() { const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP"); return !(e && e[0] == '0'); };
+    static const bool fixed = on();
+    return dynamic ? on() : fixed;
 }
 
 template <int MODE, int MC, int CS, bool CPL>
 void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>;
-    static const int pad = occupancy_pad(kern);
+    static const int pad_regs = occupancy_pad(kern);
+    const int pad = occupancy_cap_on() ? pad_regs : 0;
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
                        q.partials, a, cp, static_cast<float *>(nullptr));

@@ -1,5 +1,6 @@
 // brie_inst.hip -- instantiates elbo_adam_step / loss_gene_eval for ONE cell-feature count
 // (-DBRIE_KC=N) over likelihood mode x MC_size {1, 3, run-time} x count storage {fp32, u8, u16}.
+#include <algorithm>
 #include <cstdlib>
 #include "brie_launch.h"
 
@@ -13,31 +14,43 @@ namespace brie {
 
 namespace {
 
-// Two workgroups per CU stream best (2 waves per SIMD).  An instantiation that needs <= 168 VGPRs -- u8 counts with few
-// cell features: 166 -- would be scheduled three deep and then runs 1.6 % slower on a fast box (8.26 vs 8.13 ms at the C3
-// shape, profiles/r03m_occ_ab.log).  Capping it through the register allocator (amdgpu_waves_per_eu) changes the code of
-// every instantiation (MC_size 3 with effLen: 13 % slower, profiles/r03n_ab_max_waves.log), so such a kernel is simply
-// launched with 54 KB of unused dynamic LDS: three workgroups no longer fit the CU's 160 KB.
+// ONE workgroup per CU (4 waves) streams best: the step kernel keeps a whole row of every array in flight per wave, and
+// more waves only add concurrent streams to a memory system that is already saturated.  Same handle, occupancy toggled
+// every ten steps at the C3 shape (profiles/occ_pad_sweep.py): 3 per CU (what 166 VGPRs allow) 8.26 ms, 2 per CU 8.17 -
+// 8.21 ms, 1 per CU 8.07 - 8.11 ms on a fast box; 9.37 -> 9.12 ms on a box in its slow mode (r04j / r04k logs).  Capping
+// through the register allocator (amdgpu_waves_per_eu) re-schedules every instantiation (MC_size 3 with effLen: 13 %
+// slower, profiles/r03n_ab_max_waves.log), so the launch simply carries enough unused dynamic LDS that a second
+// workgroup no longer fits the CU's 160 KB.  BRIE_STEP_OCCUPANCY_CAP=0: hardware occupancy, =2: two per CU (A/B runs;
+// read once, or at every launch when BRIE_STEP_OCCUPANCY_CAP_DYNAMIC is set).
+struct OccupancyPads { int one = 0, two = 0; };
 template <typename Kern>
-int occupancy_pad(Kern kern) {
+OccupancyPads occupancy_pads(Kern kern) {
+    OccupancyPads p;
     hipFuncAttributes at;
-    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kern)) != hipSuccess) return 0;
-    return at.numRegs <= 168 ? 54 * 1024 : 0;
+    if (hipFuncGetAttributes(&at, reinterpret_cast<const void *>(kern)) != hipSuccess) return p;
+    const int stat = static_cast<int>(at.sharedSizeBytes);
+    p.one = std::max(0, 81 * 1024 - stat);               // 2 x (static + pad) > 160 KB
+    p.two = std::max(0, 54 * 1024 - stat);               // 3 x (static + pad) > 160 KB
+    if (p.one > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, p.one) != hipSuccess) {
+        (void)hipGetLastError();
+        p.one = std::min(p.one, 64 * 1024);              // still at most two per CU
+    }
+    return p;
 }
-// BRIE_STEP_OCCUPANCY_CAP=0 leaves the occupancy to the hardware (A/B runs); read at every launch only when
-// BRIE_STEP_OCCUPANCY_CAP_DYNAMIC is set (profiles/occ_ab.py toggles it on one handle), else once
-inline bool occupancy_cap_on() {
+inline int occupancy_cap() {
     static const bool dynamic = getenv("BRIE_STEP_OCCUPANCY_CAP_DYNAMIC") != nullptr;
-    auto on = []() { const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP"); return !(e && e[0] == '0'); };
-    static const bool fixed = on();
-    return dynamic ? on() : fixed;
+    auto read = []() { const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP"); return e ? atoi(e) : 1; };
+    static const int fixed = read();
+    return dynamic ? read() : fixed;
 }
 
 template <int MODE, int MC, int CS, bool CPL>
 void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>;
-    static const int pad_regs = occupancy_pad(kern);
-    const int pad = occupancy_cap_on() ? pad_regs : 0;
+    static const OccupancyPads pads = occupancy_pads(kern);
+    const int cap = occupancy_cap();
+    const int pad = cap == 1 ? pads.one : (cap == 2 ? pads.two : 0);
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
                        q.partials, a, cp, static_cast<float *>(nullptr));

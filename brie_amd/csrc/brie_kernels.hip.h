@@ -797,7 +797,31 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         float xc[KCX];
         RowScalars rsc{};
         load_row(r, cur, xc, rsc);
-#if BRIE_PREFETCH
+#if BRIE_PREFETCH == 2
+        // Two rows ahead: the loads of row r + 8 are issued before the body of row r (tuning build; meant for one
+        // workgroup per CU, where the register file has room for three rows per wave).  Branch-free body as below; a
+        // row index past the wave's last row re-reads that last row (an L2 hit) and is dropped.
+        {
+            RowRegs<CS> n1;
+            float x1[KCX];
+            RowScalars rs1{};
+            load_row(min(r + kWavesPerBlock, r_last), n1, x1, rs1);
+            while (r + kWavesPerBlock < r_last) {            // at least two rows after r
+                RowRegs<CS> n2;
+                float x2[KCX];
+                RowScalars rs2{};
+                load_row(min(r + 2 * kWavesPerBlock, r_last), n2, x2, rs2);
+                process_row(r, cur, xc, rsc);
+                cur = n1; rsc = rs1;
+                n1 = n2; rs1 = rs2;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { xc[k] = x1[k]; x1[k] = x2[k]; }
+                r += kWavesPerBlock;
+            }
+            process_row(r, cur, xc, rsc);
+            if (r < r_last) process_row(r + kWavesPerBlock, n1, x1, rs1);
+        }
+#elif BRIE_PREFETCH
         // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
         // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
         // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body

@@ -1,6 +1,6 @@
-"""Narrow step kernel at the hardware's occupancy against 2 workgroups per CU (54 KB of unused dynamic LDS at launch for
-instantiations of <= 168 VGPRs; brie_inst.hip::occupancy_pad).  ONE handle per model, the cap toggled every ten steps
-(BRIE_STEP_OCCUPANCY_CAP_DYNAMIC): Kc = 3 on u8 counts (166 VGPRs: 3 waves / SIMD uncapped), Kc = 1 and Kc = 0 (<= 128: 4)."""
+"""Narrow step kernel at the hardware's occupancy against 2 and 1 workgroups per CU (unused dynamic LDS at launch,
+brie_inst.hip::occupancy_pads).  ONE handle per model, the cap toggled every ten steps (BRIE_STEP_OCCUPANCY_CAP_DYNAMIC):
+Kc = 3 on u8 counts (166 VGPRs: 3 waves / SIMD uncapped), Kc = 1 and Kc = 0 (<= 128: 4).  (r04i log: 2 per CU vs hardware.)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["BRIE_STEP_OCCUPANCY_CAP_DYNAMIC"] = "1"
@@ -21,10 +21,10 @@ def main():
         sh.init_state(); sh.step(2, 0.005, 1, trace=False); sh.synchronize()
         for rnd in range(5):
             row = {"Kc": Kc, "storage": sh.count_storage}
-            for cap in ("1", "0"):
+            for cap, name in (("1", "one_per_CU"), ("2", "two_per_CU"), ("0", "hardware_occupancy")):
                 os.environ["BRIE_STEP_OCCUPANCY_CAP"] = cap
                 t0 = time.perf_counter(); sh.step(10, 0.005, 1, trace=False); sh.synchronize()
-                row["capped_2_per_CU" if cap == "1" else "hardware_occupancy"] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+                row[name] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
             print(json.dumps(row), flush=True)
         sh.close()
 

@@ -20,7 +20,7 @@ namespace {
 // 8.21 ms, 1 per CU 8.07 - 8.11 ms on a fast box; 9.37 -> 9.12 ms on a box in its slow mode (r04j / r04k logs).  Capping
 // through the register allocator (amdgpu_waves_per_eu) re-schedules every instantiation (MC_size 3 with effLen: 13 %
 // slower, profiles/r03n_ab_max_waves.log), so the launch simply carries enough unused dynamic LDS that a second
-// workgroup no longer fits the CU's 160 KB.  BRIE_STEP_OCCUPANCY_CAP=0: hardware occupancy, =2: two per CU (A/B runs;
+// workgroup no longer fits the CU's 160 KB.  BRIE_STEP_OCCUPANCY_CAP=0: hardware occupancy, =1 / =2: one / two per CU (A/B runs;
 // read once, or at every launch when BRIE_STEP_OCCUPANCY_CAP_DYNAMIC is set).
 struct OccupancyPads { int one = 0, two = 0; };
 template <typename Kern>
@@ -40,7 +40,7 @@ OccupancyPads occupancy_pads(Kern kern) {
 }
 inline int occupancy_cap() {
     static const bool dynamic = getenv("BRIE_STEP_OCCUPANCY_CAP_DYNAMIC") != nullptr;
-    auto read = []() { const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP"); return e ? atoi(e) : 1; };
+    auto read = []() { const char *e = getenv("BRIE_STEP_OCCUPANCY_CAP"); return e ? atoi(e) : -1; };     // -1: automatic
     static const int fixed = read();
     return dynamic ? read() : fixed;
 }
@@ -49,7 +49,11 @@ template <int MODE, int MC, int CS, bool CPL>
 void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
     auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>;
     static const OccupancyPads pads = occupancy_pads(kern);
-    const int cap = occupancy_cap();
+    // automatic: one per CU for one Monte-Carlo sample per step; with more samples the row body keeps the SIMD's VALU
+    // busy most of the time and a second wave per SIMD is what hides the memory latency (MC_size 3: one per CU is 4 - 15 %
+    // SLOWER than two for Kc = 1, 3, 8; profiles/r04o_occ_matrix.log)
+    int cap = occupancy_cap();
+    if (cap < 0) cap = MC == 1 ? 1 : 2;
     const int pad = cap == 1 ? pads.one : (cap == 2 ? pads.two : 0);
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,

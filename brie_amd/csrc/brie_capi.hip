@@ -1378,7 +1378,10 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out) {
     if (rc != BRIE_OK) return rc;
     if (n_repeats < 1 || !out) return fail(BRIE_ERR_INVALID, "n_repeats=%d out=%p", n_repeats, (void *)out);
     if ((rc = set_device(h)) != BRIE_OK) return rc;
-    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
+    // This pass only READS the state, so it runs next to a pending asynchronous export (brie_read_results_async reads
+    // mu / rho, writes its own slabs) -- that overlap is the point of the export.  Only a packed gene order has to be
+    // undone first, and that moves the state: then the export is waited for (ensure_identity does).
+    if (h->packed && (rc = ensure_identity(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const bool u8 = h->cs != brie::kCountF32;
@@ -1566,7 +1569,14 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     if (ld < Ng) return fail(BRIE_ERR_INVALID, "ld=%lld < Ng=%lld", (long long)ld, (long long)Ng);
     if (!h->io_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
+        // highest priority: the short export kernels must get compute units as they free up, not after the 500-draw
+        // loss_gene kernel on the main stream has dispatched its last workgroup (which serialised the two: 0.46 s of
+        // loss_gene + 0.33 s of exports and copies instead of max of the two)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const char *pe = getenv("BRIE_IO_STREAM_PRIORITY");         // "0": default priority (A/B runs)
+        if (pe && pe[0] == '0') HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
+        else HIP_TRY(hipStreamCreateWithPriority(&h->io_stream, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&h->io_event, hipEventDisableTiming));
     }
     // slabs of ~64 M elements per output: the export kernel of a slab (microseconds to milliseconds) and its copies

@@ -107,6 +107,7 @@ struct brie_handle {
     // from Gpart by wide_w_adam and loss_gene takes Xc.Wc_loc from Mbuf -- true for `wide` and for every tile handle.
     bool tile = false, wide_like = false;
     int tile_lds = 0, tile_nacc = 0, tile_njt = 0, tile_nw = 1;     // tile_nw: 4-wave halves per workgroup (1 or 2)
+    int tile_kcr = 0;               // 4: gene-feature model with <= 4 cell features, kept in registers (brie_tile.hip.h)
     size_t gpart_elems = 0, rbuf_elems = 0;
     float *win_scratch = nullptr;   // brie_read_loss_window staging
     size_t win_elems = 0;
@@ -195,11 +196,15 @@ void setup_paths(brie_handle *h) {
     const char *wp = getenv("BRIE_WIDE_PATH");         // "lds": the round-1 LDS-broadcast variants (A/B runs)
     const bool want_tile = !(wp && strcmp(wp, "lds") == 0);
     const int kgp = h->coupled ? h->kgp : 0;
+    // gene features next to <= 4 cell features: those stay in registers, nothing of the cell design goes through LDS / MFMA
+    const char *kre = getenv("BRIE_TILE_KC_REGS");      // "0": the MFMA path for them too (A/B runs)
+    const bool kcr = kgp > 0 && Kc > 0 && Kc <= 4 && !(kre && kre[0] == '0');
+    const int kcm = kcr ? 0 : Kc;
     // LDS of one workgroup: the read-only Wc_loc / Xg tiles of the gene block + one T tile per 4-wave half.  Two plain
     // workgroups per CU while that is under 80 KB; else ONE workgroup of two independent halves sharing the tiles.
-    const int tiles = static_cast<int>(sizeof(float)) * (Kc * brie::kGenesPerBlock + kgp * brie::kXgStride);
+    const int tiles = static_cast<int>(sizeof(float)) * (kcm * brie::kGenesPerBlock + kgp * brie::kXgStride);
     // per half: the T tile and the design rows [Xc | Wg_loc] of the tile's 32 cells
-    const int ttile = static_cast<int>(sizeof(float)) * brie::kTileRows * (brie::kTileStride + brie::tile_a_stride(Kc + kgp));
+    const int ttile = static_cast<int>(sizeof(float)) * brie::kTileRows * (brie::kTileStride + brie::tile_a_stride(kcm + kgp));
     const char *nhe = getenv("BRIE_TILE_HALVES");      // 1 / 2: force (A/B runs)
     h->tile_nw = nhe ? (atoi(nhe) == 2 ? 2 : 1) : (tiles + ttile <= 80 * 1024 ? 1 : 2);
     h->tile_lds = tiles + h->tile_nw * ttile;
@@ -209,7 +214,8 @@ void setup_paths(brie_handle *h) {
     const int min_kg = mk ? atoi(mk) : 8;
     h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
-    h->tile_nacc = Kc == 0 ? 0 : (Kc <= 32 ? 1 : 2);
+    h->tile_kcr = kcr ? 4 : 0;
+    h->tile_nacc = kcm == 0 ? 0 : (Kc <= 32 ? 1 : 2);
     h->tile_njt = !h->coupled ? 0 : (kgp <= 32 ? 1 : 2);
     h->kernel_kc = h->wide_like ? 0 : Kc;
     h->S = h->kernel_kc + 4;
@@ -279,9 +285,9 @@ void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::Ste
 void launch_tile(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q, const brie::StepScalars &a,
                  const brie::TileArgs &t) {
     switch (h->mode) {
-        case brie::kLik2: brie::launch_tile_mode0(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_lds); break;
-        case brie::kLikEff2: brie::launch_tile_mode1(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_lds); break;
-        default: brie::launch_tile_mode2(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_lds); break;
+        case brie::kLik2: brie::launch_tile_mode0(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_kcr, h->tile_lds); break;
+        case brie::kLikEff2: brie::launch_tile_mode1(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_kcr, h->tile_lds); break;
+        default: brie::launch_tile_mode2(c, q, a, t, h->tile_nacc, h->tile_njt, h->tile_nw, h->tile_kcr, h->tile_lds); break;
     }
 }
 void launch_margin(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,

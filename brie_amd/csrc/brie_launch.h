@@ -36,11 +36,11 @@ BRIE_DECLARE_KC(5) BRIE_DECLARE_KC(6) BRIE_DECLARE_KC(7) BRIE_DECLARE_KC(8)
 // wide designs on the matrix cores (brie_tile.hip.h), one translation unit per likelihood mode
 struct TileArgs;
 void launch_tile_mode0(const LaunchCfg &, const StepPointers &, const StepScalars &, const TileArgs &, int nacc, int njt, int nw,
-                       int lds);
+                       int kcr, int lds);
 void launch_tile_mode1(const LaunchCfg &, const StepPointers &, const StepScalars &, const TileArgs &, int nacc, int njt, int nw,
-                       int lds);
+                       int kcr, int lds);
 void launch_tile_mode2(const LaunchCfg &, const StepPointers &, const StepScalars &, const TileArgs &, int nacc, int njt, int nw,
-                       int lds);
+                       int kcr, int lds);
 // wide cell designs: KC == 0 kernels with the W tile in LDS, writing the residual buffer (defined in the kc0 unit)
 void launch_step_wide(const LaunchCfg &, const StepPointers &, const StepScalars &, const CoupledArgs &);
 

@@ -76,7 +76,11 @@ __device__ __forceinline__ void tile_sync(int *ctr, int &arrived) {
     }
 }
 
-template <int MODE, int CS, int NACC, int NJT, int NH>
+// KCR  = 4: gene-feature models with at most 4 cell features (the usual kind: a few covariates next to Xg).  A 32-feature
+//        MFMA tile would contract 3 real rows of 32 -- 8 % of a tile's cycles in X^T.R alone (profiles/r03q_tile_phases.log)
+//        -- so the cell design is handled the way elbo_adam_step does it: weights and X^T.R accumulators in registers,
+//        the cell's design row through scalar loads, 2 x 4 FMAs per feature and row.  NACC must be 0.
+template <int MODE, int CS, int NACC, int NJT, int NH, int KCR = 0>
 __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 waves/SIMD: <= 256 registers, no spills
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
@@ -88,6 +92,9 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     constexpr int CB = 8 / NW;              // 32-gene column blocks per wave
     constexpr int NT = NH * kBlock;         // threads per workgroup
     constexpr bool CPL = NJT > 0;           // per-cell statistics are only produced with gene features / cell mode
+    constexpr bool REGK = KCR > 0;          // cell features in registers, none on the matrix cores
+    static_assert(!REGK || NACC == 0, "KCR > 0 replaces the MFMA path of the cell design");
+    constexpr int KR = REGK ? KCR : 1;
     // dynamic LDS: NH x [T tile 32 x 260][W tile Kc x 256][Xg tile kgp x 257] NH x [At 32 x (Kc + kgp | 1)]; the cross-wave folds reuse T
     extern __shared__ __align__(16) float lds[];
     __shared__ int bar_ctr[2];
@@ -98,10 +105,11 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     const int tid = threadIdx.x - hf * kBlock;      // thread within the half
     float *T = lds + hf * (kTileRows * kTileStride);
     float *wl = lds + NH * (kTileRows * kTileStride);
-    float *xl = wl + t.Kc * kGenesPerBlock;
+    const int kcm = REGK ? 0 : t.Kc;        // cell features that go through the matrix cores
+    float *xl = wl + kcm * kGenesPerBlock;
     // A-operand tile of the half: the design rows [Xc | Wg_loc] of the tile's 32 cells (odd row stride: conflict-free when
     // the 32 lanes of a half-wave walk cells)
-    const int KA = t.Kc + t.kgp, AS = tile_a_stride(KA);
+    const int KA = kcm + t.kgp, AS = tile_a_stride(KA);
     float *At = xl + t.kgp * kXgStride + hf * (kTileRows * AS);
     int *ctr = bar_ctr + hf;
     int arrived = 0;
@@ -117,7 +125,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     if (a.block_active[gb] == 0) return;
     const bool cell = CPL && t.cell_mode != 0;
 
-    for (int i = threadIdx.x; i < t.Kc * kGenesPerBlock; i += NT)
+    for (int i = threadIdx.x; i < kcm * kGenesPerBlock; i += NT)
         wl[i] = t.W[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
     if constexpr (NJT > 0) {
         for (int i = threadIdx.x; i < t.kgp * kGenesPerBlock; i += NT)
@@ -130,6 +138,11 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     for (int s = 0; s < S; ++s)
 #pragma unroll
         for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
+    float accW[KR][kVec];                   // REGK: sum over the chunk's cells of x_k * residual
+#pragma unroll
+    for (int k = 0; k < KR; ++k)
+#pragma unroll
+        for (int v = 0; v < kVec; ++v) accW[k][v] = 0.0f;
     f32x16 G[NACC > 0 ? NACC : 1][CB];
 #pragma unroll
     for (int n = 0; n < (NACC > 0 ? NACC : 1); ++n)
@@ -143,10 +156,20 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     // MFMA phases, whose operand double buffers need them; the laundered index keeps the loads inside the tile loop.
     float bj[kVec], lamj[kVec], isig2[kVec];
     float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+    float Wk[KR][kVec];
     auto load_gene_params = [&]() {
         int jj = j0;
         asm volatile("" : "+v"(jj));
         const F4 tb = ld4(bp + jj), tl = ld4(lamp + jj);
+        if constexpr (REGK) {
+#pragma unroll
+            for (int k = 0; k < KCR; ++k) {
+                F4 wk = {{0.f, 0.f, 0.f, 0.f}};
+                if (k < t.Kc) wk = ld4(t.W + static_cast<int64_t>(k) * a.ld + jj);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) Wk[k][v] = wk.v[v];
+            }
+        }
 #pragma unroll
         for (int v = 0; v < kVec; ++v) {
             bj[v] = tb.v[v];
@@ -189,6 +212,10 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
         R.vm = ld4s(vmu_p + off);
         R.mr = ld4s(mrho_p + off);
         R.vr = ld4s(vrho_p + off);
+        if constexpr (REGK) {               // the cell's design row (wave-uniform: scalar loads)
+#pragma unroll
+            for (int k = 0; k < KCR; ++k) R.mp.v[k] = k < t.Kc ? t.Xc[static_cast<int64_t>(r) * t.Kc + k] : 0.0f;
+        }
     };
 
     // one streamed row: prior mean from T[ti], residual back to T[ti]
@@ -220,7 +247,11 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
         float srow = 0.0f, lrow = 0.0f;                    // per-cell sums over the lane's real genes
 #pragma unroll
         for (int v = 0; v < kVec; ++v) {
-            const float m = mt.v[v] + (cell ? cbr : bj[v]);
+            float m = mt.v[v] + (cell ? cbr : bj[v]);
+            if constexpr (REGK) {
+#pragma unroll
+                for (int k = 0; k < KCR; ++k) m = fmaf(R.mp.v[k], Wk[k][v], m);
+            }
             const float is2 = cell ? row_isig2 : isig2[v];
             const float d = R.mu.v[v] - m;
             const float rr = d * is2;
@@ -246,6 +277,10 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             res.v[v] = real[v] ? rr : 0.0f;                // padding genes are not part of any contraction
             srow += real[v] ? rr : 0.0f;
             lrow += real[v] ? lamstat : 0.0f;
+            if constexpr (REGK) {
+#pragma unroll
+                for (int k = 0; k < KCR; ++k) accW[k][v] = fmaf(R.mp.v[k], rr, accW[k][v]);
+            }
             acc[0][v] += rr;
             acc[1][v] += lamstat;
             acc[2][v] += kl;
@@ -321,7 +356,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             int e = tid + kBlock * i;
             asm volatile("" : "+v"(e));
             const int row = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_kg);
-            if (e < kTileRows * t.kgp) At[row * AS + t.Kc + (e - row * t.kgp)] = pre_g[i];
+            if (e < kTileRows * t.kgp) At[row * AS + kcm + (e - row * t.kgp)] = pre_g[i];
         }
     };
     fetch_design(row0);
@@ -374,8 +409,8 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
                     }
                 }
             };
-            forward(arow_l, wl, kGenesPerBlock, t.Kc);
-            if constexpr (NJT > 0) forward(arow_l + t.Kc, xl, kXgStride, t.kgp);
+            forward(arow_l, wl, kGenesPerBlock, kcm);
+            if constexpr (NJT > 0) forward(arow_l + kcm, xl, kXgStride, t.kgp);
 #pragma unroll
             for (int c = 0; c < CB; ++c)
 #pragma unroll
@@ -545,11 +580,18 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     }
 
     // fold the 4 waves' per-gene partials through LDS (T is free), wave 0 writes the chunk row
+    constexpr int SF = S + (REGK ? KCR : 0);        // REGK: the X^T.R rows ride along
     if (w > 0) {
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
-            for (int v = 0; v < kVec; ++v) T[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
+            for (int v = 0; v < kVec; ++v) T[((w - 1) * SF + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
+        if constexpr (REGK) {
+#pragma unroll
+            for (int k = 0; k < KCR; ++k)
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) T[((w - 1) * SF + S + k) * kGenesPerBlock + v * kWave + lane] = accW[k][v];
+        }
     }
     tile_sync<NH>(ctr, arrived);
     if (w == 0 && active) {
@@ -561,10 +603,25 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             for (int v = 0; v < kVec; ++v) {
                 float tt = acc[s][v];
 #pragma unroll
-                for (int ww = 0; ww < NW - 1; ++ww) tt += T[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
+                for (int ww = 0; ww < NW - 1; ++ww) tt += T[(ww * SF + s) * kGenesPerBlock + v * kWave + lane];
                 o.v[v] = tt;
             }
             st4(dst + s * a.ld, o);
+        }
+        if constexpr (REGK) {               // same place and meaning as the MFMA path's G: this chunk's X^T.R rows
+#pragma unroll
+            for (int k = 0; k < KCR; ++k) {
+                if (k >= t.Kc) break;
+                F4 o;
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) {
+                    float tt = accW[k][v];
+#pragma unroll
+                    for (int ww = 0; ww < NW - 1; ++ww) tt += T[(ww * SF + S + k) * kGenesPerBlock + v * kWave + lane];
+                    o.v[v] = tt;
+                }
+                st4(t.Gpart + (static_cast<int64_t>(chunk_id) * t.Kc + k) * a.ld + j0, o);
+            }
         }
     }
 }

@@ -12,9 +12,9 @@
 namespace brie {
 namespace {
 
-template <int CS, int NACC, int NJT, int NH>
+template <int CS, int NACC, int NJT, int NH, int KCR = 0>
 void tile_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int lds_bytes) {
-    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT, NH>;
+    auto kern = elbo_adam_step_tile<BRIE_TILE_MODE, CS, NACC, NJT, NH, KCR>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     dim3 grid = c.grid;
     grid.y = (grid.y + NH - 1) / NH;           // every half of a workgroup owns one cell chunk
@@ -22,36 +22,43 @@ void tile_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a
                        q.m_rho, q.v_rho, q.b, q.lam, q.effL, q.partials, a, t);
 }
 
-template <int CS, int NACC, int NJT>
+template <int CS, int NACC, int NJT, int KCR = 0>
 void tile_nw(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nw, int lds) {
-    if (nw == 2) tile_launch<CS, NACC, NJT, 2>(c, q, a, t, lds);
-    else tile_launch<CS, NACC, NJT, 1>(c, q, a, t, lds);
+    if (nw == 2) tile_launch<CS, NACC, NJT, 2, KCR>(c, q, a, t, lds);
+    else tile_launch<CS, NACC, NJT, 1, KCR>(c, q, a, t, lds);
 }
 
 template <int CS, int NACC>
-void tile_njt(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int njt, int nw, int lds) {
+void tile_njt(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int njt, int nw, int kcr,
+              int lds) {
     if (njt == 0) {
         if constexpr (NACC > 0) tile_nw<CS, NACC, 0>(c, q, a, t, nw, lds);
+    } else if constexpr (NACC == 0) {       // gene features; <= 4 cell features in registers (kcr), else none
+        if (kcr) {
+            if (njt == 1) tile_nw<CS, 0, 1, 4>(c, q, a, t, nw, lds);
+            else tile_nw<CS, 0, 2, 4>(c, q, a, t, nw, lds);
+        } else if (njt == 1) tile_nw<CS, 0, 1>(c, q, a, t, nw, lds);
+        else tile_nw<CS, 0, 2>(c, q, a, t, nw, lds);
     } else if (njt == 1) tile_nw<CS, NACC, 1>(c, q, a, t, nw, lds);
     else tile_nw<CS, NACC, 2>(c, q, a, t, nw, lds);
 }
 
 template <int CS>
 void tile_nacc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const TileArgs &t, int nacc, int njt, int nw,
-               int lds) {
-    if (nacc == 0) tile_njt<CS, 0>(c, q, a, t, njt, nw, lds);
-    else if (nacc == 1) tile_njt<CS, 1>(c, q, a, t, njt, nw, lds);
-    else tile_njt<CS, 2>(c, q, a, t, njt, nw, lds);
+               int kcr, int lds) {
+    if (nacc == 0) tile_njt<CS, 0>(c, q, a, t, njt, nw, kcr, lds);
+    else if (nacc == 1) tile_njt<CS, 1>(c, q, a, t, njt, nw, 0, lds);
+    else tile_njt<CS, 2>(c, q, a, t, njt, nw, 0, lds);
 }
 
 }  // namespace
 
 void BRIE_CAT(launch_tile_mode, BRIE_TILE_MODE)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
-                                                const TileArgs &t, int nacc, int njt, int nw, int lds_bytes) {
-    if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, nw, lds_bytes);
-    else if (c.cs == kCountMixed) tile_nacc<kCountMixed>(c, q, a, t, nacc, njt, nw, lds_bytes);
-    else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, nw, lds_bytes);
-    else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, nw, lds_bytes);
+                                                const TileArgs &t, int nacc, int njt, int nw, int kcr, int lds_bytes) {
+    if (c.cs == kCountU8) tile_nacc<kCountU8>(c, q, a, t, nacc, njt, nw, kcr, lds_bytes);
+    else if (c.cs == kCountMixed) tile_nacc<kCountMixed>(c, q, a, t, nacc, njt, nw, kcr, lds_bytes);
+    else if (c.cs == kCountU16) tile_nacc<kCountU16>(c, q, a, t, nacc, njt, nw, kcr, lds_bytes);
+    else tile_nacc<kCountF32>(c, q, a, t, nacc, njt, nw, kcr, lds_bytes);
 }
 
 }  // namespace brie

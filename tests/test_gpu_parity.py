@@ -722,7 +722,7 @@ def test_randomised_operation_sequences(lib, i, Nc, Ng, Kc, L, sparse, f32, ops)
     # Worst element: these sequences put "reset" (fresh Adam) in front of 1-2 step blocks.  The first updates of a fresh Adam
     # are lr * g / (|g| + 1e-7); a zero-coverage element whose mu sits on its prior mean has |g| ~ 1e-8 and any rounding
     # difference decides most of a 0.01 step: sequence 3 leaves ONE such element 2e-3 apart (the fp32 and fp64 oracles
-    # differ by 2e-4 there, their largest difference; profiles/debug_seq3.py).  The bulk bound (99.9 % within 2e-5) stays.
+    # differ by 2e-4 there, their largest difference; tests/tools/debug_seq3.py).  The bulk bound (99.9 % within 2e-5) stays.
     WORST = 5e-3
     rng = np.random.default_rng(900 + i)
     P = util.problem(Nc, Ng, Kc, L, seed=300 + i)

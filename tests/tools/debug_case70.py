@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import util
 from tests import test_gpu_parity as T
 case = [c for c in T._random_cases(250, seed=424242) if c[0] == 70][0]

@@ -1,6 +1,6 @@
 """debug helper: cell-mode fits with very few genes, step-by-step deviation device vs fp32 / fp64 oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import util
 

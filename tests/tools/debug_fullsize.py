@@ -1,7 +1,7 @@
 """Debug helper: C3-size fit for a few steps, compare scattered gene quads with the oracle."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from brie_amd import _capi

@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import util
 from tests.test_gpu_parity import _op_sequences
 from brie_amd import _capi

@@ -1,8 +1,8 @@
 """Soak run of the two seeded random test families of tests/test_gpu_parity.py with OTHER seeds than the committed
-lists (the oracle is the checker, as in the tests):  python profiles/soak_randomised.py [n_shapes] [n_sequences] [seed]
+lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed]
 Prints every failing case with the assertion message; exit code = number of failures."""
 import os, sys, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import test_gpu_parity as T
 
 n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 200

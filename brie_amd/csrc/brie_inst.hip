@@ -31,11 +31,6 @@ OccupancyPads occupancy_pads(Kern kern) {
     const int stat = static_cast<int>(at.sharedSizeBytes);
     p.one = std::max(0, 81 * 1024 - stat);               // 2 x (static + pad) > 160 KB
     p.two = std::max(0, 54 * 1024 - stat);               // 3 x (static + pad) > 160 KB
-    if (p.one > 64 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, p.one) != hipSuccess) {
-        (void)hipGetLastError();
-        p.one = std::min(p.one, 64 * 1024);              // still at most two per CU
-    }
     return p;
 }
 inline int occupancy_cap() {
@@ -55,6 +50,8 @@ void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a
     int cap = occupancy_cap();
     if (cap < 0) cap = MC == 1 ? 1 : 2;
     const int pad = cap == 1 ? pads.one : (cap == 2 ? pads.two : 0);
+    if (pad > 64 * 1024)        // per launch, like the tile kernel: the attribute belongs to the current device
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
                        q.partials, a, cp, static_cast<float *>(nullptr));

@@ -277,18 +277,38 @@ def test_async_result_export_equals_the_plain_reads(lib, Ng, monkeypatch):
     P = util.problem(Nc, Ng, Kc, 2, seed=5)
     sh = util.device_shard(P, Nc, Ng, Kc, 3)
     sh.step(7, 0.01, 1)
+    twin = util.device_shard(P, Nc, Ng, Kc, 3)                         # the same fit without any asynchronous export
+    twin.step(7, 0.01, 1)
     monkeypatch.setenv("BRIE_IO_SLAB_ELEMS", str(Ng * 16))            # 16-row slabs: 5 slabs, the last one ragged
     want = {w: sh.read(w) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
     got = {w: np.full((Nc, Ng), np.nan, np.float32) for w in want}
     _capi.host_register(got[_capi.PSI])                                # one page-locked destination, three pageable
     sh.read_results_async(got[_capi.PSI], got[_capi.Z_STD], got[_capi.PSI95CI], got[_capi.Z_LOC])
-    lg = sh.loss_gene(3)
+    lg = sh.loss_gene(3)                                               # runs NEXT TO the export (it only reads the state)
+    np.testing.assert_array_equal(lg, twin.loss_gene(3))
     sh.step(2, 0.01, 1)                                                # must not run before the export has finished
     sh.read_wait()
     _capi.host_unregister(got[_capi.PSI])
     for w in want:
         np.testing.assert_array_equal(got[w], want[w])
     assert np.all(np.isfinite(lg)) and not np.array_equal(sh.read(_capi.PSI), want[_capi.PSI])
+    # a packed gene order (per-batch convergence) has to be undone before loss_gene: that moves the state, so the
+    # pending export is waited for first -- results as without it
+    twin.step(2, 0.01, 1)
+    mask = np.zeros(Ng, bool)
+    mask[: max(4, Ng // 8)] = True
+    for s_ in (sh, twin):
+        s_.set_gene_mask(mask)
+        s_.step(2, 0.01, 1)
+    want2 = {w: twin.read(w) for w in want}
+    sh.read_results_async(got[_capi.PSI], got[_capi.Z_STD], got[_capi.PSI95CI], got[_capi.Z_LOC])
+    np.testing.assert_array_equal(sh.loss_gene(2), twin.loss_gene(2))
+    sh.read_wait()
+    for w in want:
+        np.testing.assert_array_equal(got[w], want2[w])
+    for s_ in (sh, twin):
+        s_.set_gene_mask(None)
+    twin.close()
     only = np.empty((Nc, Ng), np.float32)
     sh.read_results_async(psi95ci=only)                                # any subset
     sh.read_wait()

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- ELBO iterations/s of the brie-quant hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one process per GPU under torch.distributed.run (RCCL).  Started WITHOUT a launcher (no WORLD_SIZE in the
+environment) the script starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself -- as a child
+process, before anything in this process has touched the GPU -- relays rank 0's JSON line and returns its exit code.
 
 A "step" is one fused ELBO-gradient + Adam pass over every (cell, gene) element
 of the workload (= one iteration of tfp.math.minimize in
@@ -74,6 +78,39 @@ def gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed):
     return [c_1, c_2, N - c_1 - c_2], eff
 
 
+def make_inputs(torch, dev, cfg, g0, g1, seed):
+    """Xc, per-cell size factors, the L count layers of genes [g0, g1) and their effLen rows, all on the device.
+    Seeded per GEN_CHUNK genes of the WHOLE problem, so a gene has the same data in every sharding."""
+    Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
+    ng = g1 - g0
+    gx = torch.Generator(device=dev)
+    gx.manual_seed(seed)
+    Xc = torch.zeros(Nc, Kc, device=dev)
+    if Kc:
+        Xc[:, 0] = (torch.rand(Nc, generator=gx, device=dev) < 0.5).float()
+        if Kc > 1:
+            Xc[:, 1:] = torch.randn(Nc, Kc - 1, generator=gx, device=dev)
+    size = torch.exp(0.5 * torch.randn(Nc, generator=gx, device=dev))
+    layers = [torch.empty(Nc, ng, device=dev) for _ in range(L)]
+    eff_all = torch.zeros(ng, 6, device=dev) if L == 3 else None
+    c0 = (g0 // GEN_CHUNK) * GEN_CHUNK
+    while c0 < g1:
+        c1 = min(c0 + GEN_CHUNK, Ng)
+        cnt, eff = gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
+        a, b = max(c0, g0), min(c1, g1)
+        for l in range(L):
+            layers[l][:, a - g0:b - g0] = cnt[l][:, a - c0:b - c0]
+        if eff is not None:
+            eff_all[a - g0:b - g0] = eff[a - c0:b - c0]
+        c0 = c1
+    torch.cuda.synchronize()
+    return Xc, size, layers, eff_all
+
+
+def config_seed(name):
+    return 20240617 + {"c1": 1, "c2": 2, "c3": 3, "c5": 5}[name]
+
+
 def psi_delta_check(seed=11):
     """'PSI delta vs CPU ref' on BASELINE configs[0] (200 x 500, +1 covariate) after the WHOLE BRIE2.fit default
     schedule (6 x 166 Adam steps, fresh optimiser per stage, model_TFProb.py:234-241): HIP vs the CPU restatement in
@@ -110,7 +147,8 @@ def hbm_traffic(args, world, storage):
     """roofline.traffic = HBM bytes per launch of the dominant kernel from the PMC counters, collected as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE
     (KiB), FETCH_SIZE x2 on gfx950 for wide coalesced reads.  Measured LIVE by two child runs of this script (the
-    same workload, a few steps); falls back to the committed profile of the same workload when rocprofv3 is not there."""
+    same workload, a few steps; with N > 1 ranks: rank 0's gene shard, on rank 0's GPU, while the other ranks wait);
+    falls back to the committed profile of the same workload when rocprofv3 is not there."""
     import csv
     import glob
     import shutil
@@ -122,11 +160,12 @@ def hbm_traffic(args, world, storage):
             "%s_%s" % (args.config, {"u8/u16 per gene quad": "mixed"}.get(storage, storage))) or {}
     except (OSError, ValueError):
         pass
-    eligible = world == 1 and args.mc == 1 and args.kc is None and not args.emulate_shard_of
+    shard_of = args.emulate_shard_of or (world if (world > 1 and args.scaling == "strong") else 0)
+    eligible = world == 1 and args.mc == 1 and args.kc is None and not shard_of
     fallback = {"traffic": committed.get("hbm_bytes_per_launch") if eligible else None,
                 "traffic_source": ("committed: " + committed.get("source", "profiles/pmc_traffic.json")) if (eligible and committed)
                 else None}
-    if args.no_pmc or world != 1 or not shutil.which("rocprofv3"):
+    if args.no_pmc or not shutil.which("rocprofv3"):
         return fallback
     n_steps, kib = 4, {}
     try:
@@ -140,7 +179,9 @@ def hbm_traffic(args, world, storage):
                 cmd += ["--kc", str(args.kc)]
             if args.rows_per_chunk:
                 cmd += ["--rows-per-chunk", str(args.rows_per_chunk)]
-            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+            if shard_of:
+                cmd += ["--emulate-shard-of", str(shard_of)]
+            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(standalone_env(), TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=600)
             total = 0.0
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -152,18 +193,25 @@ def hbm_traffic(args, world, storage):
                 raise RuntimeError("no %s samples of elbo_adam_step" % counter)
             kib[counter] = total / n_steps
         return {"traffic": (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0,
-                "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (%d launches each; "
-                                  "KiB; FETCH_SIZE x2 gfx950 correction)" % n_steps,
+                "traffic_source": "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command%s (%d launches each; "
+                                  "KiB; FETCH_SIZE x2 gfx950 correction)"
+                                  % (" on rank 0's shard (1 of %d)" % shard_of if shard_of else "", n_steps),
                 "FETCH_SIZE_KiB_per_launch": kib["FETCH_SIZE"], "WRITE_SIZE_KiB_per_launch": kib["WRITE_SIZE"]}
     except Exception as exc:
         return dict(fallback, traffic_error=repr(exc))
 
 
-def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank, dev, Xc, size, elapsed_local):
+def per_gene_vectors(sh, Kc, n_rep):
+    from brie_amd import _capi
+    return np.concatenate([sh.read(_capi.WC_LOC).reshape(Kc, -1), sh.read(_capi.INTERCEPT).reshape(1, -1),
+                           sh.read(_capi.SIGMA).reshape(1, -1), sh.loss_gene(n_rep).reshape(1, -1)], axis=0)
+
+
+def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank, dev, Xc, size):
     """What fitBRIE does when the loop is over (brie_amd/models/wrap.py): every rank contributes the per-gene
     vectors [Wc_loc (Kc rows), intercept, sigma, loss_gene] of its gene shard and receives all Ng columns.
-    Runs over (a) torch.distributed (RCCL when the backend is nccl) -- the path fitBRIE takes -- and (b) the
-    library's own communicator (brie_comm_allgather of include/brie_amd.h, librccl called from libbrie_amd.so).
+    This leg goes over torch.distributed (RCCL when the backend is nccl); the library's own communicator
+    (brie_comm_allgather, what fitBRIE uses when it exists) is exercised by native_allgather_leg at the very end.
     Rank 0 then re-fits the first gene quad of every OTHER rank's shard alone and demands the gathered columns
     bit for bit (genes are independent, the noise stream is keyed by the global gene index)."""
     from brie_amd import _capi
@@ -171,50 +219,17 @@ def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, loca
     Nc, Ng, Kc, L = cfg["Nc"], cfg["Ng"], cfg["Kc"], cfg["L"]
     n_rep = 8
     ranges = [gene_shard(Ng, r, world) for r in range(world)]
-    local = np.concatenate([sh.read(_capi.WC_LOC).reshape(Kc, -1), sh.read(_capi.INTERCEPT).reshape(1, -1),
-                            sh.read(_capi.SIGMA).reshape(1, -1), sh.loss_gene(n_rep).reshape(1, -1)], axis=0)
+    local = per_gene_vectors(sh, Kc, n_rep)
     comm = GeneComm(device=dev)
-    comm.allgather_genes(local, Ng, ranges)                       # warm-up: communicator set-up, first-call costs
+    comm.allgather_genes(local, Ng, ranges, native=False)         # warm-up: communicator set-up, first-call costs
     dist.barrier()
     t0 = time.perf_counter()
-    full = comm.allgather_genes(local, Ng, ranges)
+    full = comm.allgather_genes(local, Ng, ranges, native=False)
     ms_torch = (time.perf_counter() - t0) * 1e3
     info = {"what": "per-gene vectors [Wc_loc x%d, intercept, sigma, loss_gene] of every rank -> all %d genes on every "
                     "rank; after the timed region" % (Kc, Ng),
-            "backend": dist.get_backend(), "rccl_ranks": world, "bytes_per_rank": int(local.size * 4),
-            "allgather_ms": ms_torch}
-    # (b) the C-ABI communicator.  Never exercised between two GPUs by the build (1-GPU boxes only), so it runs in a
-    # watchdog thread: if RCCL set-up or the collective does not come back, the line reports it and the run goes on.
-    import threading
-
-    def native_leg():
-        try:
-            nat = comm.native_comm(local_rank)
-            if nat is None:
-                info["native"] = "no native communicator on backend %s (RCCL needs one GPU per rank)" % dist.get_backend()
-                return
-            per = max(b - a for a, b in ranges)
-            buf = np.zeros((local.shape[0], per), np.float32)
-            buf[:, :local.shape[1]] = local
-            nat.allgather(buf)
-            t1 = time.perf_counter()
-            g = nat.allgather(buf).reshape(world, local.shape[0], per)
-            info["allgather_native_ms"] = (time.perf_counter() - t1) * 1e3
-            full_nat = np.concatenate([g[r][:, :b - a] for r, (a, b) in enumerate(ranges)], axis=1)
-            info["native_equals_torch"] = bool(np.array_equal(full_nat, full))
-        except Exception as exc:                                  # reported, not fatal: the torch path already ran
-            info["native_error"] = repr(exc)
-    th = threading.Thread(target=native_leg, daemon=True)
-    th.start()
-    th.join(180.0)
-    if th.is_alive():
-        info["native_error"] = "brie_comm leg did not return within 180 s"
-    # every rank's step time (max-over-ranks is what `value` uses)
-    t = torch.tensor([elapsed_local / args.steps * 1e3], dtype=torch.float64,
-                     device=dev if dist.get_backend() == "nccl" else "cpu")
-    outs = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(outs, t)
-    info["ms_per_step_per_rank"] = [float(o.item()) for o in outs]
+            "backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0,
+            "bytes_per_rank": int(local.size * 4), "allgather_ms": ms_torch}
     if rank == 0:
       checked, mismatched = [], []
       try:
@@ -238,8 +253,7 @@ def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, loca
             one.step(args.warmup, lr, args.mc, trace=False)
             one.step(args.steps, lr, args.mc, trace=False)
             one.step(1, lr, args.mc)
-            ref = np.concatenate([one.read(_capi.WC_LOC).reshape(Kc, -1), one.read(_capi.INTERCEPT).reshape(1, -1),
-                                  one.read(_capi.SIGMA).reshape(1, -1), one.loss_gene(n_rep).reshape(1, -1)], axis=0)
+            ref = per_gene_vectors(one, Kc, n_rep)
             one.close()
             (checked if np.array_equal(full[:, q:q + 4], ref) else mismatched).append(int(q))
         # a mismatch is reported in the line (and fails the run under BRIE_BENCH_STRICT=1); it must not cost the
@@ -250,11 +264,81 @@ def end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, loca
         info["recomputed_on_rank0"] = {"error": repr(exc)}
       if os.environ.get("BRIE_BENCH_STRICT") and not info["recomputed_on_rank0"].get("bit_identical", False):
         raise AssertionError("gathered per-gene vectors differ from rank 0's recomputation: %r" % (info["recomputed_on_rank0"],))
-    dist.barrier()
-    return info
+    return info, (comm, local, ranges, full)
 
 
-def main():
+def native_allgather_leg(info, state, local_rank, world, timeout_s=180.0):
+    """The same gather through the C-ABI communicator (brie_comm_* of include/brie_amd.h: librccl called from
+    libbrie_amd.so; the path fitBRIE takes when the process group runs on RCCL).  It has never run between two GPUs on
+    the build's 1-GPU boxes, so it is the LAST thing a rank does -- every timed number is assembled before -- and it
+    runs under a watchdog: returns False when RCCL set-up or the collective did not come back in `timeout_s`, in
+    which case the caller prints its line and leaves without touching the process group again.
+    BRIE_BENCH_NATIVE_COMM=0 skips the leg."""
+    import threading
+    comm, local, ranges, full = state
+    if os.environ.get("BRIE_BENCH_NATIVE_COMM", "1") == "0":
+        info["native"] = "skipped (BRIE_BENCH_NATIVE_COMM=0)"
+        return True
+
+    def leg():
+        try:
+            nat = comm.native_comm(local_rank)
+            if nat is None:
+                info["native"] = "no native communicator on backend %s (RCCL needs one GPU per rank)" % comm.backend
+                return
+            per = max(b - a for a, b in ranges)
+            buf = np.zeros((local.shape[0], per), np.float32)
+            buf[:, :local.shape[1]] = local
+            nat.allgather(buf)
+            t1 = time.perf_counter()
+            g = nat.allgather(buf).reshape(world, local.shape[0], per)
+            info["allgather_native_ms"] = (time.perf_counter() - t1) * 1e3
+            full_nat = np.concatenate([g[r][:, :b - a] for r, (a, b) in enumerate(ranges)], axis=1)
+            info["native_equals_torch"] = bool(np.array_equal(full_nat, full))
+        except Exception as exc:                                  # reported, not fatal: the torch path already ran
+            info["native_error"] = repr(exc)
+    th = threading.Thread(target=leg, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        info["native_error"] = "brie_comm leg did not return within %.0f s" % timeout_s
+        return False
+    return True
+
+
+LAUNCH_ENV_KEYS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK",
+                   "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                   "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE",
+                   "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "OMP_NUM_THREADS")
+
+
+def launcher_command(argv, n_gpus, port):
+    """The command `python bench.py --gpus N ...` turns into when no launcher started it: the driver's own launch line
+    (one rank per GPU of ONE node, rendezvous on 127.0.0.1), with this script's arguments relayed unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(argv, n_gpus):
+    """Start the N ranks as a CHILD process tree and return its exit code.  Called before this process has imported
+    torch.cuda or made any HIP call: a process that has initialised the GPU must never exec or be replaced."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(launcher_command(argv, n_gpus, port), env=env)
+
+
+def standalone_env():
+    """Environment of a single-process child of a rank (the rocprofv3 --pmc runs): the launcher's variables removed."""
+    return {k: v for k, v in os.environ.items() if k not in LAUNCH_ENV_KEYS}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -272,7 +356,7 @@ def main():
     ap.add_argument("--count-storage", default="auto", choices=["auto", "f32"],
                     help="auto: integer counts <= 255 are kept as u8 in HBM (bit-identical results); f32: as uploaded")
     ap.add_argument("--no-pmc", action="store_true",
-                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (N=1 only)")
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the second timed leg with fp32 count storage")
     ap.add_argument("--no-e2e", action="store_true",
                     help="skip the PCIe-inclusive leg: one whole BRIE2.fit + BRIE_RV from host arrays to host results")
@@ -280,34 +364,58 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psi-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     # RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this driver (exported on the pool already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-    import torch
-    from brie_amd import _capi
-    from brie_amd.sharding import gene_shard
+    if args.gpus < 1:
+        raise SystemExit("--gpus %d" % args.gpus)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves (child processes; nothing here has touched the GPU yet)
+        raise SystemExit(self_launch(argv, args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("BRIE_BENCH_ECHO_RANK"):          # launcher test (CPU): what reached the ranks, no GPU touched
+        if rank == 0:
+            print(json.dumps({"echo": True, "world": world, "argv": argv, "master_addr": os.environ.get("MASTER_ADDR"),
+                              "local_world": os.environ.get("LOCAL_WORLD_SIZE")}))
+        return
+
+    import torch
+    from brie_amd import _capi
+    from brie_amd.sharding import gene_shard
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if os.environ.get("BRIE_BENCH_SINGLE_DEVICE"):     # testing aid: several ranks share GPU 0 (with gloo, see below)
+    single_device = bool(os.environ.get("BRIE_BENCH_SINGLE_DEVICE"))   # testing aid: several ranks share GPU 0 (gloo)
+    if single_device:
         local_rank = 0
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d has no GPU: %d visible, --gpus %d (BRIE_BENCH_SINGLE_DEVICE=1 puts every rank on "
+                         "GPU 0 over gloo for a dry run)" % (rank, torch.cuda.device_count(), args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist = side = None
     if world > 1 or "RANK" in os.environ:       # launched by torch.distributed.run: one rank per GPU over RCCL
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if os.environ.get("BRIE_BENCH_SINGLE_DEVICE"):  # NCCL/RCCL refuses two ranks on one device: gloo for the dry run
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        patience = datetime.timedelta(minutes=30)        # rank 0 does minutes of host work while the others wait
+        if single_device:                                # NCCL/RCCL refuses two ranks on one device: gloo for the dry run
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=patience)
         else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=patience)
+            # waits for rank 0's host-side legs (CPU baseline, counter runs) go through sockets, not through a
+            # collective spinning on the GPU
+            side = dist.new_group(backend="gloo", timeout=patience)
+
+    def wait_for_rank0():
+        if dist is not None:
+            dist.barrier(group=side)
 
     cfg = dict(CONFIGS[args.config])
     if args.kc is not None:
@@ -323,31 +431,13 @@ def main():
     else:
         g0, g1 = 0, Ng
     ng = g1 - g0
-    seed = 20240617 + {"c1": 1, "c2": 2, "c3": 3, "c5": 5}[args.config]
+    if ng <= 0:
+        raise SystemExit("rank %d holds no genes: %d genes cannot be sharded over %d ranks" % (rank, Ng, world))
+    seed = config_seed(args.config)
 
     # ---- synthetic inputs, generated on the device, resident before the timed region
     t_gen = time.time()
-    gx = torch.Generator(device=dev)
-    gx.manual_seed(seed)
-    Xc = torch.zeros(Nc, Kc, device=dev)
-    if Kc:
-        Xc[:, 0] = (torch.rand(Nc, generator=gx, device=dev) < 0.5).float()
-        if Kc > 1:
-            Xc[:, 1:] = torch.randn(Nc, Kc - 1, generator=gx, device=dev)
-    size = torch.exp(0.5 * torch.randn(Nc, generator=gx, device=dev))
-    layers = [torch.empty(Nc, ng, device=dev) for _ in range(L)]
-    eff_all = torch.zeros(ng, 6, device=dev) if L == 3 else None
-    c0 = (g0 // GEN_CHUNK) * GEN_CHUNK
-    while c0 < g1:
-        c1 = min(c0 + GEN_CHUNK, Ng)
-        cnt, eff = gen_chunk(torch, dev, cfg, Xc, size, c0, c1, seed)
-        a, b = max(c0, g0), min(c1, g1)
-        for l in range(L):
-            layers[l][:, a - g0:b - g0] = cnt[l][:, a - c0:b - c0]
-        if eff is not None:
-            eff_all[a - g0:b - g0] = eff[a - c0:b - c0]
-        c0 = c1
-    torch.cuda.synchronize()
+    Xc, size, layers, eff_all = make_inputs(torch, dev, cfg, g0, g1, seed)
 
     sh = _capi.Shard(Nc, ng, Kc, n_layers=L, has_efflen=L == 3, seed=seed, device=local_rank, gene_offset=g0)
     if args.count_storage == "f32":
@@ -399,24 +489,30 @@ def main():
         sh.close()
         return
     elapsed_local = elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
+    # ---- every timed number of every rank, assembled before anything else runs
     kern_ms, n_launch = sh.profile_read()
-    stream_gbs = None
-    if rank == 0:
-        # measured ceiling of THIS box: a kernel with the same 16-B read/write stream mix and no arithmetic
-        n_read = L + 6
-        stream_gbs = max(_capi.calibrate_stream(n_read, 6, 1 << 30, iters=5, device=local_rank, nt=nt)
-                         for nt in (False, True, False, True))
     sh.profile_enable(False)
+    storage_main, storage_bytes_main, alg_bytes = sh.count_storage, sh.step_storage_bytes(), sh.step_algorithmic_bytes()
+    mine = [elapsed_local / args.steps * 1e3, kern_ms / max(n_launch, 1), float(alg_bytes), float(storage_bytes_main),
+            float(ng)]
+    per_rank = [mine]
+    if dist is not None:
+        on_dev = dist.get_backend() == "nccl"
+        t = torch.tensor(mine, dtype=torch.float64, device=dev if on_dev else "cpu")
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        per_rank = [[float(x) for x in o.cpu().tolist()] for o in outs]
+        elapsed = max(r[0] for r in per_rank) * args.steps / 1e3            # MAX over ranks
+    total_elems = Nc * (Ng if args.scaling == "strong" else Ng * world)
+    if args.emulate_shard_of:
+        total_elems = Nc * ng
+    value = args.steps * total_elems / elapsed
+
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last
-    psi_dev = sh.read(_capi.PSI) if (rank == 0 and world == 1 and not args.no_psi_check) else None
+    psi_quad = sh.read(_capi.PSI)[:, q0:q0 + 4].copy() if (rank == 0 and not args.no_psi_check and q0 + 4 <= ng) else None
     f32_leg = None
-    storage_main, storage_bytes_main = sh.count_storage, sh.step_storage_bytes()
     if rank == 0 and world == 1 and not args.no_f32_leg and storage_main != "f32":
         # the same kernel on the fp32 layers as uploaded (compact storage is reported separately)
         sh.set_count_storage(1)
@@ -426,40 +522,39 @@ def main():
         ms32, n32 = sh.profile_read()
         sh.profile_enable(False)
         f32_leg = {"avg_kernel_ms": ms32 / max(n32, 1), "storage_bytes_per_launch": sh.step_storage_bytes()}
-    total_elems = Nc * (Ng if args.scaling == "strong" else Ng * world)
-    if args.emulate_shard_of:
-        total_elems = Nc * ng
-    value = args.steps * total_elems / elapsed
 
     # ---- N > 1: the end-of-fit exchange of a gene-sharded fit (BASELINE configs[3]: "RCCL weight all-gather"),
     # untimed by `value` (there is no collective inside the optimisation loop) but executed, checked and reported
-    gather_info = None
+    gather_info = gather_state = None
     # (BRIE_BENCH_FORCE_GATHER=1: run this leg with a world of ONE rank too -- the only way to put the nccl branch and
     #  the C-ABI communicator through RCCL on a 1-GPU box)
     if dist is not None and args.scaling == "strong" and (world > 1 or os.environ.get("BRIE_BENCH_FORCE_GATHER")):
-        gather_info = end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank, dev, Xc, size,
-                                           elapsed_local)
+        gather_info, gather_state = end_of_fit_allgather(torch, dist, sh, cfg, args, seed, lr, rank, world, local_rank,
+                                                         dev, Xc, size)
+        gather_info["ms_per_step_per_rank"] = [r[0] for r in per_rank]
 
     out = None
     if rank == 0:
-        alg_bytes = sh.step_algorithmic_bytes()
-        avg_ms = kern_ms / max(n_launch, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "definition": "achieved = ALGORITHMIC bytes (48 + 4 L per element, fp32 model of SURVEY 8d) / average "
-                              "launch time of the dominant kernel; what the kernel physically moves is hbm_rate_GBs",
-                "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": avg_ms,
-                "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": n_launch,
-                "count_storage": storage_main, "storage_bytes_per_launch": storage_bytes_main,
+        # the dominant kernel against the roofline, PER GPU: each rank's algorithmic bytes / its own average launch time
+        gpus = [{"rank": r, "genes": int(v[4]), "ms_per_step": v[0], "avg_kernel_ms": v[1],
+                 "achieved": v[2] / (v[1] * 1e-3) / 1e9, "frac": v[2] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "hbm_rate_GBs": v[3] / (v[1] * 1e-3) / 1e9} for r, v in enumerate(per_rank)]
+        worst = min(gpus, key=lambda g: g["frac"])
+        roof = {"bound": "hbm", "achieved": worst["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": worst["frac"], "traffic": None,
+                "definition": "achieved = ALGORITHMIC bytes (48 + 4 L per element, fp32 model of SURVEY 8d) of ONE launch "
+                              "on ONE GPU / average launch time of the dominant kernel there (HIP events on the handle's "
+                              "stream); with N > 1 the slowest GPU's figure, every GPU's under per_gpu; what the kernel "
+                              "physically moves is hbm_rate_GBs",
+                "kernel": "elbo_adam_step<Kc=%d>" % Kc, "avg_kernel_ms": worst["avg_kernel_ms"],
+                "algorithmic_bytes_per_launch": int(per_rank[worst["rank"]][2]), "launches_timed": n_launch,
+                "count_storage": storage_main, "storage_bytes_per_launch": int(per_rank[worst["rank"]][3]),
                 # the physical HBM rate: bytes the current storage moves (integer counts are kept as u8 / u16,
                 # bit-identical results) over the same time -- below `achieved` by construction
-                "hbm_rate_GBs": storage_bytes_main / (avg_ms * 1e-3) / 1e9,
-                "hbm_frac_of_peak": storage_bytes_main / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                # ... and against what a pure streaming kernel with the same stream mix and access order reaches
-                # on THIS box (brie_calibrate_stream)
-                "measured_stream_ceiling_GBs": stream_gbs,
-                "frac_of_measured_stream_ceiling": storage_bytes_main / (avg_ms * 1e-3) / 1e9 / stream_gbs}
+                "hbm_rate_GBs": worst["hbm_rate_GBs"], "hbm_frac_of_peak": worst["hbm_rate_GBs"] / HBM_PEAK_GBS,
+                "rccl_ranks": world if (dist is not None and dist.get_backend() == "nccl") else 0}
+        if world > 1:
+            roof["per_gpu"] = gpus
         if f32_leg is not None:
             t32 = f32_leg["avg_kernel_ms"] * 1e-3
             roof["f32_count_storage"] = dict(f32_leg, achieved=alg_bytes / t32 / 1e9, frac=alg_bytes / t32 / 1e9 / HBM_PEAK_GBS,
@@ -485,6 +580,7 @@ def main():
     del sh
     torch.cuda.empty_cache()
 
+    # ---- rank 0's host-side legs; the other ranks wait on sockets (wait_for_rank0 below)
     if rank == 0:
         out["roofline"].update(hbm_traffic(args, world, storage_main))
     if e2e_inputs is not None:
@@ -506,24 +602,23 @@ def main():
         mdl.close()
         del e2e_inputs, rv
 
-    if rank == 0 and world == 1 and not args.no_psi_check and q0 + 4 <= ng:
-        # PSI delta ON THE HEADLINE WORKLOAD: genes are independent and the noise stream is keyed by the global gene
+    if rank == 0 and psi_quad is not None:
+        # PSI delta ON THE TIMED WORKLOAD: genes are independent and the noise stream is keyed by the global gene
         # index, so the CPU oracle run on one gene quad over all Nc cells is an exact reference for those genes
         from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
         n_total = args.warmup + args.steps + 1
         o = OracleBRIE2(Nc, 4, Kc, effLen=quad_eff, seed=seed, gene_offset=g0 + q0, dtype=np.float64)
         o.minimize(add_pseudo_count(quad_layers), Xc_host, n_total, lr, args.mc)
-        d = np.abs(psi_dev[:, q0:q0 + 4] - o.Psi)
+        d = np.abs(psi_quad - o.Psi)
         out["psi_delta_headline_workload"] = {
             "what": "genes %d..%d of the timed %s run, all %d cells, %d Adam steps vs the fp64 CPU oracle"
                     % (g0 + q0, g0 + q0 + 3, args.config, Nc, n_total),
             "max": float(d.max()), "p99": float(np.percentile(d, 99))}
-    if rank == 0 and world == 1:
+    if rank == 0:
         if not args.no_psi_check:
             out["psi_delta_vs_cpu_ref"] = psi_delta_check()
         if not args.no_cpu_baseline:
             from oracle.brie_oracle_torch import time_reference_shape
-            import torch as _t
             cores = min(6, os.cpu_count() or 1)          # reference default --nproc 6 (bin/quant.py:183)
             n_gene = min(int(math.ceil(500000 / float(Nc))), sample_layers[0].shape[1])
             nb = max(1, min(3, sample_layers[0].shape[1] // n_gene))
@@ -538,8 +633,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": eps_s, "unit": "cell*gene*iterations/s", "cores": cores, "kind": "port",
                 "sample": "%d reference-sized gene batches (%d genes x %d cells each, model_wrap.py:242) x %d Adam "
-                          "steps, eager torch-CPU autograd restatement (TF absent), %.1f s"
-                          % (nb, n_gene, Nc, n_steps, el),
+                          "steps, eager torch-CPU autograd restatement (TF absent), %.1f s; rank 0's host cores%s"
+                          % (nb, n_gene, Nc, n_steps, el, " while the other ranks idle" if world > 1 else ""),
                 "gpu_over_cpu": value / eps_s,
             }
             # second, separately labelled baseline: the same algorithm as ONE fused
@@ -548,6 +643,7 @@ def main():
                 from oracle.c_oracle import COracle
                 from oracle.brie_oracle import add_pseudo_count
                 co = COracle(add_pseudo_count(sample_layers), Xc_host, effLen=None if L == 2 else eff_host, seed=seed)
+                co.set_threads(os.cpu_count() or 1)       # (torch.distributed.run exports OMP_NUM_THREADS=1)
                 co.minimize(2, 0.005, args.mc)
                 t0 = time.perf_counter()
                 co.minimize(3, 0.005, args.mc)
@@ -565,10 +661,19 @@ def main():
                     "gpu_over_cpu": value / fused}
             except Exception as exc:                      # gcc / OpenMP missing: the eager baseline above stands
                 out["cpu_baseline_fused"] = {"error": repr(exc)}
+
+    # ---- LAST: the C-ABI communicator's gather (never run between two GPUs by the build).  Nothing measured comes
+    # after it; if it does not come back, rank 0 prints its line and every rank leaves without another collective.
+    wait_for_rank0()
+    came_back = True
+    if gather_state is not None:
+        came_back = native_allgather_leg(gather_info, gather_state, local_rank, world)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if not came_back:
+        os._exit(0 if rank == 0 else 3)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=side)
         dist.destroy_process_group()
 
 

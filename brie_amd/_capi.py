@@ -30,7 +30,7 @@ EXPORTS = [
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
-    "brie_loglik_mc", "brie_debug_address",
+    "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16",
 ]
 COMM_ID_BYTES = 128
 
@@ -118,6 +118,8 @@ def load_library(path=None):
     lib.brie_read_wait.argtypes = [vp]
     lib.brie_debug_address.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
     lib.brie_loglik_mc.argtypes = [vp, i32, vp, i64]
+    lib.brie_get_loss.argtypes = [vp, i32, i32, vp]
+    lib.brie_host_convert_u16.argtypes = [vp, i64, i64, i64, vp, ctypes.POINTER(i32)]
     lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
@@ -235,6 +237,21 @@ def calibrate_stream(n_read, n_write, bytes_per_stream=1 << 30, iters=5, device=
     return out.value
 
 
+def host_convert_u16(a):
+    """The host half of the staged count ingest (brie_host_convert_u16): (uint16 copy, not_integral flag)."""
+    lib = load_library()
+    a = np.asarray(a, np.float32)
+    if a.ndim != 2 or a.strides[1] != 4 or a.strides[0] % 4:
+        a = np.ascontiguousarray(a)
+    out = np.empty(a.shape, np.uint16)
+    flag = ctypes.c_int32()
+    if a.size == 0:
+        return out, False
+    _check(lib, lib.brie_host_convert_u16(a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.strides[0] // 4,
+                                          out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(flag)))
+    return out, bool(flag.value)
+
+
 def host_register(a):
     """Page-lock a numpy array in place (hipHostRegister); ctypes drops the GIL for the duration of the call."""
     lib = load_library()
@@ -300,7 +317,7 @@ def simulate_counts(psi, total, effLen=None, seed=0, gene_offset=0, device=0):
 
 class Shard(object):
     """Thin object wrapper over one `brie_handle` (one gene shard on one GPU)."""
-    pins_host = True        # result arrays are page-locked while the fit runs (BRIE2.fit, prefetch_results)
+    first_touch_results = True   # BRIE2.fit first-touches its (pageable) result arrays on a background thread
 
     def __init__(self, Nc, Ng, Kc=0, n_layers=2, has_efflen=False, train_intercept=True,
                  train_sigma=True, seed=0, device=0, gene_offset=0, Kg=0, intercept_mode=0, sharded=False):
@@ -442,6 +459,13 @@ class Shard(object):
         """(Nc, Ng) Monte-Carlo log-likelihood of every entry under the current target (brie_loglik_mc)."""
         out = np.empty((self.Nc, self.Ng), np.float32)
         _check(self.lib, self.lib.brie_loglik_mc(self._h, int(size), out.ctypes.data_as(ctypes.c_void_p), self.Ng))
+        return out
+
+    def get_loss(self, mc_size=1, axis=0):
+        """One stochastic loss evaluation under the current target, per gene (axis 0, (Ng,)) or per cell (axis 1, (Nc,));
+        brie_get_loss."""
+        out = np.empty(self.Ng if int(axis) == 0 else self.Nc, np.float32)
+        _check(self.lib, self.lib.brie_get_loss(self._h, int(mc_size), int(axis), out.ctypes.data_as(ctypes.c_void_p)))
         return out
 
     def read_results_async(self, psi=None, z_std=None, psi95ci=None, z_loc=None):

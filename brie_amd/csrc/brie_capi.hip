@@ -8,7 +8,10 @@
 #include "brie_comm_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <mutex>
+#include <sched.h>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -149,6 +152,11 @@ struct brie_handle {
     size_t loss_parts_elems = 0;
     int rows_per_chunk = 0, n_chunks = 0, gene_blocks = 0, fin_blocks = 0;
     int user_rows_per_chunk = 0;
+    int *tickets = nullptr;         // (gene_blocks) fused finalize of launch-bound problems (brie::FusedFinalize)
+    brie::FusedFinalize *ff_dev = nullptr, *ff_pin = nullptr;   // one struct per step of a brie_step call: device / page-locked
+    size_t ff_cap = 0;
+    hipEvent_t ff_event = nullptr;  // the copy out of ff_pin has completed
+    int fused_mode = -1;            // BRIE_FUSED_FINALIZE: -1 automatic, 0 never, 1 whenever the kernel variant allows
     uint32_t draw = 0;
     int64_t t = 0;                  // Adam iteration of the current optimiser
     bool have_c[3] = {false, false, false}, have_xc = false, have_eff = false, have_state = false;
@@ -158,6 +166,7 @@ struct brie_handle {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    int64_t prof_batched = 0;       // launches covered by a shared event pair beyond one per pair (fused finalize)
 };
 
 namespace {
@@ -622,6 +631,162 @@ int copy_cellgene(brie_handle *h, float *dev, const float *ext, float *ext_out, 
     return BRIE_OK;
 }
 
+// ---- staged host ingest of a count layer (replaces the densify + cast of model_wrap.py:108-111) ----------
+// The API hands over (Nc, Ng) fp32 layers in PAGEABLE host memory: 8 GB at configs[2].  Left to the runtime, such a
+// copy is pinned or staged page by page by ONE runtime thread and its speed is the box's (0.17 s on one, 0.69 s on the
+// next).  Here T host threads each own a lane -- two page-locked slabs, two device slabs, a stream -- and walk their
+// share of the row slabs: convert the slab to u16 while checking that it holds nothing but integers in [0, 65535]
+// (else the slab travels as the fp32 values themselves), start its asynchronous copy, enqueue the kernel that writes
+// it into the tiled fp32 layer, and go on converting the next slab while the copy engine works.  Half the bytes cross
+// PCIe, the host side runs at the memory bandwidth of T cores, and what reaches the layer is bit-identical.
+struct IngestLane {
+    void *pin[2] = {nullptr, nullptr};
+    void *dev[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+};
+struct IngestPool {
+    std::mutex mu;                      // one staged upload at a time per process
+    int device = -1;
+    size_t slab_bytes = 0;
+    std::vector<IngestLane> lanes;
+    void release() {
+        for (IngestLane &ln : lanes) {
+            for (int b = 0; b < 2; ++b) {
+                if (ln.pin[b]) hipHostFree(ln.pin[b]);
+                if (ln.dev[b]) hipFree(ln.dev[b]);
+                if (ln.ev[b]) hipEventDestroy(ln.ev[b]);
+            }
+            if (ln.stream) hipStreamDestroy(ln.stream);
+        }
+        lanes.clear();
+        device = -1;
+        slab_bytes = 0;
+    }
+};
+IngestPool g_ingest;
+
+int ingest_threads() {
+    const char *e = getenv("BRIE_INGEST_THREADS");
+    if (e && atoi(e) > 0) return std::min(64, atoi(e));
+    cpu_set_t set;
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = static_cast<int>(std::thread::hardware_concurrency());
+    return std::max(1, std::min(8, n));
+}
+
+// rows x cols floats (row pitch ld) -> u16; returns nonzero when some value is not a non-negative integer <= 65535
+// (negative zero counts as "not": its sign bit would be lost)
+// (host code only: the device pass of this translation unit knows no x86 function multiversioning)
+#if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
+#define BRIE_HOST_SIMD_CLONES __attribute__((noinline))
+#else
+#define BRIE_HOST_SIMD_CLONES __attribute__((target_clones("arch=x86-64-v4", "arch=x86-64-v3", "default")))
+#endif
+BRIE_HOST_SIMD_CLONES uint32_t convert_rows_u16(const float *src, int64_t ld, int64_t rows, int64_t cols, uint16_t *dst) {
+    uint32_t bad = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const float *s = src + r * ld;
+        uint16_t *d = dst + r * cols;
+        uint32_t b = 0;
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int64_t j = 0; j < cols; ++j) {
+            const float v = s[j];
+            uint32_t bits;
+            memcpy(&bits, &v, sizeof(bits));
+            const int32_t iv = static_cast<int32_t>(v < 65536.0f ? (v > -1.0f ? v : -1.0f) : 65536.0f);   // NaN -> 65536
+            b |= static_cast<uint32_t>(static_cast<float>(iv) != v) | (bits >> 31) | static_cast<uint32_t>(iv > 65535);
+            d[j] = static_cast<uint16_t>(iv);
+        }
+        bad |= b;
+    }
+    return bad;
+}
+
+bool use_staged_ingest(const brie_handle *h, const void *src, int64_t elems) {
+    const char *m = getenv("BRIE_INGEST");               // "direct" / "staged": force (A/B runs, tests)
+    if (m && strcmp(m, "direct") == 0) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) {
+        if (at.type != hipMemoryTypeUnregistered) return false;      // device, managed or page-locked host memory: DMA as is
+    } else {
+        (void)hipGetLastError();                                      // plain pageable host memory
+    }
+    if (m && strcmp(m, "staged") == 0) return true;
+    const char *me = getenv("BRIE_INGEST_MIN_ELEMS");
+    const int64_t min_elems = me ? atoll(me) : (int64_t(1) << 24);   // below 64 MB the plain copy is as good
+    (void)h;
+    return elems >= min_elems;
+}
+
+int staged_count_upload(brie_handle *h, float *dev, const float *src, int64_t ld) {
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    std::lock_guard<std::mutex> lock(g_ingest.mu);
+    const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
+    const int64_t slab_elems = std::max<int64_t>(Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 22));   // 16 MB of fp32
+    const int64_t R = std::max<int64_t>(1, slab_elems / Ng);
+    const int64_t n_slabs = (Nc + R - 1) / R;
+    const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
+    const size_t slab_bytes = static_cast<size_t>(R) * Ng * sizeof(float);
+    if (g_ingest.device != h->p.device || g_ingest.slab_bytes < slab_bytes || static_cast<int>(g_ingest.lanes.size()) < T) {
+        g_ingest.release();
+        g_ingest.lanes.resize(static_cast<size_t>(T));
+        g_ingest.device = h->p.device;
+        g_ingest.slab_bytes = slab_bytes;
+        for (IngestLane &ln : g_ingest.lanes) {
+            hipError_t e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+            for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+                e = hipHostMalloc(&ln.pin[b], slab_bytes, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipMalloc(&ln.dev[b], slab_bytes);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev[b], hipEventDisableTiming);
+            }
+            if (e != hipSuccess) {
+                g_ingest.release();
+                return fail(BRIE_ERR_HIP, "staged ingest buffers: %s", hipGetErrorString(e));
+            }
+        }
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));             // earlier work on the layer (memset, a previous upload)
+    std::atomic<int> err{0};
+    const int device = h->p.device, gene_blocks = h->gene_blocks;
+    const int64_t row_stride = h->row_stride, gb_stride = h->gb_stride;
+    auto lane_fn = [&, device, gene_blocks, row_stride, gb_stride](int t) {
+        IngestLane &ln = g_ingest.lanes[static_cast<size_t>(t)];
+        hipError_t e = hipSetDevice(device);
+        int64_t k = 0;
+        for (int64_t s = t; s < n_slabs && e == hipSuccess && err.load() == 0; s += T, ++k) {
+            const int b = static_cast<int>(k & 1);
+            if (k >= 2) e = hipEventSynchronize(ln.ev[b]);            // the copy out of this page-locked slab is done
+            if (e != hipSuccess) break;
+            const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
+            const float *rows_src = src + r0 * ld;
+            const uint32_t bad = convert_rows_u16(rows_src, ld, rows, Ng, static_cast<uint16_t *>(ln.pin[b]));
+            if (bad)                                                  // fractional / huge / negative: the values themselves
+                for (int64_t r = 0; r < rows; ++r)
+                    memcpy(static_cast<float *>(ln.pin[b]) + r * Ng, rows_src + r * ld, static_cast<size_t>(Ng) * sizeof(float));
+            const size_t bytes = static_cast<size_t>(rows) * Ng * (bad ? sizeof(float) : sizeof(uint16_t));
+            e = hipMemcpyAsync(ln.dev[b], ln.pin[b], bytes, hipMemcpyHostToDevice, ln.stream);
+            if (e == hipSuccess) e = hipEventRecord(ln.ev[b], ln.stream);
+            if (e != hipSuccess) break;
+            hipLaunchKernelGGL(brie::ingest_slab, dim3(grid_1d(static_cast<int64_t>(gene_blocks) * rows * brie::kWave)), dim3(256),
+                               0, ln.stream, ln.dev[b], bad ? 1 : 0, dev, static_cast<int>(r0), static_cast<int>(rows),
+                               static_cast<int>(Ng), gene_blocks, row_stride, gb_stride);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ln.stream);
+        if (e != hipSuccess) { (void)hipGetLastError(); err.store(static_cast<int>(e)); }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; ++t) pool.emplace_back(lane_fn, t);
+    lane_fn(0);
+    for (std::thread &th : pool) th.join();
+    (void)hipSetDevice(device);
+    if (err.load() != 0)
+        return fail(BRIE_ERR_HIP, "staged ingest: %s", hipGetErrorString(static_cast<hipError_t>(err.load())));
+    return BRIE_OK;
+}
+
 int grid_1d(int64_t n) {
     int64_t g = (n + 255) / 256;
     return static_cast<int>(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -720,6 +885,11 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
         e = hipMalloc(reinterpret_cast<void **>(&h->block_active), h->gene_blocks * sizeof(int32_t));
         if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+        e = hipMalloc(reinterpret_cast<void **>(&h->tickets), h->gene_blocks * sizeof(int));
+        if (e == hipSuccess) e = hipMemsetAsync(h->tickets, 0, h->gene_blocks * sizeof(int), h->stream);
+        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+        const char *ffe = getenv("BRIE_FUSED_FINALIZE");
+        h->fused_mode = ffe ? (ffe[0] == '0' ? 0 : 1) : -1;
         if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { brie_destroy(h); return rc; }
     }
     if (h->coupled) {
@@ -775,6 +945,12 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
 int brie_destroy(brie_handle *h) {
     if (!h) return BRIE_OK;
     hipSetDevice(h->p.device);
+    // a pending asynchronous export still launches export_slab kernels that read mu / rho (error paths: the caller's
+    // loss_gene raised between brie_read_results_async and brie_read_wait, or a C client skipped the wait): let the
+    // worker and its stream finish BEFORE anything is freed
+    if (h->io_thread.joinable()) h->io_thread.join();
+    if (h->io_stream) hipStreamSynchronize(h->io_stream);
+    h->io_pending = false;
     if (h->stream) hipStreamSynchronize(h->stream);
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
@@ -785,13 +961,16 @@ int brie_destroy(brie_handle *h) {
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
     if (h->block_active) hipFree(h->block_active);
+    if (h->tickets) hipFree(h->tickets);
+    if (h->ff_dev) hipFree(h->ff_dev);
+    if (h->ff_pin) hipHostFree(h->ff_pin);
+    if (h->ff_event) hipEventDestroy(h->ff_event);
     if (h->quad_ids) hipFree(h->quad_ids);
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
     if (h->io_scratch) hipFree(h->io_scratch);
     if (h->win_scratch) hipFree(h->win_scratch);
-    if (h->io_thread.joinable()) h->io_thread.join();
-    if (h->io_stream) { hipStreamSynchronize(h->io_stream); hipStreamDestroy(h->io_stream); }
+    if (h->io_stream) hipStreamDestroy(h->io_stream);
     if (h->io_event) hipEventDestroy(h->io_event);
     if (h->io_slab) hipFree(h->io_slab);
     (void)free_tier_tables(h);
@@ -861,7 +1040,9 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
                     (long long)C, (long long)rows, (long long)cols);
     if (R * C > 0) {
         const bool cellgene = (which <= BRIE_COUNT3) || which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG;
-        if (cellgene) {
+        if (which <= BRIE_COUNT3 && use_staged_ingest(h, src, R * C)) {
+            if ((rc = staged_count_upload(h, dev, src, ld)) != BRIE_OK) return rc;
+        } else if (cellgene) {
             if ((rc = copy_cellgene(h, dev, src, nullptr, ld)) != BRIE_OK) return rc;
         } else {
             HIP_TRY(hipMemcpy2DAsync(dev, ldd * sizeof(float), src, ld * sizeof(float), C * sizeof(float), R,
@@ -1194,6 +1375,27 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->loss_parts), lp_need * sizeof(double)));
         h->loss_parts_elems = lp_need;
     }
+    // Launch-bound problems: the per-gene finalize runs inside the step kernel (brie::FusedFinalize), one launch per
+    // step.  Automatic when the whole grid is a fraction of one round of workgroups and the last workgroup's serial sum
+    // over the chunks is short; only the plain variants of elbo_adam_step (ELBO target, uncoupled, Kc <= 8) take it.
+    const bool fused_ok = !h->coupled && !h->wide_like && h->target == 0 && !split;
+    const bool fused = fused_ok && (h->fused_mode == 1 ||
+                                    (h->fused_mode < 0 && h->gene_blocks * h->n_chunks <= 512 && h->n_chunks <= 64));
+    if (fused) {
+        if (static_cast<size_t>(n_steps) > h->ff_cap) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (h->ff_dev) HIP_TRY(hipFree(h->ff_dev));
+            if (h->ff_pin) HIP_TRY(hipHostFree(h->ff_pin));
+            h->ff_dev = h->ff_pin = nullptr;
+            h->ff_cap = 0;
+            const size_t cap = std::max<size_t>(256, static_cast<size_t>(n_steps));
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->ff_dev), cap * sizeof(brie::FusedFinalize)));
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->ff_pin), cap * sizeof(brie::FusedFinalize), hipHostMallocDefault));
+            h->ff_cap = cap;
+        }
+        if (!h->ff_event) HIP_TRY(hipEventCreateWithFlags(&h->ff_event, hipEventDisableTiming));
+        else HIP_TRY(hipEventSynchronize(h->ff_event));            // the previous call's copy has left ff_pin
+    }
     if (h->profiling) {
         while (h->ev_pool.size() < h->ev_used + 2 * static_cast<size_t>(n_steps)) {
             hipEvent_t ev;
@@ -1260,23 +1462,47 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     f.train_b = h->cell_mode ? 0 : h->p.train_intercept;        // cell mode: the (1,Ng) vectors are not parameters
     f.train_lam = h->cell_mode ? 0 : h->p.train_sigma;
 
+    auto adam_alpha = [lr](int64_t t) {
+        const double tt = static_cast<double>(t);
+        return static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) / (1.0 - std::pow(0.9, tt)));
+    };
+    if (fused) {        // the finalize arguments of every step of this call, in device memory before the first launch
+        int64_t t = h->t, rp = h->ring_pos;
+        for (int i = 0; i < n_steps; ++i, ++rp) {
+            brie::FinalizeArgs fi = f;
+            fi.alpha = adam_alpha(++t);
+            fi.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
+            fi.ring_slot = static_cast<int32_t>(rp % brie::kLossRing);
+            fi.ring_prev = static_cast<int32_t>((rp + brie::kLossRing - 1) % brie::kLossRing);
+            h->ff_pin[i].fin = fi;
+            h->ff_pin[i].tickets = h->tickets;
+        }
+        HIP_TRY(hipMemcpyAsync(h->ff_dev, h->ff_pin, static_cast<size_t>(n_steps) * sizeof(brie::FusedFinalize),
+                               hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipEventRecord(h->ff_event, h->stream));
+    }
     for (int i = 0; i < n_steps; ++i) {
         h->t += 1;
-        const double tt = static_cast<double>(h->t);
-        const float alpha = static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) /
-                                               (1.0 - std::pow(0.9, tt)));
+        const float alpha = adam_alpha(h->t);
         a.alpha = alpha; f.alpha = alpha; cf.alpha = alpha;
         a.draw = h->draw++;
         f.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
         f.ring_slot = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
-        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        // HIP events around every launch of the dominant kernel; single-kernel steps (fused finalize) are bracketed as
+        // ONE batch instead -- two event packets per 6-us kernel would be most of what is measured -- so their average
+        // includes the gaps between the back-to-back launches
+        const bool ev_each = h->profiling && !fused, ev_first = h->profiling && fused && i == 0,
+                   ev_last = h->profiling && fused && i == n_steps - 1;
+        if (ev_each || ev_first) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        if (fused) cfg.ff = h->ff_dev + i;
         if (use_tile) launch_tile(h, cfg, q, a, ta);
         else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
-        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
+        if (ev_each || ev_last) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        if (h->profiling && fused) h->prof_batched += (i == n_steps - 1) ? n_steps - 1 : 0;    // launches beyond the pair
+        if (!fused) hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
         if (use_tile && h->p.Kc > 0) {            // G = Xc^T . r was reduced inside the pass: Adam on Wc_loc
             const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
             hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
@@ -1509,21 +1735,23 @@ int brie_read(brie_handle *h, int which, float *dst, int64_t rows, int64_t cols,
     return BRIE_OK;
 }
 
-int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld) {
-    int rc = check_ready(h);
-    if (rc != BRIE_OK) return rc;
-    if (size < 1 || !out) return fail(BRIE_ERR_INVALID, "size=%d out=%p", size, (void *)out);
-    if (ld < h->p.Ng) return fail(BRIE_ERR_INVALID, "ld=%lld < Ng", (long long)ld);
-    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "logLik_MC needs the tiled layout");
-    if ((rc = set_device(h)) != BRIE_OK) return rc;
+}  // extern "C"
+
+namespace {
+// Per-entry Monte-Carlo terms of the loss into row-major (Nc, Ng) DEVICE buffers: res_ll = mean over `size` samples
+// z ~ q of the log-likelihood (target ELBO) or their log-mean-exp with z ~ prior (target marginLik); res_kl (may be
+// null; ELBO only) = KL(q || prior).  by_draw: see brie::LogLikArgs.  An accessor, not the hot loop: compact count
+// layers are expanded into fp32 temporaries, the prior mean goes through Mbuf.
+int eval_elements(brie_handle *h, int32_t size, int by_draw, float *res_ll, float *res_kl) {
+    int rc = BRIE_OK;
+    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "the per-entry accessors need the tiled layout");
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     const size_t mat = static_cast<size_t>(Nc) * h->ld;
     // fp32 views of the count layers (pseudo-count included), expanded into temporaries when stored compactly
     float *tmp[3] = {nullptr, nullptr, nullptr};
-    float *res = nullptr;
-    auto cleanup = [&]() { for (float *q : tmp) if (q) hipFree(q); if (res) hipFree(res); };
+    auto cleanup = [&]() { for (float *q : tmp) if (q) hipFree(q); };
     brie::LogLikArgs a{};
     const float *layers[3] = {nullptr, nullptr, nullptr};
     for (int l = 0; l < h->p.n_layers; ++l) {
@@ -1535,33 +1763,99 @@ int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld) {
         launch_expand(h, l, tmp[l], h->pc, l < 2 ? 1 : 0);
         layers[l] = tmp[l];
     }
-    if (hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(Nc) * Ng * sizeof(float)) != hipSuccess) {
-        cleanup();
-        return fail(BRIE_ERR_HIP, "hipMalloc result");
-    }
     a.c1 = layers[0]; a.c2 = layers[1]; a.c3 = layers[2];
     a.mu = h->mu; a.rho = h->rho; a.b = h->b; a.lam = h->lam; a.cb = h->cb; a.clam = h->clam; a.effL = h->effL;
     a.prior_m = nullptr;
     a.margin = h->target == 1 ? 1 : 0;
-    if (a.margin && (h->p.Kc > 0 || h->p.Kg > 0)) {            // prior mean Xc.Wc_loc (+ Wg_loc.Xg^T) into Mbuf
+    if ((a.margin || res_kl) && (h->p.Kc > 0 || h->p.Kg > 0)) {   // prior mean Xc.Wc_loc (+ Wg_loc.Xg^T) into Mbuf
         if (h->p.Kc > 0 && (rc = wide_forward_mean(h)) != BRIE_OK) { cleanup(); return rc; }
         if (h->p.Kg > 0 && (rc = gwide_forward_mean(h, h->p.Kc > 0)) != BRIE_OK) { cleanup(); return rc; }
         a.prior_m = h->Mbuf;
     }
-    a.out = res; a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+    a.out = res_ll; a.kl_out = a.margin ? nullptr : res_kl;
+    a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
     a.Nc = static_cast<int32_t>(Nc); a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
-    a.mode = h->mode; a.cell_mode = h->cell_mode ? 1 : 0; a.n_mc = size;
+    a.mode = h->mode; a.cell_mode = h->cell_mode ? 1 : 0; a.n_mc = size; a.by_draw = by_draw;
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
-    a.draw = h->draw++; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    // by_draw == 0: ONE draw id; sample k of the `size` samples is keyed (draw, k) like the MC samples of one step -- no
+    // (draw, k) pair of this call is ever produced again by a later step or loss_gene (those use k < MC_size of LATER
+    // draw ids).  by_draw == 1: `size` draw ids, sample k at (draw + k, 0).
+    a.draw = h->draw; a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
+    h->draw += by_draw ? static_cast<uint32_t>(size) : 1u;
     hipLaunchKernelGGL(brie::loglik_mc_export, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * Nc * brie::kWave)),
                        dim3(256), 0, h->stream, a);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess)
-        e = hipMemcpy2DAsync(out, ld * sizeof(float), res, Ng * sizeof(float), Ng * sizeof(float), Nc, hipMemcpyDefault,
-                             h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     cleanup();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "per-entry loss terms: %s", hipGetErrorString(e));
+    return BRIE_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld) {
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (size < 1 || !out) return fail(BRIE_ERR_INVALID, "size=%d out=%p", size, (void *)out);
+    if (ld < h->p.Ng) return fail(BRIE_ERR_INVALID, "ld=%lld < Ng", (long long)ld);
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    float *res = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(Nc) * Ng * sizeof(float)) != hipSuccess)
+        return fail(BRIE_ERR_HIP, "hipMalloc result");
+    rc = eval_elements(h, size, 0, res, nullptr);
+    hipError_t e = hipSuccess;
+    if (rc == BRIE_OK) {
+        e = hipMemcpy2DAsync(out, ld * sizeof(float), res, Ng * sizeof(float), Ng * sizeof(float), Nc, hipMemcpyDefault,
+                             h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    }
+    hipFree(res);
+    if (rc != BRIE_OK) return rc;
     if (e != hipSuccess) return fail(BRIE_ERR_HIP, "logLik_MC: %s", hipGetErrorString(e));
+    return BRIE_OK;
+}
+
+int brie_get_loss(brie_handle *h, int32_t mc_size, int32_t axis, float *out) {
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (mc_size < 1 || !out) return fail(BRIE_ERR_INVALID, "mc_size=%d out=%p", mc_size, (void *)out);
+    if (axis != 0 && axis != 1) return fail(BRIE_ERR_INVALID, "axis=%d (0 = per gene, 1 = per cell)", axis);
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
+    const bool elbo = h->target == 0;
+    const int rows_per_chunk = 256;
+    const int n_chunks = static_cast<int>((Nc + rows_per_chunk - 1) / rows_per_chunk);
+    float *ll = nullptr, *kl = nullptr, *res = nullptr;
+    double *part = nullptr;
+    auto cleanup = [&]() { hipFree(ll); hipFree(kl); hipFree(res); hipFree(part); };
+    const size_t mat = static_cast<size_t>(Nc) * Ng * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ll), mat);
+    if (e == hipSuccess && elbo) e = hipMalloc(reinterpret_cast<void **>(&kl), mat);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(axis == 0 ? Ng : Nc) * sizeof(float));
+    if (e == hipSuccess && axis == 0)
+        e = hipMalloc(reinterpret_cast<void **>(&part), static_cast<size_t>(n_chunks) * 2 * Ng * sizeof(double));
+    if (e != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "get_loss buffers: %s", hipGetErrorString(e)); }
+    // ELBO: KL - mean_k ll(z_k), the samples at consecutive draw ids like brie_loss_gene(mc_size) (the loss is linear in
+    // them); marginLik: -log-mean-exp over the samples of ONE draw id, like a step with this MC_size
+    if ((rc = eval_elements(h, mc_size, elbo ? 1 : 0, ll, kl)) != BRIE_OK) { cleanup(); return rc; }
+    if (axis == 0) {
+        const dim3 grid(static_cast<unsigned>((Ng + 255) / 256), static_cast<unsigned>(n_chunks));
+        hipLaunchKernelGGL(brie::loss_axis0_partial, grid, dim3(256), 0, h->stream, kl, ll, part, static_cast<int>(Nc),
+                           static_cast<int>(Ng), rows_per_chunk);
+        hipLaunchKernelGGL(brie::loss_axis0_final, dim3(grid.x), dim3(256), 0, h->stream, part, res, static_cast<int>(Ng),
+                           n_chunks);
+    } else {
+        hipLaunchKernelGGL(brie::loss_axis1, dim3(static_cast<unsigned>(Nc)), dim3(brie::kBlock), 0, h->stream, kl, ll, res,
+                           static_cast<int>(Nc), static_cast<int>(Ng));
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(out, res, static_cast<size_t>(axis == 0 ? Ng : Nc) * sizeof(float), hipMemcpyDefault, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "get_loss: %s", hipGetErrorString(e));
     return BRIE_OK;
 }
 
@@ -1650,6 +1944,28 @@ int brie_read_wait(brie_handle *h) {
     return io_wait(h);
 }
 
+// the host half of the staged ingest on its own (no GPU involved): tests and host-bandwidth measurements
+int brie_host_convert_u16(const float *src, int64_t rows, int64_t cols, int64_t ld, uint16_t *dst, int32_t *not_integral) {
+    if (!not_integral || rows < 0 || cols < 0 || ld < cols) return fail(BRIE_ERR_INVALID, "bad argument");
+    *not_integral = 0;
+    if (rows * cols == 0) return BRIE_OK;
+    if (!src || !dst) return fail(BRIE_ERR_INVALID, "null argument");
+    const int T = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(ingest_threads(), rows)));
+    std::vector<uint32_t> bad(static_cast<size_t>(T), 0u);
+    std::vector<std::thread> pool;
+    auto part = [&](int t) {
+        const int64_t a = rows * t / T, b = rows * (t + 1) / T;
+        bad[static_cast<size_t>(t)] = convert_rows_u16(src + a * ld, ld, b - a, cols, dst + a * cols);
+    };
+    for (int t = 1; t < T; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (std::thread &th : pool) th.join();
+    uint32_t any = 0;
+    for (uint32_t b : bad) any |= b;
+    *not_integral = any ? 1 : 0;
+    return BRIE_OK;
+}
+
 int brie_host_register(void *ptr, int64_t bytes) {
     if (!ptr || bytes <= 0) return fail(BRIE_ERR_INVALID, "bad argument");
     HIP_TRY(hipHostRegister(ptr, static_cast<size_t>(bytes), hipHostRegisterPortable));
@@ -1706,6 +2022,7 @@ int brie_profile_enable(brie_handle *h, int32_t enable) {
     h->ev_used = 0;
     h->prof_ms = 0.0;
     h->prof_launches = 0;
+    h->prof_batched = 0;
     return BRIE_OK;
 }
 
@@ -1721,6 +2038,8 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
         h->prof_launches += 1;
     }
     h->ev_used = 0;
+    h->prof_launches += h->prof_batched;
+    h->prof_batched = 0;
     *kernel_ms_total = h->prof_ms;
     *n_launches = h->prof_launches;
     return BRIE_OK;

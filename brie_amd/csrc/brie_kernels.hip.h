@@ -439,6 +439,130 @@ constexpr float kOneMinusB2 = 1.0f - 0.999f;
 constexpr float kAdamEps = 1e-7f;
 
 // ----------------------------------------------------------------------------
+// gene_finalize: per gene, sum the chunk partials (fp64), Adam for Wc_loc,
+// intercept (clip +-9) and sigma_log, and emit the loss partial sums.
+// ----------------------------------------------------------------------------
+struct FinalizeArgs {
+    const float *partials;      // (n_chunks, S, ld)
+    float *W, *m_W, *v_W;       // (Kc, ld)
+    float *b, *m_b, *v_b;       // (ld)
+    float *lam, *m_lam, *v_lam; // (ld)
+    double *loss_parts;         // (n_blocks, 2): sum KL, sum ll for this step
+    const float *gene_active;   // (ld) 1 = train, 0 = frozen (per-batch convergence)
+    float *ring_kl, *ring_ll;   // (kLossRing, ld) per-gene loss terms of the last steps
+    int64_t ld;
+    int32_t Ng, Kc, n_chunks, train_b, train_lam;
+    int32_t ring_slot, ring_prev;
+    float alpha;
+};
+constexpr int kLossRing = 128;  // >= d2 = 2*min(50, add_iter/2) of model_TFProb.py:248-249
+
+__device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float g, float alpha) {
+    m += (g - m) * kOneMinusB1;
+    v += (g * g - v) * kOneMinusB2;
+    x -= (m * alpha) / (sqrtf(v) + kAdamEps);
+}
+
+// statistic s of gene j: the chunk partials summed in fp64 in chunk order, then what the statistic is for -- Adam on a
+// Wc_loc entry / the intercept (clip) / sigma_log, or the gene's KL / ll term into the loss ring.  Returns the sum
+// (0 for genes beyond Ng).  One body for the gene_finalize kernel and for the fused tail of elbo_adam_step.
+__device__ __forceinline__ double finalize_gene_stat(const FinalizeArgs &a, int j, int s) {
+    const int S = a.Kc + 4;
+    double t = 0.0;
+    if (j < a.Ng && a.gene_active[j] == 0.0f) {
+        // frozen gene: parameters untouched, its last loss terms are carried forward
+        if (s >= a.Kc + 2) {
+            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
+            const float last = ring[static_cast<int64_t>(a.ring_prev) * a.ld + j];
+            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = last;
+            t = static_cast<double>(last);
+        }
+    } else if (j < a.Ng) {
+        const float *p = a.partials + static_cast<int64_t>(s) * a.ld + j;
+        const int64_t stride = static_cast<int64_t>(S) * a.ld;
+        int c = 0;
+        for (; c + 8 <= a.n_chunks; c += 8) {
+            float x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += static_cast<double>(x[u]);
+        }
+        for (; c < a.n_chunks; ++c) t += static_cast<double>(p[c * stride]);
+        if (s < a.Kc) {
+            const int64_t o = static_cast<int64_t>(s) * a.ld + j;
+            float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
+            adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);            // dL/dW = -Xc^T r
+            a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
+        } else if (s == a.Kc) {
+            if (a.train_b) {
+                float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
+                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/db = -sum r
+                x = fminf(fmaxf(x, -9.0f), 9.0f);
+                a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
+            }
+        } else if (s == a.Kc + 1) {
+            if (a.train_lam) {
+                float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
+                adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
+                a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
+            }
+        } else {
+            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
+            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = static_cast<float>(t);
+        }
+    }
+    return t;
+}
+
+// fp64 sum over the 256 threads of a workgroup, the same tree for every caller (deterministic loss partials)
+__device__ __forceinline__ double block_sum_f64(double *sh, double t) {
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double tot = sh[0];
+    __syncthreads();
+    return tot;
+}
+
+// Launch-bound problems (configs[0]: 26 workgroups, two dependent ~6 us kernels per step): the per-gene finalize runs
+// INSIDE the step kernel.  Every workgroup of a gene block takes a ticket when its chunk's partial row is written and
+// visible device-wide; the one that draws the last ticket sums the block's partials and applies Adam exactly as
+// gene_finalize would (same body, same fp64 orders: bit-identical), then re-arms the ticket.  One launch per step.
+// The kernel takes a POINTER to the step's FusedFinalize in device memory (null: off -- the separate gene_finalize
+// launch follows, as for every problem that fills the GPU, where the last workgroup's finalize would be a serial tail
+// behind 15 000 streaming workgroups).  A pointer, not the struct by value: 170 more bytes of kernel arguments made
+// the compiler load them in the prologue and spill 43 SGPRs around the row loop of the headline instantiation.
+struct FusedFinalize {
+    FinalizeArgs fin;
+    int *tickets;               // (gene_blocks), zero between launches
+};
+static_assert(kBlock == kGenesPerBlock, "the fused finalize maps thread t of the last workgroup to gene t of the block");
+template <int S>
+__device__ __forceinline__ void fused_finalize_tail(const FusedFinalize &ff, int gb, int n_chunk_groups) {
+    __shared__ int is_last;
+    __shared__ double sh[kBlock];
+    __threadfence();                                   // this workgroup's partial row: visible to the whole device
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(ff.tickets + gb, 1) == n_chunk_groups - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();                                   // ... and everybody else's rows to this one
+    if (threadIdx.x == 0) ff.tickets[gb] = 0;          // re-armed for the next launch
+    const int j = gb * kBlock + static_cast<int>(threadIdx.x);
+    for (int s = 0; s < S; ++s) {
+        const double t = finalize_gene_stat(ff.fin, j, s);
+        if (s >= S - 2) {                              // KL / ll rows: the block's fp64 partial of the step's loss
+            const double tot = block_sum_f64(sh, t);
+            if (threadIdx.x == 0) ff.fin.loss_parts[2 * gb + (s - (S - 2))] = tot;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // elbo_adam_step: one fused pass = ELBO forward + gradient + Adam for Z_loc,
 // Z_std_log + per-gene sufficient statistics.  Algorithmic HBM traffic per
 // element: read L counts + read/write mu, rho + read/write 4 moments
@@ -457,14 +581,18 @@ constexpr float kAdamEps = 1e-7f;
 // from the PRIOR N(m, sigma), the samples are combined with an online log-mean-exp, q = sum_k w_k dl/dz_k takes the
 // place of the residual r in every prior-parameter statistic (and -q_eps sigma that of the sigma statistic), there is
 // no KL term and the posterior arrays are neither read nor written.  (Uncoupled Kc <= 8 models use margin_step.)
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
+// FUSED: the per-gene finalize runs in this kernel's tail (FusedFinalize, launch-bound problems).  A template flag, not
+// a run-time one: with the tail merely guarded by a null check the compiler scheduled and allocated the row loop of the
+// headline instantiation differently (1 400 of its 1 368 instructions moved); FUSED = false compiles the kernel as before.
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false,
+          bool FUSED = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
-    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
+    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf, const FusedFinalize *__restrict__ ffp) {
     static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
     static_assert(!GW || CPL, "GW is the coupled variant for Kg > 4");
     extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
@@ -483,7 +611,10 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
-    if (a.block_active[gb] == 0) return;                 // whole gene block frozen (workgroup-uniform)
+    if (a.block_active[gb] == 0) {                       // whole gene block frozen (workgroup-uniform)
+        if constexpr (FUSED) fused_finalize_tail<S>(*ffp, gb, static_cast<int>(gridDim.y));   // carries its losses forward
+        return;
+    }
     if constexpr (WIDE) {
         for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
             wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
@@ -875,94 +1006,21 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             st4(dst + s * a.ld, o);
         }
     }
+    if constexpr (FUSED) fused_finalize_tail<S>(*ffp, gb, static_cast<int>(gridDim.y));
 }
 
 #ifdef BRIE_HOST_TU   // non-template kernels: defined once, in brie_capi.hip's translation unit
-// ----------------------------------------------------------------------------
-// gene_finalize: per gene, sum the chunk partials (fp64), Adam for Wc_loc,
-// intercept (clip +-9) and sigma_log, and emit the loss partial sums.
-// ----------------------------------------------------------------------------
-struct FinalizeArgs {
-    const float *partials;      // (n_chunks, S, ld)
-    float *W, *m_W, *v_W;       // (Kc, ld)
-    float *b, *m_b, *v_b;       // (ld)
-    float *lam, *m_lam, *v_lam; // (ld)
-    double *loss_parts;         // (n_blocks, 2): sum KL, sum ll for this step
-    const float *gene_active;   // (ld) 1 = train, 0 = frozen (per-batch convergence)
-    float *ring_kl, *ring_ll;   // (kLossRing, ld) per-gene loss terms of the last steps
-    int64_t ld;
-    int32_t Ng, Kc, n_chunks, train_b, train_lam;
-    int32_t ring_slot, ring_prev;
-    float alpha;
-};
-constexpr int kLossRing = 128;  // >= d2 = 2*min(50, add_iter/2) of model_TFProb.py:248-249
-
-__device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float g, float alpha) {
-    m += (g - m) * kOneMinusB1;
-    v += (g * g - v) * kOneMinusB2;
-    x -= (m * alpha) / (sqrtf(v) + kAdamEps);
-}
-
 // grid = (gene blocks of 256, S): thread (j, s) owns statistic s of gene j, so every (gene, stat)
 // chunk column is summed by its own thread with 8 independent loads in flight.
 __global__ __launch_bounds__(kBlock) void gene_finalize(const FinalizeArgs a) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     const int s = blockIdx.y;
-    const int S = a.Kc + 4;
-    double t = 0.0;
-    if (j < a.Ng && a.gene_active[j] == 0.0f) {
-        // frozen gene: parameters untouched, its last loss terms are carried forward
-        if (s >= a.Kc + 2) {
-            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
-            const float last = ring[static_cast<int64_t>(a.ring_prev) * a.ld + j];
-            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = last;
-            t = static_cast<double>(last);
-        }
-    } else if (j < a.Ng) {
-        const float *p = a.partials + static_cast<int64_t>(s) * a.ld + j;
-        const int64_t stride = static_cast<int64_t>(S) * a.ld;
-        int c = 0;
-        for (; c + 8 <= a.n_chunks; c += 8) {
-            float x[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = p[(c + u) * stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t += static_cast<double>(x[u]);
-        }
-        for (; c < a.n_chunks; ++c) t += static_cast<double>(p[c * stride]);
-        if (s < a.Kc) {
-            const int64_t o = static_cast<int64_t>(s) * a.ld + j;
-            float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
-            adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);            // dL/dW = -Xc^T r
-            a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
-        } else if (s == a.Kc) {
-            if (a.train_b) {
-                float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
-                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/db = -sum r
-                x = fminf(fmaxf(x, -9.0f), 9.0f);
-                a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
-            }
-        } else if (s == a.Kc + 1) {
-            if (a.train_lam) {
-                float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
-                adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
-                a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
-            }
-        } else {
-            float *ring = s == a.Kc + 2 ? a.ring_kl : a.ring_ll;
-            ring[static_cast<int64_t>(a.ring_slot) * a.ld + j] = static_cast<float>(t);
-        }
-    }
+    const double t = finalize_gene_stat(a, j, s);
     if (s < a.Kc + 2) return;                      // uniform per block: only the KL / ll rows reduce further
     // block reduction in fp64 -> one deterministic partial per (block, term)
     __shared__ double sh[kBlock];
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    for (int st = kBlock / 2; st > 0; st >>= 1) {
-        if (static_cast<int>(threadIdx.x) < st) sh[threadIdx.x] += sh[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) a.loss_parts[2 * blockIdx.x + (s - a.Kc - 2)] = sh[0];
+    const double tot = block_sum_f64(sh, t);
+    if (threadIdx.x == 0) a.loss_parts[2 * blockIdx.x + (s - a.Kc - 2)] = tot;
 }
 
 #endif  // BRIE_HOST_TU
@@ -1554,6 +1612,42 @@ __global__ void scatter_sparse(const int64_t *indptr, const int32_t *indices, co
     }
 }
 
+// Staged host ingest (brie_upload of a count layer in pageable host memory): rows [r0, r0 + rows) of the caller's
+// row-major (Nc, Ng) layer arrive in a device staging slab -- as u16 when the host found only integers in [0, 65535]
+// in the slab (half the bytes over PCIe), else as the fp32 values themselves -- and are written into the tiled fp32
+// layer.  The fp32 value stored is the uploaded value bit for bit either way.
+__global__ void ingest_slab(const void *slab, int is_f32, float *dst, int r0, int rows, int Ng, int gene_blocks,
+                            int64_t row_stride, int64_t gb_stride) {
+    const int64_t total = static_cast<int64_t>(gene_blocks) * rows * kWave;
+    const bool vec_ok = (Ng % kVec) == 0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int lane = static_cast<int>(i % kWave);
+        const int g = static_cast<int>((i / kWave) % gene_blocks);        // gene blocks fastest: a slab row is read contiguously
+        const int rl = static_cast<int>(i / (static_cast<int64_t>(kWave) * gene_blocks));
+        const int j0 = (g * kWave + lane) * kVec;
+        if (j0 >= Ng) continue;
+        const int64_t so = static_cast<int64_t>(rl) * Ng + j0;
+        F4 o = {{0.f, 0.f, 0.f, 0.f}};
+        if (is_f32) {
+            const float *p = static_cast<const float *>(slab) + so;
+            if (vec_ok) o = ld4(p);
+            else
+                for (int v = 0; v < kVec && j0 + v < Ng; ++v) o.v[v] = p[v];
+        } else {
+            const uint16_t *p = static_cast<const uint16_t *>(slab) + so;
+            if (vec_ok) {
+                const uint2 u = *reinterpret_cast<const uint2 *>(p);
+#pragma unroll
+                for (int v = 0; v < kVec; ++v) o.v[v] = u16_lane(u, v);
+            } else {
+                for (int v = 0; v < kVec && j0 + v < Ng; ++v) o.v[v] = static_cast<float>(p[v]);
+            }
+        }
+        st4(dst + g * gb_stride + static_cast<int64_t>(r0 + rl) * row_stride + lane * kVec, o);
+    }
+}
+
 // flag[gene quad]: bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255; bit 2: some
 // value is negative / NaN / inf.  Nc_tiled = Nc for the tiled layer, 0 (one flag word) for the row-major layout.
 __global__ void count_range_check(const float *c, int64_t n4, int Nc_tiled, int *flag) {
@@ -1743,8 +1837,11 @@ struct LogLikArgs {
     const float *b, *lam, *cb, *clam;   // gene-mode / cell-mode intercept and log sigma
     const float *effL;                  // (6, ld) or null rows unused for kLik2
     float *out;
+    float *kl_out;                      // get_loss: KL(q || prior) of every entry, row-major (Nc, Ng); null = not wanted
     int64_t ld, row_stride, gb_stride;
     int32_t Nc, Ng, gene_blocks, mode, margin, cell_mode, n_mc;
+    int32_t by_draw;                    // 0: sample k is keyed (draw, k) like the MC samples of one step;
+                                        // 1: (draw + k, 0) like n_mc consecutive single-sample evaluations (get_loss, ELBO)
     uint32_t seed_lo, seed_hi, draw, quad_offset;
 };
 __global__ void loglik_mc_export(const LogLikArgs a) {
@@ -1779,7 +1876,8 @@ __global__ void loglik_mc_export(const LogLikArgs a) {
         for (int v = 0; v < kVec; ++v) { M[v] = -INFINITY; S[v] = 0.0f; }
         for (int k = 0; k < a.n_mc; ++k) {
             float e[kVec];
-            normal4(a.quad_offset + q, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+            normal4(a.quad_offset + q, static_cast<uint32_t>(r), a.draw + (a.by_draw ? static_cast<uint32_t>(k) : 0u),
+                    a.by_draw ? 0u : static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 const float z = fmaf(scale[v], e[v], loc[v]);
@@ -1805,7 +1903,67 @@ __global__ void loglik_mc_export(const LogLikArgs a) {
         if (vec_ok) st4(dst, o);
         else
             for (int v = 0; v < kVec && j0 + v < a.Ng; ++v) dst[v] = o.v[v];
+        if (a.kl_out) {     // tfd.kl_divergence(Normal(mu, s), Normal(m, sigma)) per entry (model_TFProb.py:208)
+            F4 kl;
+#pragma unroll
+            for (int v = 0; v < kVec; ++v) {
+                const float m = (a.prior_m ? a.prior_m[off + v] : 0.0f) + (a.cell_mode ? a.cb[r] : a.b[j0 + v]);
+                const float lam = a.cell_mode ? a.clam[r] : a.lam[j0 + v];
+                const float d = a.mu[off + v] - m, dl = a.rho[off + v] - lam;
+                kl.v[v] = 0.5f * d * d * expf(-2.0f * lam) + 0.5f * expm1f(2.0f * dl) - dl;
+            }
+            float *kd = a.kl_out + static_cast<int64_t>(r) * a.Ng + j0;
+            if (vec_ok) st4(kd, kl);
+            else
+                for (int v = 0; v < kVec && j0 + v < a.Ng; ++v) kd[v] = kl.v[v];
+        }
     }
+}
+
+// get_loss(axis) (model_TFProb.py:206-211): reduce_sum(KL, axis) - reduce_sum(ll, axis) of row-major (Nc, Ng) entry
+// terms, each sum in fp64 and in a fixed order.  kl == null: marginLik (no KL term, ll = log-mean-exp).
+// axis 0: partial[c][t][j] over the rows of chunk c, then the chunks in order.
+__global__ void loss_axis0_partial(const float *kl, const float *ll, double *part, int Nc, int Ng, int rows_per_chunk) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ng) return;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(r0 + rows_per_chunk, Nc);
+    double skl = 0.0, sll = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        if (kl) skl += static_cast<double>(kl[static_cast<int64_t>(r) * Ng + j]);
+        sll += static_cast<double>(ll[static_cast<int64_t>(r) * Ng + j]);
+    }
+    part[(static_cast<int64_t>(blockIdx.y) * 2 + 0) * Ng + j] = skl;
+    part[(static_cast<int64_t>(blockIdx.y) * 2 + 1) * Ng + j] = sll;
+}
+__global__ void loss_axis0_final(const double *part, float *out, int Ng, int n_chunks) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= Ng) return;
+    double skl = 0.0, sll = 0.0;
+    for (int c = 0; c < n_chunks; ++c) {
+        skl += part[(static_cast<int64_t>(c) * 2 + 0) * Ng + j];
+        sll += part[(static_cast<int64_t>(c) * 2 + 1) * Ng + j];
+    }
+    out[j] = static_cast<float>(skl - sll);
+}
+// axis 1: one workgroup per cell, threads stride over the genes, fp64 tree in LDS
+__global__ __launch_bounds__(kBlock) void loss_axis1(const float *kl, const float *ll, float *out, int Nc, int Ng) {
+    __shared__ double sh[2][kBlock];
+    const int r = blockIdx.x;
+    double skl = 0.0, sll = 0.0;
+    for (int j = threadIdx.x; j < Ng; j += kBlock) {
+        if (kl) skl += static_cast<double>(kl[static_cast<int64_t>(r) * Ng + j]);
+        sll += static_cast<double>(ll[static_cast<int64_t>(r) * Ng + j]);
+    }
+    sh[0][threadIdx.x] = skl; sh[1][threadIdx.x] = sll;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if (static_cast<int>(threadIdx.x) < st) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + st];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[r] = static_cast<float>(sh[0][0] - sh[1][0]);
 }
 
 __global__ void exp_vec(const float *src, float *dst, int n) {

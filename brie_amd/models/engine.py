@@ -11,9 +11,9 @@ Deviations from the reference (documented in DESIGN.md):
    reference is unseeded); `seed=` is a new optional argument;
  * all genes of a shard are fitted concurrently (the reference loops over
    ~`batch_size/Nc`-gene batches); convergence is decided on the shard's summed
-   loss trace;
- * gene features (`Kg <= 4`) and `intercept_mode='cell'` couple the genes of a fit: a gene shard then
-   needs `comm=` for the per-step all-reduce; `target='marginLik'` is supported for uncoupled models.
+   loss trace, or per reference-sized batch with `conv_batch_genes` (what fitBRIE passes);
+ * gene features (`Kg <= 64`) and `intercept_mode='cell'` couple the genes of a fit: a gene shard then
+   needs `comm=` for the per-step all-reduce; `target='marginLik'` works for every model variant.
 """
 import time
 
@@ -151,7 +151,10 @@ class BRIE2(object):
         as uploaded / pseudo-counted / compacted, brie_reconfigure replaces what depends on Kc and the seed."""
         other, self._reuse = self._reuse, None
         sh = getattr(other, "_shard", None)
-        if sh is None or not hasattr(sh, "reconfigure"):
+        if sh is None:
+            return None
+        if not hasattr(sh, "reconfigure"):
+            other.close()
             return None
         same = (other.Nc == self.Nc and other.Ng == self.Ng and other.Kg == self.Kg and other._n_layers == n_layers
                 and other._cell_mode == self._cell_mode and other.gene_offset == self.gene_offset
@@ -159,6 +162,10 @@ class BRIE2(object):
                 and other.effLen is self.effLen and other._pseudo_count == self._pseudo_count
                 and other._same_layers(count_layers[:n_layers]))
         if not same:
+            # `reuse` hands the earlier model's device memory over either way: when its handle cannot be adopted
+            # (other intercept mode, other layers, ...) it is released BEFORE this model allocates its own shard, so
+            # two full shards are never resident at once (its results were read by the caller already)
+            other.close()
             return None
         other._shard = None                                   # the handle changes owner
         sh.reconfigure(self.Kc, self.seed, self._intercept_value is None, self._sigma_value is None)
@@ -197,22 +204,21 @@ class BRIE2(object):
     def _start_result_buffers(self, sh):
         """Host destinations of Psi / Z_std / Psi95CI / Z_loc (what BRIE_RV reads, model_wrap.py:28-35), allocated
         when the fit starts and first-touched by a background thread while the GPU optimises: the page faults of
-        16 GB of fresh host memory (configs[2]) leave the critical path."""
+        16 GB of fresh host memory (configs[2]) leave the critical path.  The buffers stay PAGEABLE: page-locking
+        them (brie_host_register) would let the copy engine write at PCIe speed, but registering GBs of user memory
+        while kernels run stalls the device queues (measured: +1.0 s on the 996 steps of configs[2],
+        profiles/r02d_e2e_fit_c3_pinned_while_running.json)."""
         import threading
         bufs = {w: np.empty((self.Nc, self.Ng), np.float32) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
-        pinned = []
 
         def touch():
-            # first touch only.  Page-locking them instead (brie_host_register) would let the copy engine write at
-            # PCIe speed, but registering GBs of user memory while kernels run stalls the device queues (measured:
-            # +1.0 s on the 996 steps of configs[2], profiles/r02d_e2e_fit_c3_pinned_while_running.json)
             for a in bufs.values():
                 a.fill(0)
         th = None
-        if getattr(sh, "pins_host", False):
+        if getattr(sh, "first_touch_results", False):
             th = threading.Thread(target=touch, daemon=True)
             th.start()
-        return bufs, pinned, th
+        return bufs, th
 
     def _need(self):
         if self._shard is None:
@@ -301,27 +307,35 @@ class BRIE2(object):
 
     # ------------------------------------------------------------------ loss (model_TFProb.py:194-211)
     def get_loss(self, count_layers, target="ELBO", axis=None, **kwargs):
-        """One stochastic evaluation of the ELBO loss (no parameter update).
+        """One stochastic evaluation of the loss (no parameter update), model_TFProb.py:194-211.
 
-        axis=None -> scalar, axis=0 -> per gene.  Advances the noise stream by MC_size draws.
+        axis=None -> scalar, axis=0 -> per gene (Ng,), axis=1 -> per cell (Nc,); `MC_size` samples.
+        target="ELBO": sum KL - sum mean_k ll(z_k); linear in the samples, so it is evaluated as the mean of MC_size
+        single-sample evaluations at consecutive draw ids (one read of the data; the noise stream advances by MC_size).
+        target="marginLik": -sum log-mean-exp_k ll(z_k), z_k ~ prior (:202-205), the MC_size samples of ONE draw id.
         """
         if target not in ("ELBO", "marginLik"):
             raise ValueError("target=%r" % (target,))
+        if axis not in (None, 0, 1):
+            raise ValueError("axis=%r (None, 0 or 1: the loss terms are (Nc, Ng) matrices)" % (axis,))
         sh = self._ensure_shard(count_layers, self.Xc, self.Xg)
-        sh.set_target(target)
         mc = int(kwargs.get("MC_size", 1))
         if mc < 1:
             raise ValueError("MC_size=%r" % (mc,))
-        if mc != 1 and target == "marginLik":
-            raise NotImplementedError("get_loss(target='marginLik') outside fit supports MC_size=1")
-        # ELBO: KL - mean_k ll(z_k) is linear in the samples, i.e. the mean of MC_size single-sample evaluations
-        # (one read of the data, MC_size draws in registers; the noise stream advances by MC_size draws)
-        lg = sh.loss_gene(mc)
+        saved = getattr(self, "target", "ELBO")
+        sh.set_target(target)
+        try:
+            if axis == 1 or (target == "marginLik" and mc != 1):
+                if not hasattr(sh, "get_loss"):
+                    raise NotImplementedError("this backend has no per-entry loss accessor")
+                lg = sh.get_loss(mc, 1 if axis == 1 else 0)          # per-entry terms, reduced along `axis` (brie_get_loss)
+            else:
+                lg = sh.loss_gene(mc)                                # one pass, MC_size draws in registers
+        finally:
+            sh.set_target(saved)
         if axis is None:
             return _wrap(np.float32(lg.astype(np.float64).sum()))
-        if axis == 0:
-            return _wrap(lg)
-        raise NotImplementedError("axis=%r" % (axis,))
+        return _wrap(lg)
 
     # ------------------------------------------------------------------ fit (model_TFProb.py:214-273)
     def fit(self, count_layers, Xc=None, Xg=None, target="ELBO", optimizer=None, learn_rate=0.05,
@@ -344,8 +358,11 @@ class BRIE2(object):
         instead of taking new convergence decisions -- the companion fits of a common-noise LRT stop where the base
         model stopped, so both evaluate the same stretch of the noise stream.
         prefetch_results: stream Psi, Z_std, Psi95CI and Z_loc to the host while the final 500-draw loss_gene pass
-        runs (one export pass, page-locked destinations prepared during the fit); the attributes then return those
-        arrays.  False: nothing is read until an attribute is asked for.
+        runs (one export pass into pageable destinations that were allocated when the fit started and first-touched
+        by a background thread during it); the attributes then return those arrays.  Host memory: four (Nc, Ng)
+        float32 arrays are allocated by EVERY fit -- 16 GB at configs[2] -- whether or not the caller reads them;
+        pass False when only loss_gene / the per-gene vectors are wanted (fit_BRIE_matrix does for its companion
+        models): nothing is read until an attribute is asked for.
         """
         start_time = time.time()
         if target not in ("ELBO", "marginLik"):
@@ -447,23 +464,23 @@ class BRIE2(object):
         tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s, "stage_s": stage_s}
         t0 = time.time()
         if staging is not None:              # results stream out on a second stream while loss_gene computes
-            bufs, pinned, th = staging
+            bufs, th = staging
             if th is not None:
                 th.join()
             tm["wait_for_first_touch_s"] = time.time() - t0
             sh.read_results_async(bufs[_capi.PSI], bufs[_capi.Z_STD], bufs[_capi.PSI95CI], bufs[_capi.Z_LOC])
         t0 = time.time()
-        self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))            # model_TFProb.py:261-264
-        tm["loss_gene_s"] = time.time() - t0
+        try:
+            self.loss_gene = _wrap(sh.loss_gene(n_loss_gene))        # model_TFProb.py:261-264
+        finally:
+            # the export worker writes into `bufs`: it is waited for on every path out of here (an exception in
+            # loss_gene, KeyboardInterrupt) before the buffers or the handle can go away
+            if staging is not None:
+                t1 = time.time()
+                sh.read_wait()
+                tm["read_wait_s"] = time.time() - t1
+        tm["loss_gene_s"] = time.time() - t0 - tm.get("read_wait_s", 0.0)
         if staging is not None:
-            t0 = time.time()
-            sh.read_wait()
-            tm["read_wait_s"] = time.time() - t0
-            t0 = time.time()
-            for a in pinned:
-                _capi.host_unregister(a)
-            tm["unpin_s"] = time.time() - t0
-            tm["pinned_arrays"] = len(pinned)
             self._results = bufs
         self.losses = _wrap(losses)
         self.n_iter = n_iter

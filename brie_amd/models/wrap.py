@@ -266,7 +266,9 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
                                comm=None if separable else comm, **keyargs)
 
     g_lo, g_hi = 0, Ng
-    sharded = comm is not None and comm.world > 1
+    # (a communicator of ONE rank shards nothing; `always_gather` lets a 1-GPU box drive the sharded branch -- trace
+    #  all-reduce, end-of-fit gather -- through RCCL anyway: tests/test_gpu_comm.py)
+    sharded = comm is not None and (comm.world > 1 or getattr(comm, "always_gather", False))
     n_batch_genes = int(np.ceil(batch_size / Nc))                     # model_wrap.py:242
     ranges = [(0, Ng)]
     if sharded:
@@ -284,7 +286,11 @@ def fitBRIE(adata, Xc=None, Xg=None, intercept=None, intercept_mode='gene', LRT_
                              % (Ng, comm.world))
         ranges = [gene_shard(Ng, r, comm.world, align) for r in range(comm.world)]
         g_lo, g_hi = ranges[comm.rank]
-        if not emulate_batches:       # literal sequential batches are independent fits: nothing is exchanged in the loop
+        # Only the literal independent batch loop (separable AND emulate_batches) exchanges nothing inside the fit.  A
+        # coupled model ignores emulate_batches -- it is ONE sharded fit with a per-step all-reduce -- and must take its
+        # stopping decisions on the loss summed over ranks like every other sharded fit, or the ranks extend a different
+        # number of rounds and their collectives no longer pair up.
+        if not (separable and emulate_batches):
             keyargs = dict(keyargs, trace_reduce=comm.allreduce_sum, conv_total_genes=Ng)
 
     parts = [(g_lo, g_hi)]

@@ -89,9 +89,15 @@ class GeneComm(object):
     def _ranges(self, Ng, ranges):
         return [gene_shard(Ng, r, self.world) for r in range(self.world)] if ranges is None else list(ranges)
 
-    def allgather_genes(self, local, Ng, ranges=None):
+    def allgather_genes(self, local, Ng, ranges=None, native=None):
         """local (k, n_local) per-gene rows -> (k, Ng) on every rank.  `ranges`: the [g0, g1) of every rank
-        (default: gene_shard with quad alignment)."""
+        (default: gene_shard with quad alignment).
+
+        The end-of-fit gather of a gene-sharded fit (BASELINE's "RCCL weight all-gather"; replaces the `concate` of
+        model_wrap.py:260).  native=None: through the library's own communicator (`brie_comm_allgather`: librccl
+        called from libbrie_amd.so) whenever it exists, i.e. when the process group runs on RCCL; torch.distributed
+        otherwise (gloo: CPU tests, two ranks sharing a GPU).  native=False forces the torch path, True demands the
+        library's."""
         import torch
         local = np.asarray(local, np.float32)
         if local.ndim == 1:
@@ -100,6 +106,13 @@ class GeneComm(object):
         per = max(b - a for a, b in ranges)
         buf = np.zeros((local.shape[0], per), np.float32)
         buf[:, :local.shape[1]] = local
+        nat = self.native_comm() if native in (None, True) else None
+        if native is True and nat is None:
+            raise RuntimeError("no native communicator: the process group runs on %s, not on RCCL" % self.backend)
+        self.last_gather_path = "brie_comm_allgather" if nat is not None else "torch.distributed"
+        if nat is not None:
+            g = nat.allgather(buf).reshape(self.world, local.shape[0], per)
+            return np.concatenate([g[r][:, :b - a] for r, (a, b) in enumerate(ranges)], axis=1)
         t = self._tensor(buf)
         out = [torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)

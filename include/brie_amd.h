@@ -209,6 +209,14 @@ int brie_loss_gene(brie_handle *h, int32_t n_repeats, float *out);
  * with z ~ prior (target marginLik, :157,188-189).  Consumes one noise draw id (samples k = 0..size-1). */
 int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld);
 
+/* BRIE2.get_loss(count_layers, target, axis, MC_size) (model_TFProb.py:194-211) as ONE stochastic evaluation on the
+ * current state, no update: reduce_sum(KL, axis) - reduce_sum(mean_k ll(z_k), axis) for target ELBO, -reduce_sum(
+ * log-mean-exp_k ll(z_k), axis) for marginLik (:202-205), each sum in fp64.  axis 0 -> out[Ng] (per gene), axis 1 ->
+ * out[Nc] (per cell); the scalar of axis=None is the sum of either.  Noise: ELBO takes its mc_size samples at mc_size
+ * consecutive draw ids (the loss is linear in them: identical to brie_loss_gene(mc_size) per gene); marginLik takes
+ * them at ONE draw id (k = 0..mc_size-1), like a step with that MC_size.  An accessor (per-entry temporaries). */
+int brie_get_loss(brie_handle *h, int32_t mc_size, int32_t axis, float *out);
+
 /* BRIE_RV.__init__ (model_wrap.py:18-40): copy state / derived arrays out. */
 int brie_read(brie_handle *h, int which, float *dst,
               int64_t rows, int64_t cols, int64_t ld);
@@ -225,6 +233,16 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
 int brie_read_wait(brie_handle *h);
 int brie_host_register(void *ptr, int64_t bytes);
 int brie_host_unregister(void *ptr);
+
+/* Host ingest of the count layers (the reference densifies and casts on the host, model_wrap.py:108-111, and hands
+ * TF pageable fp32 arrays).  brie_upload of a count layer that lives in PAGEABLE host memory and holds >= 16 M entries
+ * goes through a staged pipeline: a few host threads convert row slabs to u16 in page-locked buffers (a slab holding
+ * anything but integers in [0, 65535] travels as fp32), each slab's copy runs asynchronously while the next is being
+ * converted, a kernel writes it into the tiled fp32 layer.  Bit-identical to the plain copy; BRIE_INGEST=direct|staged
+ * forces either, BRIE_INGEST_THREADS sets the thread count (default: the cores of the process, at most 8).
+ * brie_host_convert_u16 is the host half on its own (tests, host-bandwidth measurements; no GPU involved):
+ * dst[r][c] = (uint16) src[r*ld + c], *not_integral = 1 when some value is not a non-negative integer <= 65535. */
+int brie_host_convert_u16(const float *src, int64_t rows, int64_t cols, int64_t ld, uint16_t *dst, int32_t *not_integral);
 
 /* Noise-draw counter (one draw id per loss evaluation). */
 int brie_get_draw(brie_handle *h, uint32_t *draw);

@@ -191,3 +191,12 @@ int brie_oracle_threads(void) {
     return 1;
 #endif
 }
+
+/* torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks: the cpu_baseline leg of bench.py sets the count itself */
+void brie_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}

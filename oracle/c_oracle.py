@@ -85,3 +85,8 @@ class COracle(object):
 
     def threads(self):
         return int(self.lib.brie_oracle_threads())
+
+    def set_threads(self, n):
+        """OpenMP threads of the fused pass (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks)."""
+        self.lib.brie_oracle_set_threads(ctypes.c_int(int(n)))
+        return self.threads()

@@ -48,7 +48,18 @@ CASES = {
                    desc="configs[2] 50k cells, Kc=3: 32-gene sample over all cells, 996 steps, MC_size 1"),
     "c3_cli": dict(Nc=50000, Ng=16, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3,
                    desc="configs[2]: 16-gene sample over all cells, 4998 steps, MC_size 3"),
+    # round 3: the samples the parity rule is frozen on -- hundreds of genes over ALL cells
+    "c3_api_512": dict(Nc=50000, Ng=512, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1,
+                       desc="configs[2] 50k cells, Kc=3: 512 genes of the recipe over all cells, 996 steps, MC_size 1"),
+    "c2_api_512": dict(Nc=10000, Ng=512, Kc=1, L=3, theta=1.5, min_iter=1000, MC=1,
+                       desc="configs[1] 10k cells, effLen, Kc=1: 512 genes over all cells, 996 steps, MC_size 1"),
+    "c3_cli_128": dict(Nc=50000, Ng=128, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3,
+                       desc="configs[2]: 128 genes over all cells, brie-quant schedule: 4998 steps, MC_size 3"),
+    "c2_cli_128": dict(Nc=10000, Ng=128, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3,
+                       desc="configs[1]: 128 genes over all cells, brie-quant schedule: 4998 steps, MC_size 3"),
 }
+R03 = ("c1_api", "c1_kc0_api", "c1_cli", "c2_api_512", "c3_api_512", "c2_cli_128", "c3_cli_128")
+PARAMS = ("Wc_loc", "intercept", "sigma_log")
 QUICK = ("c1_api", "c1_kc0_api", "c2_api", "c3_api")
 SEED = 11
 VARIANTS = {"hip": [], "hip_adam": ["BRIE_STRICT_ADAM=1"], "hip_strict": ["BRIE_FAST_MATH=0"]}
@@ -65,12 +76,14 @@ def schedule(min_iter):
     return [(int(min_iter / 6), lr) for lr in LEARNING_RATES]
 
 
-def run_oracle(case, dtype):
+def run_oracle(case, dtype, want_params=False):
     """Psi of the C restatement in `dtype` after the case's full staged schedule (cached)."""
     os.makedirs(CACHE, exist_ok=True)
     path = os.path.join(CACHE, "%s_%s.npz" % (case, np.dtype(dtype).name))
     if os.path.exists(path):
-        return np.load(path)["psi"]
+        z = np.load(path)
+        if all(k in z.files for k in PARAMS) or not want_params:
+            return {k: z[k] for k in z.files if k in PARAMS + ("psi",)}
     from oracle.c_oracle import COracle
     P, c = problem(case)
     t0 = time.time()
@@ -78,10 +91,13 @@ def run_oracle(case, dtype):
     for n, lr in schedule(c["min_iter"]):
         o.reset_optimizer()
         o.minimize(n, lr, c["MC"])
-    psi = np.asarray(o.Psi, np.float64)
-    np.savez_compressed(path, psi=psi, seconds=time.time() - t0)
+    # Psi kept as float32: rounding the fp64 answer to fp32 moves it by <= 6e-8, three orders below the 1e-4 that is
+    # counted, and the cache (which travels to the GPU box) stays at 4 bytes per entry
+    out = {"psi": np.asarray(o.Psi, np.float32), "Wc_loc": np.asarray(o.Wc_loc, np.float64),
+           "intercept": np.asarray(o.intercept, np.float64), "sigma_log": np.asarray(o.sigma_log, np.float64)}
+    np.savez(path, seconds=time.time() - t0, **out)
     print("oracle %s %s: %.1f s" % (case, np.dtype(dtype).name, time.time() - t0), flush=True)
-    return psi
+    return out
 
 
 def run_hip_worker(case, out):
@@ -95,7 +111,8 @@ def run_hip_worker(case, out):
         sh.reset_optimizer()
         sh.step(n, lr, c["MC"], trace=False)
     psi = sh.read(_capi.PSI)
-    np.savez_compressed(out, psi=psi, seconds=time.time() - t0)
+    np.savez(out, psi=psi, seconds=time.time() - t0, Wc_loc=sh.read(_capi.WC_LOC),
+             intercept=sh.read(_capi.INTERCEPT).reshape(-1), sigma_log=sh.read(_capi.SIGMA_LOG).reshape(-1))
     sh.close()
 
 
@@ -130,11 +147,49 @@ def build_variants(names=None):
     return paths
 
 
+def per_gene(psi, par, covered):
+    """Where the exceedances sit: per gene, how many cells lie beyond 1e-4 for HIP-vs-o64, o32-vs-o64 and HIP-vs-o32, and
+    whether one of the gene's OWN parameters (Wc_loc column, intercept, sigma_log) moved by more than 1e-3 between two
+    of the three runs -- a shifted per-gene parameter moves all of the gene's cells at once (the per-gene clusters)."""
+    def ex(a, b):
+        return (np.abs(np.asarray(psi[a], np.float64) - np.asarray(psi[b], np.float64)) > 1e-4)
+
+    def shift(a, b):
+        w = np.abs(np.asarray(par[a]["Wc_loc"], np.float64) - np.asarray(par[b]["Wc_loc"], np.float64))
+        w = w.max(0) if w.size else np.zeros(psi[a].shape[1])
+        return np.maximum(w, np.maximum(
+            np.abs(np.asarray(par[a]["intercept"], np.float64).ravel() - np.asarray(par[b]["intercept"], np.float64).ravel()),
+            np.abs(np.asarray(par[a]["sigma_log"], np.float64).ravel() - np.asarray(par[b]["sigma_log"], np.float64).ravel())))
+    e_h, e_o, e_ho = ex("hip", "o64"), ex("o32", "o64"), ex("hip", "o32")
+    s_h, s_o, s_ho = shift("hip", "o64"), shift("o32", "o64"), shift("hip", "o32")
+    n_h, n_o = int(e_h.sum()), int(e_o.sum())
+    moved_h, moved_o = s_h > 1e-3, s_o > 1e-3
+    out = {
+        "n_entries": int(e_h.size), "n_genes": int(e_h.shape[1]),
+        "exceed_hip_vs_o64": n_h, "exceed_o32_vs_o64": n_o, "exceed_hip_vs_o32": int(e_ho.sum()),
+        "ratio_hip_over_o32": n_h / max(1, n_o),
+        "exceed_covered_hip": int((e_h & covered).sum()), "exceed_covered_o32": int((e_o & covered).sum()),
+        "ratio_covered_hip_over_o32": int((e_h & covered).sum()) / max(1, int((e_o & covered).sum())),
+        "genes_with_an_exceedance": {"hip": int((e_h.sum(0) > 0).sum()), "o32": int((e_o.sum(0) > 0).sum())},
+        "genes_whose_own_parameter_moved_gt_1e-3": {"hip_vs_o64": int(moved_h.sum()), "o32_vs_o64": int(moved_o.sum()),
+                                                    "hip_vs_o32": int((s_ho > 1e-3).sum())},
+        "share_of_exceedances_in_those_genes": {"hip": float(e_h[:, moved_h].sum() / max(1, n_h)),
+                                                "o32": float(e_o[:, moved_o].sum() / max(1, n_o))},
+        "max_per_gene_parameter_shift": {"hip_vs_o64": float(s_h.max()), "o32_vs_o64": float(s_o.max()),
+                                         "hip_vs_o32": float(s_ho.max())},
+        "per_gene": {"exceed_hip": e_h.sum(0).astype(int).tolist(), "exceed_o32": e_o.sum(0).astype(int).tolist(),
+                     "exceed_hip_vs_o32": e_ho.sum(0).astype(int).tolist(),
+                     "param_shift_hip_vs_o64": [float("%.3g" % x) for x in s_h],
+                     "param_shift_o32_vs_o64": [float("%.3g" % x) for x in s_o]},
+    }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_r02.json"))
-    ap.add_argument("--cases", default=",".join(CASES))
-    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_r03.json"))
+    ap.add_argument("--cases", default=",".join(R03))
+    ap.add_argument("--variants", default="hip")
     ap.add_argument("--oracles-only", action="store_true")
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--worker", default=None)
@@ -143,18 +198,22 @@ def main():
     if args.worker:
         run_hip_worker(args.worker, args.worker_out)
         return
+    cases = [c for c in args.cases.split(",") if c]
+    if args.oracles_only:
+        for case in cases:
+            run_oracle(case, np.float32, want_params=True)
+            run_oracle(case, np.float64, want_params=True)
+        return
     libs = build_variants([v for v in args.variants.split(",") if v])
     if args.build_only:
         print(libs)
         return
-    cases = [c for c in args.cases.split(",") if c]
     result = {"seed": SEED, "definition": __doc__.split("\n\n")[2].strip(), "cases": {}}
     for case in cases:
         P, c = problem(case)
         covered = (np.asarray(P["counts"][0]) + np.asarray(P["counts"][1])) > 0
-        psi = {"o32": run_oracle(case, np.float32), "o64": run_oracle(case, np.float64)}
-        if args.oracles_only:
-            continue
+        par = {"o32": run_oracle(case, np.float32, want_params=True), "o64": run_oracle(case, np.float64, want_params=True)}
+        psi = {k: v["psi"] for k, v in par.items()}
         secs = {}
         for v in [v for v in args.variants.split(",") if v]:
             tmp = os.path.join(CACHE, "_%s_%s.npz" % (case, v))
@@ -163,6 +222,7 @@ def main():
                            check=True, env=env)
             z = np.load(tmp)
             psi[v], secs[v] = z["psi"], float(z["seconds"])
+            par[v] = {k: z[k] for k in PARAMS}
             os.remove(tmp)
         pairs = [(v, "o64") for v in psi if v.startswith("hip")] + [(v, "o32") for v in psi if v.startswith("hip")] + \
                 [("o32", "o64")] + [("hip", v) for v in psi if v.startswith("hip_")]
@@ -171,18 +231,19 @@ def main():
                  "zero_coverage_fraction": float(1 - covered.mean()), "hip_seconds": secs, "pairs": {}}
         for a, b in pairs:
             entry["pairs"]["%s_vs_%s" % (a, b)] = summary(psi[a], psi[b], covered)
+        if "hip" in psi:
+            entry["where_the_exceedances_sit"] = per_gene(psi, par, covered)
         result["cases"][case] = entry
         f = entry["pairs"]
+        g = entry.get("where_the_exceedances_sit", {})
         print("%-11s hip-o64 max %.2e p99.9 %.2e frac>1e-4 %.2e | o32-o64 max %.2e p99.9 %.2e frac %.2e | "
-              "strict-o64 max %.2e frac %.2e" % (
+              "HIP/o32 exceedances %.2f (covered %.2f)" % (
                   case, f["hip_vs_o64"]["max"], f["hip_vs_o64"]["p99.9"], f["hip_vs_o64"]["frac_gt_1e-4"],
                   f["o32_vs_o64"]["max"], f["o32_vs_o64"]["p99.9"], f["o32_vs_o64"]["frac_gt_1e-4"],
-                  f.get("hip_strict_vs_o64", {}).get("max", float("nan")),
-                  f.get("hip_strict_vs_o64", {}).get("frac_gt_1e-4", float("nan"))), flush=True)
-    if not args.oracles_only:
-        with open(args.out, "w") as fh:
+                  g.get("ratio_hip_over_o32", float("nan")), g.get("ratio_covered_hip_over_o32", float("nan"))), flush=True)
+        with open(args.out, "w") as fh:            # after every case: a cut-off call still leaves the finished ones
             json.dump(result, fh, indent=1)
-        print("wrote", args.out)
+    print("wrote", args.out)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,24 @@ def test_BRIE2_fit_matches_oracle_fit(lib):
     lg2 = m.get_loss(other, axis=0, MC_size=3)
     np.testing.assert_allclose(lg2.numpy(), o.eval_loss_gene(add_pseudo_count(other), P["Xc"], 3), rtol=2e-3, atol=2e-2)
     assert np.abs(lg2.numpy() - lg.numpy()).max() > 1.0
+    # axis=1 (per cell) and target="marginLik" with several samples (model_TFProb.py:194-205: **kwargs reach logLik_MC,
+    # any axis reaches reduce_sum): same evaluation, other reduction
+    d0 = m._shard.draw
+    g0 = m.get_loss(P["counts"], axis=0, MC_size=2)
+    m._shard.draw = d0
+    g1 = m.get_loss(P["counts"], axis=1, MC_size=2)
+    assert g0.shape == (Ng,) and g1.shape == (Nc,)
+    np.testing.assert_allclose(g1.numpy().astype(np.float64).sum(), g0.numpy().astype(np.float64).sum(), rtol=1e-4)
+    m._shard.draw = d0
+    o.draw = d0
+    mg = m.get_loss(P["counts"], target="marginLik", axis=0, MC_size=3)
+    np.testing.assert_allclose(mg.numpy(), o.margin_loss_and_grads(cnt, P["Xc"], 3, need_grads=False)["loss_gene"],
+                               rtol=5e-3, atol=5e-2)        # (two separately fitted states: prior parameters within 2e-3)
+    assert m._shard.draw == d0 + 1
+    tot = m.get_loss(P["counts"], target="marginLik", MC_size=3)
+    assert np.isfinite(float(tot.numpy())) and tot.numpy().shape == ()
+    with pytest.raises(ValueError):
+        m.get_loss(P["counts"], axis=2)
     m.close()
 
 

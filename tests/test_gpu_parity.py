@@ -503,6 +503,147 @@ def test_loglik_mc_accessor_matches_oracle(lib, target, mode, Kg, Kc, L):
     sh.close()
 
 
+@pytest.mark.parametrize("Nc,Ng,Kc,L,MC", [(200, 500, 0, 2, 1), (200, 500, 1, 2, 3), (70, 1030, 3, 3, 2), (1300, 300, 8, 2, 1)])
+def test_fused_finalize_is_bit_identical_to_the_two_kernel_step(lib, monkeypatch, Nc, Ng, Kc, L, MC):
+    """Launch-bound problems (configs[0]) run the per-gene finalize in the tail of elbo_adam_step behind a
+    last-workgroup-done ticket (brie::FusedFinalize): one launch per step instead of two.  Same body, same fp64
+    summation orders: loss trace, state, per-gene parameters, loss ring and frozen-gene handling must be bit-identical
+    to the separate gene_finalize launch -- which stays the path of every problem that fills the GPU."""
+    from brie_amd import _capi
+    P = util.problem(Nc, Ng, Kc, L, seed=33)
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("BRIE_FUSED_FINALIZE", fused)
+        sh = util.device_shard(P, Nc, Ng, Kc, 5)
+        tr = [sh.step(7, 0.01, MC)]
+        sh.step(5, 0.02, MC, trace=False)                   # enqueue-only calls pipeline across brie_step calls
+        tr.append(sh.step(130, 0.005, MC))                  # more steps than the ring holds
+        win = sh.read_loss_window(20)
+        mask = np.ones(Ng, bool)
+        mask[: Ng // 2] = False                             # freeze half of the genes (whole gene blocks among them)
+        sh.set_gene_mask(mask)
+        tr.append(sh.step(9, 0.01, MC))
+        win2 = sh.read_loss_window(9)
+        sh.set_gene_mask(None)
+        sh.reset_optimizer()
+        tr.append(sh.step(4, 0.001, MC))
+        st = util.device_state(sh)
+        lg = sh.loss_gene(3)
+        sh.profile_enable(True)
+        sh.step(6, 0.001, MC, trace=False)
+        ms, n = sh.profile_read()
+        assert n == 6 and ms > 0.0                          # per launch, or one event pair around the single-kernel steps
+        out[fused] = (np.concatenate(tr), win, win2, st, lg)
+        sh.close()
+    a, b = out["0"], out["1"]
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    for k in a[3]:
+        np.testing.assert_array_equal(a[3][k], b[3][k], err_msg=k)
+    np.testing.assert_array_equal(a[4], b[4])
+    assert np.isfinite(a[0]).all()
+
+
+@pytest.mark.parametrize("Ng,L", [(1000, 2), (515, 3), (4, 2)])
+def test_staged_host_ingest_is_bit_identical_to_the_plain_copy(lib, monkeypatch, Ng, L):
+    """brie_upload of a pageable host count layer through the staged pipeline (host threads convert row slabs to u16 in
+    page-locked buffers, asynchronous copies, a kernel writes the tiled layer; include/brie_amd.h) must leave exactly
+    the layer the plain strided copy leaves: integer slabs travel as u16, a slab with a fractional / huge / negative-zero
+    value as fp32, ragged last slabs, Ng not a multiple of 4."""
+    from brie_amd import _capi
+    Nc, Kc = 333, 1
+    P = util.problem(Nc, Ng, Kc, L, seed=21)
+    cnt = [np.array(c) for c in P["counts"]]
+    cnt[1][8, 2 % Ng] = 300.0                      # > 255: a u16 quad next to u8 quads (the storage tiers still apply)
+
+    def build(mode, slab_rows=None, frac=False):
+        monkeypatch.setenv("BRIE_INGEST", mode)
+        monkeypatch.setenv("BRIE_INGEST_THREADS", "3")
+        if slab_rows:
+            monkeypatch.setenv("BRIE_INGEST_SLAB_ELEMS", str(slab_rows * Ng))
+        layers = [c.copy() for c in cnt]
+        if frac:
+            layers[0][7, 1 % Ng] = 70000.0         # > 65535: this slab travels as fp32 (and the shard stays fp32 storage)
+            layers[0][200, 0] = 2.5                # fractional: its slab too, the others as u16
+            layers[1][301, Ng - 1] = -0.0 if Ng > 1 else 0.0
+        sh = _capi.Shard(Nc, Ng, Kc, n_layers=L, has_efflen=L == 3, seed=9)
+        for l in range(L):
+            sh.upload(_capi.COUNT1 + l, layers[l])
+        got = [sh.read(_capi.COUNT1 + l) for l in range(L)]
+        sh.add_pseudo_count(0.01)
+        if L == 3:
+            sh.upload(_capi.EFFLEN, P["effLen"])
+        sh.upload(_capi.XC, P["Xc"])
+        sh.init_state()
+        tr = sh.step(5, 0.01, 1)
+        out = (got, tr, sh.read(_capi.Z_LOC), sh.count_storage)
+        sh.close()
+        return out, layers
+    for frac in (False, True):
+        (ref, tr_ref, z_ref, st_ref), layers = build("direct", frac=frac)
+        for l in range(L):
+            np.testing.assert_array_equal(ref[l], layers[l])
+        for slab_rows in (50, 64, 400):            # ragged last slab / exact multiple-ish / one slab
+            (got, tr, z, st), _ = build("staged", slab_rows, frac=frac)
+            for l in range(L):
+                assert np.array_equal(got[l], ref[l]) and np.array_equal(np.signbit(got[l]), np.signbit(ref[l])), (l, slab_rows)
+            np.testing.assert_array_equal(tr, tr_ref)
+            np.testing.assert_array_equal(z, z_ref)
+            assert st == st_ref
+
+
+@pytest.mark.parametrize("target,mode,Kg,Kc,L,MC", [("marginLik", "gene", 0, 2, 2, 3), ("marginLik", "cell", 3, 1, 3, 4),
+                                                    ("marginLik", "gene", 0, 10, 2, 3), ("marginLik", "gene", 6, 0, 2, 2),
+                                                    ("ELBO", "gene", 0, 2, 2, 3), ("ELBO", "cell", 2, 1, 3, 1),
+                                                    ("ELBO", "gene", 0, 12, 2, 2)])
+def test_get_loss_per_gene_and_per_cell_match_oracle(lib, target, mode, Kg, Kc, L, MC):
+    """brie_get_loss = BRIE2.get_loss(target, axis, MC_size) (model_TFProb.py:194-211) as one evaluation:
+    target marginLik with MC_size > 1 is -sum log-mean-exp over the samples (:202-205) -- against the oracle's
+    margin_loss_and_grads(need_grads=False) on the same noise; axis=1 sums the (Nc, Ng) terms over genes -- against the
+    oracle's per-entry KL / log-likelihood summed the same way; the two axes of one evaluation have the same total."""
+    from oracle import philox
+    Nc, Ng = 40, 70
+    P = util.problem(Nc, Ng, Kc, L, seed=71)
+    P["Xg"] = np.random.default_rng(9).normal(size=(Ng, Kg)).astype(np.float32) * 0.5
+    o = util.oracle_model(P, Nc, Ng, Kc, 73, np.float64, Kg=Kg, mode=mode)
+    sh = util.device_shard(P, Nc, Ng, Kc, 73, Kg=Kg, mode=mode)
+    o.minimize(P["counts_pc"], P["Xc"], 3, 0.02, 1)
+    sh.step(3, 0.02, 1)
+    for k in util.STATE_KEYS:                      # same state on both sides: this test is about the accessor
+        setattr(o, k, np.asarray(util.device_state(sh)[k], np.float64))
+    sh.set_target(target)
+    cnt = [np.asarray(c, np.float64) for c in P["counts_pc"]]
+    draw = sh.draw
+    per_gene = sh.get_loss(MC, 0)
+    used = sh.draw - draw
+    assert used == (MC if target == "ELBO" else 1)           # ELBO: MC draw ids; marginLik: the MC samples of one
+    sh.draw = draw
+    per_cell = sh.get_loss(MC, 1)
+    assert per_gene.shape == (Ng,) and per_cell.shape == (Nc,)
+    if target == "marginLik":
+        o.draw = draw
+        want = o.margin_loss_and_grads(cnt, P["Xc"], MC, need_grads=False)
+        np.testing.assert_allclose(per_gene, want["loss_gene"], rtol=2e-4, atol=2e-3)
+        eps = np.stack([philox.normal(73, draw, k, Nc, Ng) for k in range(MC)]).astype(np.float64)
+        z = o.prior_mean(P["Xc"])[None] + np.exp(o.sigma_log)[None] * eps
+        ll = np.stack([o.loglik_terms(cnt, z[k])[0] for k in range(MC)])
+        terms = -(ll.max(0) + np.log(np.exp(ll - ll.max(0)).mean(0)))
+    else:
+        eps = np.stack([philox.normal(73, draw + k, 0, Nc, Ng) for k in range(MC)]).astype(np.float64)
+        z = o.Z_loc[None] + o.Z_std[None] * eps
+        ll = np.mean([o.loglik_terms(cnt, z[k])[0] for k in range(MC)], axis=0)
+        d, dl = o.Z_loc - o.prior_mean(P["Xc"]), o.Z_std_log - o.sigma_log
+        terms = 0.5 * d * d * np.exp(-2 * o.sigma_log) + 0.5 * np.expm1(2 * dl) - dl - ll
+        # ... and the fast pass (brie_loss_gene: the same samples in registers) gives the same per-gene values
+        sh.draw = draw
+        np.testing.assert_allclose(sh.loss_gene(MC), per_gene, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(per_gene, terms.sum(0), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(per_cell, terms.sum(1), rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(per_gene.astype(np.float64).sum(), per_cell.astype(np.float64).sum(), rtol=1e-5)
+    sh.close()
+
+
 @pytest.mark.parametrize("Kc,L,MC", [(9, 2, 1), (20, 3, 3), (33, 2, 2)])
 def test_wide_cell_design_matches_oracle(lib, Kc, L, MC):
     """Kc > 8: Wc_loc tile in LDS for Xc.Wc_loc, Xc^T.r reduced by a hand-written v_mfma_f32_32x32x2_f32 kernel."""

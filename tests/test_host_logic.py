@@ -208,6 +208,66 @@ def test_more_ranks_than_gene_quads_is_refused(patched_wrap):
         patched_wrap.fitBRIE(ad, comm=Comm(), **FIT)
 
 
+@pytest.mark.parametrize("coupling", ["Kg", "cell"])
+@pytest.mark.parametrize("emulate", [False, True])
+def test_coupled_sharded_fit_always_decides_on_the_global_loss(patched_wrap, monkeypatch, coupling, emulate):
+    """a COUPLED model (Kg > 0 or intercept_mode='cell') ignores emulate_batches -- it stays one sharded fit
+    with a per-step all-reduce -- so its stopping decisions must be taken on the loss summed over ranks whatever
+    emulate_batches says; a rank-local decision lets the ranks extend a different number of rounds and their
+    collectives no longer pair up.  Only the literal independent batch loop (separable fits) drops the collectives."""
+    class Comm(object):
+        rank, world = 0, 2
+
+        def allreduce_sum(self, a):
+            return np.asarray(a, np.float64)
+        allreduce_min = allreduce_sum
+
+    class Stop(Exception):
+        pass
+    seen = {}
+
+    def recorder(data, **kw):
+        seen.update(kw)
+        raise Stop()
+    monkeypatch.setattr(patched_wrap, "fit_BRIE_matrix", recorder)
+    P = make_problem(12, 16, Kc=1, L=2, seed=3)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    kw = dict(Xg=np.ones((16, 1), np.float32)) if coupling == "Kg" else dict(intercept_mode='cell')
+    comm = Comm()
+    with pytest.raises(Stop):
+        patched_wrap.fitBRIE(ad, Xc=P["Xc"], comm=comm, emulate_batches=emulate, **dict(FIT, **kw))
+    assert seen["trace_reduce"].__func__ is Comm.allreduce_sum and seen["conv_total_genes"] == 16
+    assert seen["comm"] is comm                                   # the per-step all-reduce of the coupled shard
+    # the separable twin: literal batches exchange nothing, the concurrent fit does
+    seen.clear()
+    with pytest.raises(Stop):
+        patched_wrap.fitBRIE(ad, Xc=P["Xc"], comm=comm, emulate_batches=emulate, **FIT)
+    assert ("trace_reduce" in seen) == (not emulate) and seen["comm"] is None
+
+
+def test_staged_ingest_host_half_converts_exactly_or_says_so(built_lib):
+    """brie_host_convert_u16 (the host half of the staged count ingest, include/brie_amd.h): integers in [0, 65535]
+    become u16 exactly; anything else -- fractional (pseudo-counted input), negative, negative zero, > 65535, NaN, inf --
+    is reported, and the slab then travels as the fp32 values themselves."""
+    from brie_amd import _capi
+    rng = np.random.default_rng(3)
+    a = rng.poisson(3.0, (37, 1003)).astype(np.float32)
+    a[5, 7], a[36, 1002] = 65535.0, 300.0
+    out, bad = _capi.host_convert_u16(a)
+    assert not bad and out.dtype == np.uint16
+    np.testing.assert_array_equal(out, a.astype(np.uint16))
+    for val in (0.5, 0.01, -1.0, -0.0, 65536.0, 1e9, np.nan, np.inf, -np.inf):
+        for pos in ((0, 0), (36, 1002), (17, 511)):
+            b = a.copy()
+            b[pos] = val
+            assert _capi.host_convert_u16(b)[1], (val, pos)
+    view = a[:, 3:900]                                            # a row pitch that is not the row length
+    out, bad = _capi.host_convert_u16(view)
+    assert not bad
+    np.testing.assert_array_equal(out, view.astype(np.uint16))
+    assert _capi.host_convert_u16(np.zeros((0, 5), np.float32))[0].shape == (0, 5)
+
+
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):

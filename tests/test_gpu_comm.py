@@ -141,3 +141,47 @@ def test_two_rank_communicator_on_two_gpus(lib, tmp_path):
     np.testing.assert_array_equal(r[0]["Wg"], r[1]["Wg"])
     np.testing.assert_allclose(r[0]["Wg"], ref.read(_capi.WG_LOC), atol=2e-5)
     np.testing.assert_allclose(np.concatenate([r[0]["Z"], r[1]["Z"]], axis=1), ref.read(_capi.Z_LOC), atol=2e-5)
+
+
+def _native_gather_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import brie_amd
+    from brie_amd.sharding import GeneComm
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    P = make_problem(80, 52, Kc=1, L=2, seed=12)
+    kw = dict(LRT_index=[0], min_iter=60, max_iter=60, n_loss_gene=3, verbose=False, seed=5)
+    ref = brie_amd.fitBRIE(FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]}), Xc=P["Xc"], **kw)
+    comm = GeneComm(device=torch.device("cuda", 0))
+    comm.always_gather = True          # a world of one shards nothing: drive the sharded branch through RCCL anyway
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    res = brie_amd.fitBRIE(ad, Xc=P["Xc"], comm=comm, **kw)
+    path_in_fit = comm.last_gather_path
+    # the library's communicator also answers on its own, and equals the torch path
+    x = np.arange(3 * 52, dtype=np.float32).reshape(3, 52)
+    nat = comm.allgather_genes(x, 52, native=True)
+    tor = comm.allgather_genes(x, 52, native=False)
+    np.savez(os.path.join(out_dir, "native.npz"), path=path_in_fit, native_exists=comm.native_comm() is not None,
+             same=all(np.array_equal(getattr(res, k), getattr(ref, k)) for k in
+                      ("sigma", "intercept", "cell_coeff", "loss_gene", "ELBO_gain", "Psi", "losses")),
+             gather_ok=np.array_equal(nat, x) and np.array_equal(tor, x), keys=sorted(ad.varm))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fitBRIE_end_of_fit_gather_runs_through_the_library_communicator(lib, tmp_path):
+    """with the process group on RCCL the per-gene vectors of a gene-sharded fitBRIE are gathered by
+    brie_comm_allgather (librccl called from libbrie_amd.so), not by torch.distributed; replaces the `concate` of
+    model_wrap.py:260.  One rank on this box: the branch, the communicator set-up over the torch store and the RCCL
+    calls all execute; the result equals the unsharded fit bit for bit."""
+    import torch.multiprocessing as mp
+    mp.spawn(_native_gather_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "native.npz")
+    assert bool(r["native_exists"]) and str(r["path"]) == "brie_comm_allgather"    # what fitBRIE's own gather went through
+    assert bool(r["same"]) and bool(r["gather_ok"])
+    assert "cell_coeff" in list(r["keys"])

@@ -152,11 +152,6 @@ struct brie_handle {
     size_t loss_parts_elems = 0;
     int rows_per_chunk = 0, n_chunks = 0, gene_blocks = 0, fin_blocks = 0;
     int user_rows_per_chunk = 0;
-    int *tickets = nullptr;         // (gene_blocks) fused finalize of launch-bound problems (brie::FusedFinalize)
-    brie::FusedFinalize *ff_dev = nullptr, *ff_pin = nullptr;   // one struct per step of a brie_step call: device / page-locked
-    size_t ff_cap = 0;
-    hipEvent_t ff_event = nullptr;  // the copy out of ff_pin has completed
-    int fused_mode = -1;            // BRIE_FUSED_FINALIZE: -1 automatic, 0 never, 1 whenever the kernel variant allows
     uint32_t draw = 0;
     int64_t t = 0;                  // Adam iteration of the current optimiser
     bool have_c[3] = {false, false, false}, have_xc = false, have_eff = false, have_state = false;
@@ -166,7 +161,6 @@ struct brie_handle {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
-    int64_t prof_batched = 0;       // launches covered by a shared event pair beyond one per pair (fused finalize)
 };
 
 namespace {
@@ -724,7 +718,7 @@ int staged_count_upload(brie_handle *h, float *dev, const float *src, int64_t ld
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     std::lock_guard<std::mutex> lock(g_ingest.mu);
     const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
-    const int64_t slab_elems = std::max<int64_t>(Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 22));   // 16 MB of fp32
+    const int64_t slab_elems = std::max<int64_t>(Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 21));   // 8 MB of fp32
     const int64_t R = std::max<int64_t>(1, slab_elems / Ng);
     const int64_t n_slabs = (Nc + R - 1) / R;
     const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
@@ -885,11 +879,6 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
         e = hipMalloc(reinterpret_cast<void **>(&h->block_active), h->gene_blocks * sizeof(int32_t));
         if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
-        e = hipMalloc(reinterpret_cast<void **>(&h->tickets), h->gene_blocks * sizeof(int));
-        if (e == hipSuccess) e = hipMemsetAsync(h->tickets, 0, h->gene_blocks * sizeof(int), h->stream);
-        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
-        const char *ffe = getenv("BRIE_FUSED_FINALIZE");
-        h->fused_mode = ffe ? (ffe[0] == '0' ? 0 : 1) : -1;
         if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { brie_destroy(h); return rc; }
     }
     if (h->coupled) {
@@ -961,10 +950,6 @@ int brie_destroy(brie_handle *h) {
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
     if (h->block_active) hipFree(h->block_active);
-    if (h->tickets) hipFree(h->tickets);
-    if (h->ff_dev) hipFree(h->ff_dev);
-    if (h->ff_pin) hipHostFree(h->ff_pin);
-    if (h->ff_event) hipEventDestroy(h->ff_event);
     if (h->quad_ids) hipFree(h->quad_ids);
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
@@ -1375,27 +1360,6 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->loss_parts), lp_need * sizeof(double)));
         h->loss_parts_elems = lp_need;
     }
-    // Launch-bound problems: the per-gene finalize runs inside the step kernel (brie::FusedFinalize), one launch per
-    // step.  Automatic when the whole grid is a fraction of one round of workgroups and the last workgroup's serial sum
-    // over the chunks is short; only the plain variants of elbo_adam_step (ELBO target, uncoupled, Kc <= 8) take it.
-    const bool fused_ok = !h->coupled && !h->wide_like && h->target == 0 && !split;
-    const bool fused = fused_ok && (h->fused_mode == 1 ||
-                                    (h->fused_mode < 0 && h->gene_blocks * h->n_chunks <= 512 && h->n_chunks <= 64));
-    if (fused) {
-        if (static_cast<size_t>(n_steps) > h->ff_cap) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            if (h->ff_dev) HIP_TRY(hipFree(h->ff_dev));
-            if (h->ff_pin) HIP_TRY(hipHostFree(h->ff_pin));
-            h->ff_dev = h->ff_pin = nullptr;
-            h->ff_cap = 0;
-            const size_t cap = std::max<size_t>(256, static_cast<size_t>(n_steps));
-            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->ff_dev), cap * sizeof(brie::FusedFinalize)));
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->ff_pin), cap * sizeof(brie::FusedFinalize), hipHostMallocDefault));
-            h->ff_cap = cap;
-        }
-        if (!h->ff_event) HIP_TRY(hipEventCreateWithFlags(&h->ff_event, hipEventDisableTiming));
-        else HIP_TRY(hipEventSynchronize(h->ff_event));            // the previous call's copy has left ff_pin
-    }
     if (h->profiling) {
         while (h->ev_pool.size() < h->ev_used + 2 * static_cast<size_t>(n_steps)) {
             hipEvent_t ev;
@@ -1466,21 +1430,6 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         const double tt = static_cast<double>(t);
         return static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) / (1.0 - std::pow(0.9, tt)));
     };
-    if (fused) {        // the finalize arguments of every step of this call, in device memory before the first launch
-        int64_t t = h->t, rp = h->ring_pos;
-        for (int i = 0; i < n_steps; ++i, ++rp) {
-            brie::FinalizeArgs fi = f;
-            fi.alpha = adam_alpha(++t);
-            fi.loss_parts = h->loss_parts + static_cast<size_t>(i) * h->fin_blocks * 2;
-            fi.ring_slot = static_cast<int32_t>(rp % brie::kLossRing);
-            fi.ring_prev = static_cast<int32_t>((rp + brie::kLossRing - 1) % brie::kLossRing);
-            h->ff_pin[i].fin = fi;
-            h->ff_pin[i].tickets = h->tickets;
-        }
-        HIP_TRY(hipMemcpyAsync(h->ff_dev, h->ff_pin, static_cast<size_t>(n_steps) * sizeof(brie::FusedFinalize),
-                               hipMemcpyHostToDevice, h->stream));
-        HIP_TRY(hipEventRecord(h->ff_event, h->stream));
-    }
     for (int i = 0; i < n_steps; ++i) {
         h->t += 1;
         const float alpha = adam_alpha(h->t);
@@ -1490,19 +1439,12 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         f.ring_slot = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
-        // HIP events around every launch of the dominant kernel; single-kernel steps (fused finalize) are bracketed as
-        // ONE batch instead -- two event packets per 6-us kernel would be most of what is measured -- so their average
-        // includes the gaps between the back-to-back launches
-        const bool ev_each = h->profiling && !fused, ev_first = h->profiling && fused && i == 0,
-                   ev_last = h->profiling && fused && i == n_steps - 1;
-        if (ev_each || ev_first) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        if (fused) cfg.ff = h->ff_dev + i;
+        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         if (use_tile) launch_tile(h, cfg, q, a, ta);
         else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
-        if (ev_each || ev_last) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
-        if (h->profiling && fused) h->prof_batched += (i == n_steps - 1) ? n_steps - 1 : 0;    // launches beyond the pair
-        if (!fused) hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
+        if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        hipLaunchKernelGGL(brie::gene_finalize, dim3(h->fin_blocks, h->S), dim3(brie::kBlock), 0, h->stream, f);
         if (use_tile && h->p.Kc > 0) {            // G = Xc^T . r was reduced inside the pass: Adam on Wc_loc
             const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
             hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
@@ -2022,7 +1964,6 @@ int brie_profile_enable(brie_handle *h, int32_t enable) {
     h->ev_used = 0;
     h->prof_ms = 0.0;
     h->prof_launches = 0;
-    h->prof_batched = 0;
     return BRIE_OK;
 }
 
@@ -2038,8 +1979,6 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
         h->prof_launches += 1;
     }
     h->ev_used = 0;
-    h->prof_launches += h->prof_batched;
-    h->prof_batched = 0;
     *kernel_ms_total = h->prof_ms;
     *n_launches = h->prof_launches;
     return BRIE_OK;

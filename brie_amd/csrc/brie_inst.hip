@@ -40,9 +40,9 @@ inline int occupancy_cap() {
     return dynamic ? read() : fixed;
 }
 
-template <int MODE, int MC, int CS, bool CPL, bool FUSED = false>
+template <int MODE, int MC, int CS, bool CPL>
 void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const CoupledArgs &cp) {
-    auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL, false, false, false, FUSED>;
+    auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, CPL>;
     static const OccupancyPads pads = occupancy_pads(kern);
     // automatic: one per CU for one Monte-Carlo sample per step; with more samples the row body keeps the SIMD's VALU
     // busy most of the time and a second wave per SIMD is what hides the memory latency (MC_size 3: one per CU is 4 - 15 %
@@ -54,7 +54,7 @@ void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), pad, c.stream, q.c1, q.c2,
                        q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL,
-                       q.partials, a, cp, static_cast<float *>(nullptr), c.ff);
+                       q.partials, a, cp, static_cast<float *>(nullptr));
 }
 
 // Kg > 4: coupled variant with the gene block's Xg tile in dynamic LDS (up to 64 KiB on top of the static arrays)
@@ -65,7 +65,7 @@ void step_launch_gw(const LaunchCfg &c, const StepPointers &q, const StepScalars
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
     hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), c.gw_lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu,
-                       q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr, c.ff);
+                       q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr);
 }
 
 // target="marginLik" for the coupled variants (the uncoupled ones use margin_step)
@@ -76,11 +76,11 @@ void step_launch_margin(const LaunchCfg &c, const StepPointers &q, const StepSca
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   kKgWideMax * kGenesPerBlock * static_cast<int>(sizeof(float)));
         hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), c.gw_lds_bytes, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu,
-                           q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr, c.ff);
+                           q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, cp, nullptr);
     } else {
         hipLaunchKernelGGL((elbo_adam_step<BRIE_KC, MODE, 0, CS, true, false, false, true>), c.grid, dim3(kBlock), 0,
                            c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam,
-                           q.effL, q.partials, a, cp, nullptr, c.ff);
+                           q.effL, q.partials, a, cp, nullptr);
     }
 }
 
@@ -91,12 +91,6 @@ void step_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
     if (c.coupled && c.gw_lds_bytes > 0) { step_launch_gw<MODE, CS>(c, q, a, cp); return; }
     if (c.coupled) { step_launch<MODE, 0, CS, true>(c, q, a, cp); return; }
     // MC_size 1 = API default (model_TFProb.py:130), 3 = CLI default (bin/quant.py:173)
-    if (c.ff != nullptr) {      // launch-bound problem: the same kernels with the per-gene finalize in their tail
-        if (a.mc == 1) step_launch<MODE, 1, CS, false, true>(c, q, a, cp);
-        else if (a.mc == 3) step_launch<MODE, 3, CS, false, true>(c, q, a, cp);
-        else step_launch<MODE, 0, CS, false, true>(c, q, a, cp);
-        return;
-    }
     if (a.mc == 1) step_launch<MODE, 1, CS, false>(c, q, a, cp);
     else if (a.mc == 3) step_launch<MODE, 3, CS, false>(c, q, a, cp);
     else step_launch<MODE, 0, CS, false>(c, q, a, cp);
@@ -171,7 +165,7 @@ void wide_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
 #define BRIE_WIDE_M(MC, CPL, GW, MRG, LDS)                                                                         \
     hipLaunchKernelGGL((elbo_adam_step<0, MODE, MC, CS, CPL, true, GW, MRG>), c.grid, dim3(kBlock), LDS, c.stream, q.c1, \
                        q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho, q.Xc, q.W, q.b, q.lam, q.effL, \
-                       q.partials, a, cp, c.rbuf, c.ff)
+                       q.partials, a, cp, c.rbuf)
 #define BRIE_WIDE(MC, CPL, GW, LDS) BRIE_WIDE_M(MC, CPL, GW, false, LDS)
     if (c.margin) {                                  // target="marginLik": prior samples, residual q into rbuf
         if (c.coupled && c.gw_lds_bytes > 0) {

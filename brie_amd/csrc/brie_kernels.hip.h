@@ -465,7 +465,7 @@ __device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float 
 
 // statistic s of gene j: the chunk partials summed in fp64 in chunk order, then what the statistic is for -- Adam on a
 // Wc_loc entry / the intercept (clip) / sigma_log, or the gene's KL / ll term into the loss ring.  Returns the sum
-// (0 for genes beyond Ng).  One body for the gene_finalize kernel and for the fused tail of elbo_adam_step.
+// (0 for genes beyond Ng).
 __device__ __forceinline__ double finalize_gene_stat(const FinalizeArgs &a, int j, int s) {
     const int S = a.Kc + 4;
     double t = 0.0;
@@ -528,40 +528,6 @@ __device__ __forceinline__ double block_sum_f64(double *sh, double t) {
     return tot;
 }
 
-// Launch-bound problems (configs[0]: 26 workgroups, two dependent ~6 us kernels per step): the per-gene finalize runs
-// INSIDE the step kernel.  Every workgroup of a gene block takes a ticket when its chunk's partial row is written and
-// visible device-wide; the one that draws the last ticket sums the block's partials and applies Adam exactly as
-// gene_finalize would (same body, same fp64 orders: bit-identical), then re-arms the ticket.  One launch per step.
-// The kernel takes a POINTER to the step's FusedFinalize in device memory (null: off -- the separate gene_finalize
-// launch follows, as for every problem that fills the GPU, where the last workgroup's finalize would be a serial tail
-// behind 15 000 streaming workgroups).  A pointer, not the struct by value: 170 more bytes of kernel arguments made
-// the compiler load them in the prologue and spill 43 SGPRs around the row loop of the headline instantiation.
-struct FusedFinalize {
-    FinalizeArgs fin;
-    int *tickets;               // (gene_blocks), zero between launches
-};
-static_assert(kBlock == kGenesPerBlock, "the fused finalize maps thread t of the last workgroup to gene t of the block");
-template <int S>
-__device__ __forceinline__ void fused_finalize_tail(const FusedFinalize &ff, int gb, int n_chunk_groups) {
-    __shared__ int is_last;
-    __shared__ double sh[kBlock];
-    __threadfence();                                   // this workgroup's partial row: visible to the whole device
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(ff.tickets + gb, 1) == n_chunk_groups - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();                                   // ... and everybody else's rows to this one
-    if (threadIdx.x == 0) ff.tickets[gb] = 0;          // re-armed for the next launch
-    const int j = gb * kBlock + static_cast<int>(threadIdx.x);
-    for (int s = 0; s < S; ++s) {
-        const double t = finalize_gene_stat(ff.fin, j, s);
-        if (s >= S - 2) {                              // KL / ll rows: the block's fp64 partial of the step's loss
-            const double tot = block_sum_f64(sh, t);
-            if (threadIdx.x == 0) ff.fin.loss_parts[2 * gb + (s - (S - 2))] = tot;
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------
 // elbo_adam_step: one fused pass = ELBO forward + gradient + Adam for Z_loc,
 // Z_std_log + per-gene sufficient statistics.  Algorithmic HBM traffic per
@@ -581,18 +547,14 @@ __device__ __forceinline__ void fused_finalize_tail(const FusedFinalize &ff, int
 // from the PRIOR N(m, sigma), the samples are combined with an online log-mean-exp, q = sum_k w_k dl/dz_k takes the
 // place of the residual r in every prior-parameter statistic (and -q_eps sigma that of the sigma statistic), there is
 // no KL term and the posterior arrays are neither read nor written.  (Uncoupled Kc <= 8 models use margin_step.)
-// FUSED: the per-gene finalize runs in this kernel's tail (FusedFinalize, launch-bound problems).  A template flag, not
-// a run-time one: with the tail merely guarded by a null check the compiler scheduled and allocated the row loop of the
-// headline instantiation differently (1 400 of its 1 368 instructions moved); FUSED = false compiles the kernel as before.
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false,
-          bool FUSED = false>
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
 __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
-    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf, const FusedFinalize *__restrict__ ffp) {
+    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
     static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
     static_assert(!GW || CPL, "GW is the coupled variant for Kg > 4");
     extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
@@ -611,10 +573,7 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
     const bool active = j0 < a.Ng;
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
-    if (a.block_active[gb] == 0) {                       // whole gene block frozen (workgroup-uniform)
-        if constexpr (FUSED) fused_finalize_tail<S>(*ffp, gb, static_cast<int>(gridDim.y));   // carries its losses forward
-        return;
-    }
+    if (a.block_active[gb] == 0) return;                 // whole gene block frozen (workgroup-uniform)
     if constexpr (WIDE) {
         for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
             wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
@@ -1006,7 +965,6 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             st4(dst + s * a.ld, o);
         }
     }
-    if constexpr (FUSED) fused_finalize_tail<S>(*ffp, gb, static_cast<int>(gridDim.y));
 }
 
 #ifdef BRIE_HOST_TU   // non-template kernels: defined once, in brie_capi.hip's translation unit

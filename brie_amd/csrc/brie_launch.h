@@ -23,7 +23,6 @@ struct LaunchCfg {
     float *rbuf = nullptr;         // wide designs (Kc > 8): residual buffer read back by wide_design_grad
     int gw_lds_bytes = 0;          // > 0: Kg > 4, GW variant with an Xg tile of this many bytes in dynamic LDS
     int margin = 0;                // 1: target="marginLik" through the MARGIN variants (coupled / wide models)
-    const FusedFinalize *ff = nullptr;   // device struct of this step: the per-gene finalize runs inside the step kernel
 };
 
 #define BRIE_DECLARE_KC(N)                                                                          \

@@ -503,48 +503,6 @@ def test_loglik_mc_accessor_matches_oracle(lib, target, mode, Kg, Kc, L):
     sh.close()
 
 
-@pytest.mark.parametrize("Nc,Ng,Kc,L,MC", [(200, 500, 0, 2, 1), (200, 500, 1, 2, 3), (70, 1030, 3, 3, 2), (1300, 300, 8, 2, 1)])
-def test_fused_finalize_is_bit_identical_to_the_two_kernel_step(lib, monkeypatch, Nc, Ng, Kc, L, MC):
-    """Launch-bound problems (configs[0]) run the per-gene finalize in the tail of elbo_adam_step behind a
-    last-workgroup-done ticket (brie::FusedFinalize): one launch per step instead of two.  Same body, same fp64
-    summation orders: loss trace, state, per-gene parameters, loss ring and frozen-gene handling must be bit-identical
-    to the separate gene_finalize launch -- which stays the path of every problem that fills the GPU."""
-    from brie_amd import _capi
-    P = util.problem(Nc, Ng, Kc, L, seed=33)
-    out = {}
-    for fused in ("0", "1"):
-        monkeypatch.setenv("BRIE_FUSED_FINALIZE", fused)
-        sh = util.device_shard(P, Nc, Ng, Kc, 5)
-        tr = [sh.step(7, 0.01, MC)]
-        sh.step(5, 0.02, MC, trace=False)                   # enqueue-only calls pipeline across brie_step calls
-        tr.append(sh.step(130, 0.005, MC))                  # more steps than the ring holds
-        win = sh.read_loss_window(20)
-        mask = np.ones(Ng, bool)
-        mask[: Ng // 2] = False                             # freeze half of the genes (whole gene blocks among them)
-        sh.set_gene_mask(mask)
-        tr.append(sh.step(9, 0.01, MC))
-        win2 = sh.read_loss_window(9)
-        sh.set_gene_mask(None)
-        sh.reset_optimizer()
-        tr.append(sh.step(4, 0.001, MC))
-        st = util.device_state(sh)
-        lg = sh.loss_gene(3)
-        sh.profile_enable(True)
-        sh.step(6, 0.001, MC, trace=False)
-        ms, n = sh.profile_read()
-        assert n == 6 and ms > 0.0                          # per launch, or one event pair around the single-kernel steps
-        out[fused] = (np.concatenate(tr), win, win2, st, lg)
-        sh.close()
-    a, b = out["0"], out["1"]
-    np.testing.assert_array_equal(a[0], b[0])
-    np.testing.assert_array_equal(a[1], b[1])
-    np.testing.assert_array_equal(a[2], b[2])
-    for k in a[3]:
-        np.testing.assert_array_equal(a[3][k], b[3][k], err_msg=k)
-    np.testing.assert_array_equal(a[4], b[4])
-    assert np.isfinite(a[0]).all()
-
-
 @pytest.mark.parametrize("Ng,L", [(1000, 2), (515, 3), (4, 2)])
 def test_staged_host_ingest_is_bit_identical_to_the_plain_copy(lib, monkeypatch, Ng, L):
     """brie_upload of a pageable host count layer through the staged pipeline (host threads convert row slabs to u16 in

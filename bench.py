@@ -459,7 +459,7 @@ def main(argv=None):
     quad_eff = eff_all[q0:q0 + 4].cpu().numpy() if (L == 3 and rank == 0) else None
     Xc_host = Xc.cpu().numpy()
     e2e_inputs = None
-    if rank == 0 and world == 1 and not (args.no_e2e or args.pmc_child or args.emulate_shard_of):
+    if rank == 0 and world == 1 and not (args.no_e2e or args.pmc_child):
         e2e_inputs = [x.cpu().numpy() for x in layers]          # the API hands over HOST buffers
     del layers
     torch.cuda.empty_cache()
@@ -589,7 +589,8 @@ def main(argv=None):
         # Psi / Z_std / Psi95CI / Z_loc out (model_wrap.py:138-146) -- upload, compaction and read-back included.
         import brie_amd
         t0 = time.perf_counter()
-        mdl = brie_amd.BRIE2(Nc, Ng, Kc=Kc, effLen=eff_all.cpu().numpy() if L == 3 else None, seed=seed, device=local_rank)
+        mdl = brie_amd.BRIE2(Nc, ng, Kc=Kc, effLen=eff_all.cpu().numpy() if L == 3 else None, seed=seed, device=local_rank,
+                             gene_offset=g0)
         mdl.fit(e2e_inputs, Xc=Xc_host, min_iter=1000, max_iter=1000, MC_size=args.mc, pseudo_count=0.01, verbose=False)
         rv = brie_amd.BRIE_RV(mdl)
         total = time.perf_counter() - t0

@@ -109,9 +109,16 @@ class BRIE2(object):
             return self._shard
         sh = self._adopt_shard(count_layers, n_layers)
         if sh is None:
+            t0 = time.time()
             sh = self._new_shard(n_layers)
             sh.owner = self
+            t1 = time.time()
             self._upload_layers(sh, count_layers, n_layers)
+            if hasattr(sh, "synchronize"):
+                sh.synchronize()
+            # where the ingest goes: allocation of the shard's HBM arrays; host -> device copy of the count layers
+            # (staged pipeline for pageable layers, brie_upload) + range check + storage tiers
+            self._ingest_timing = {"create_shard_s": t1 - t0, "upload_count_layers_s": time.time() - t1}
             if self.effLen is not None:
                 sh.upload(_capi.EFFLEN, np.ascontiguousarray(self.effLen, dtype=np.float32))
         if self.Kc > 0:
@@ -462,6 +469,8 @@ class BRIE2(object):
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
         tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s, "stage_s": stage_s}
+        tm.update(getattr(self, "_ingest_timing", None) or {})
+        self._ingest_timing = None
         t0 = time.time()
         if staging is not None:              # results stream out on a second stream while loss_gene computes
             bufs, th = staging

@@ -74,8 +74,19 @@ __device__ __forceinline__ float u01(uint32_t x) {
     return (static_cast<float>(x >> 9) + 0.5f) * 0x1p-23f;      // exact in fp32, in (0,1)
 }
 
+// the same value as ONE instruction: (v + 0.5) 2^-23 = v 2^-23 + 2^-24, both exact in fp32 for v < 2^23.  Used by the
+// VALU-bound forward passes only; the HBM-bound step kernels keep the form they were tuned with.
+__device__ __forceinline__ float u01_fma(uint32_t x) {
+    return __builtin_fmaf(static_cast<float>(x >> 9), 0x1p-23f, 0x1p-24f);
+}
+
+template <bool LEAN = false>
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &n0, float &n1) {
+#ifdef BRIE_LG_ROUND2
     const float ua = u01(xa), ub = u01(xb);
+#else
+    const float ua = LEAN ? u01_fma(xa) : u01(xa), ub = LEAN ? u01_fma(xb) : u01(xb);
+#endif
 #if BRIE_FAST_MATH
     const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(ua));
     n0 = r * __builtin_amdgcn_cosf(ub);      // v_cos_f32 takes revolutions: cos(2 pi ub)
@@ -90,12 +101,13 @@ __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &n0, 
 }
 
 // eps for genes 4q..4q+3 of cell `cell` at (draw, k)
+template <bool LEAN = false>
 __device__ __forceinline__ void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k,
                                         uint32_t seed_lo, uint32_t seed_hi, float e[4]) {
     uint32_t x[4];
     philox4x32_10(quad, cell, draw, k, seed_lo, seed_hi, x);
-    box_muller(x[0], x[1], e[0], e[1]);
-    box_muller(x[2], x[3], e[2], e[3]);
+    box_muller<LEAN>(x[0], x[1], e[0], e[1]);
+    box_muller<LEAN>(x[2], x[3], e[2], e[3]);
 }
 
 // ----------------------------------------------------------------------------
@@ -138,7 +150,15 @@ __device__ __forceinline__ float f_log_sel(float x) {
 template <bool LEAN = false>
 __device__ __forceinline__ float f_log1p(float x) {
 #if BRIE_FAST_MATH
-    // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2
+    // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2.
+    // LEAN (the forward-only passes): log(1 + x) throughout.  Rounding 1 + x costs at most 6e-8 ABSOLUTE in a term that
+    // enters the loss as c * (min(+-z, 0) - log1p) with |z| > 6.9 there -- nothing next to the fp32 sums it is added to --
+    // and without the two-sided branch the four elements of a lane are one basic block again, which is what lets the
+    // compiler pair their arithmetic into v_pk_* instructions (the branchy form compiled to 4 x s_and_saveexec ... s_or
+    // per draw and no packed math at all).
+#ifndef BRIE_LG_ROUND2      // -DBRIE_LG_ROUND2=1: the forward passes exactly as round 2 built them (A/B runs)
+    if constexpr (LEAN) return f_log_sel<true>(1.0f + x);
+#endif
     return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<LEAN>(1.0f + x);
 #else
     return log1pf(x);
@@ -245,6 +265,50 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
         }
         g = c1 * sn - c2 * sp - N * (phi1 * sn - phi2 * sp);
     }
+}
+
+// Forward-only log-likelihood of TWO elements at once (2-category mode, the forward passes): the same operations as
+// loglik<kLik2, true> per element, written on 2-vectors so that every fp32 add / mul / fma is ONE v_pk_* instruction
+// for the pair (gfx950 issues packed fp32 at the scalar rate); the transcendentals stay per element.
+// BRIE_LG_PACKED=0 compiles the per-element form instead (A/B runs).
+#ifndef BRIE_LG_PACKED
+#ifdef BRIE_LG_ROUND2
+#define BRIE_LG_PACKED 0
+#else
+#define BRIE_LG_PACKED 1
+#endif
+#endif
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ floatx2 loglik2_pair(floatx2 z, floatx2 c1, floatx2 c2) {
+#if BRIE_FAST_MATH
+    constexpr float kLog2e = 0x1.715476p+0f;                         // what __expf multiplies by
+    const floatx2 t = z * kLog2e;
+    floatx2 e;
+    e.x = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.x));             // exp(-|z|) in (0,1]
+    e.y = __builtin_amdgcn_exp2f(-__builtin_fabsf(t.y));
+    const floatx2 a = e + 1.0f;
+    floatx2 y;
+    y.x = __builtin_amdgcn_logf(a.x);
+    y.y = __builtin_amdgcn_logf(a.y);
+    constexpr float c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;        // ln2 = c + cc (f_log_sel<true>)
+    floatx2 l1p;
+    {
+#pragma clang fp contract(off)
+        const floatx2 r = y * c;
+        l1p = r + __builtin_elementwise_fma(y, floatx2{cc, cc}, __builtin_elementwise_fma(y, floatx2{c, c}, -r));
+    }
+    floatx2 m1, m2;
+    m1.x = fminf(z.x, 0.0f); m1.y = fminf(z.y, 0.0f);
+    m2.x = fminf(-z.x, 0.0f); m2.y = fminf(-z.y, 0.0f);
+    const floatx2 ls1 = m1 - l1p, ls2 = m2 - l1p;                    // log_sigmoid(z), log_sigmoid(-z)
+    return c1 * ls1 + c2 * ls2;
+#else
+    floatx2 out;
+    float g;
+    loglik<kLik2, true>(z.x, c1.x, c2.x, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, out.x, g);
+    loglik<kLik2, true>(z.y, c1.y, c2.y, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, out.y, g);
+    return out;
+#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -1104,14 +1168,25 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
             float lsum[kVec] = {0.f, 0.f, 0.f, 0.f};
             for (int rep = 0; rep < a.n_rep; ++rep) {
                 float e[kVec];
-                normal4(gquad, static_cast<uint32_t>(r), a.draw0 + static_cast<uint32_t>(rep), 0u,
-                        a.seed_lo, a.seed_hi, e);
+                normal4<true>(gquad, static_cast<uint32_t>(r), a.draw0 + static_cast<uint32_t>(rep), 0u,
+                              a.seed_lo, a.seed_hi, e);
+                if constexpr (MODE == kLik2 && BRIE_LG_PACKED) {
 #pragma unroll
-                for (int v = 0; v < kVec; ++v) {
-                    float l, g;
-                    loglik<MODE, true>(fmaf(s[v], e[v], zc[v]), c1.v[v], c2.v[v], c3.v[v],
-                                 L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
-                    lsum[v] += l;
+                    for (int p = 0; p < kVec; p += 2) {
+                        const floatx2 z = __builtin_elementwise_fma(floatx2{s[p], s[p + 1]}, floatx2{e[p], e[p + 1]},
+                                                                    floatx2{zc[p], zc[p + 1]});
+                        const floatx2 l = loglik2_pair(z, floatx2{c1.v[p], c1.v[p + 1]}, floatx2{c2.v[p], c2.v[p + 1]});
+                        lsum[p] += l.x;
+                        lsum[p + 1] += l.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) {
+                        float l, g;
+                        loglik<MODE, true>(fmaf(s[v], e[v], zc[v]), c1.v[v], c2.v[v], c3.v[v],
+                                     L0[v], L4[v], L5[v], lL0[v], lL4[v], lL5[v], l, g);
+                        lsum[v] += l;
+                    }
                 }
             }
 #pragma unroll

@@ -20,13 +20,30 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def assert_states_close(so, sd, bulk=2e-5, worst=1e-3):
+_RECORD = None            # tests/tools/soak_randomised.py sets a list: (array, n, p99.9, max, n beyond `worst`) per call
+
+
+def assert_states_close(so, sd, bulk=2e-5, worst=1e-3, lr=0.01, fresh=1):
+    """State arrays of the oracle and of the device after a few Adam steps (the short-horizon parity rule).
+
+      bulk    99.9 % of every array within `bulk` (2e-5);
+      worst   every element within `worst` (1e-3) -- EXCEPT sign flips: Keras Adam's first update of a fresh optimiser
+              is lr * g / (|g| + 1e-7), i.e. +-lr whatever |g| is, so an element whose gradient is ~0 (zero coverage,
+              mu on its prior mean: |g| ~ 1e-8) moves by +lr or -lr on the SIGN of a rounding error.  Such an element
+              may sit up to 2 lr apart per fresh optimiser in the sequence (`fresh`; + 10 % for the steps that follow),
+              and there may be at most max(1, 1e-4 n) of them per array.  (1 000 soak cases of the two random families
+              need exactly this: profiles/r3c_soak.log -- before, two of them were explained in a log.)"""
     for k in util.STATE_KEYS:
         if so[k].size == 0:
             continue
         d = np.abs(np.asarray(so[k], np.float64) - np.asarray(sd[k], np.float64))
+        n_out = int((d >= worst).sum())
+        if _RECORD is not None:
+            _RECORD.append((k, int(d.size), float(np.percentile(d, 99.9)), float(d.max()), n_out))
+            continue
         assert np.percentile(d, 99.9) < bulk, (k, float(np.percentile(d, 99.9)))
-        assert d.max() < worst, (k, float(d.max()))
+        assert n_out <= max(1, int(1e-4 * d.size)), (k, "elements beyond %g" % worst, n_out, float(d.max()))
+        assert d.max() < max(worst, 2.2 * lr * fresh), (k, float(d.max()))
 
 
 def test_library_loads(lib):
@@ -818,11 +835,9 @@ def test_randomised_operation_sequences(lib, i, Nc, Ng, Kc, L, sparse, f32, ops)
     fp32 count storage -- the oracle follows with the same masks and the same noise-stream position."""
     import scipy.sparse as sp
     from brie_amd import _capi
-    # Worst element: these sequences put "reset" (fresh Adam) in front of 1-2 step blocks.  The first updates of a fresh Adam
-    # are lr * g / (|g| + 1e-7); a zero-coverage element whose mu sits on its prior mean has |g| ~ 1e-8 and any rounding
-    # difference decides most of a 0.01 step: sequence 3 leaves ONE such element 2e-3 apart (the fp32 and fp64 oracles
-    # differ by 2e-4 there, their largest difference; tests/tools/debug_seq3.py).  The bulk bound (99.9 % within 2e-5) stays.
-    WORST = 5e-3
+    # Worst element: these sequences put "reset" (fresh Adam) in front of 1-2 step blocks -- the sign-flip exemption of
+    # assert_states_close is sized by the number of fresh optimisers in the sequence.  The bulk bound (99.9 % within 2e-5) stays.
+    fresh = 1 + sum(op == "reset" for op in ops)                  # every reset is a fresh optimiser (+ the initial one)
     rng = np.random.default_rng(900 + i)
     P = util.problem(Nc, Ng, Kc, L, seed=300 + i)
     if i % 2:                  # a few counts above 255 (moderate: a count of 60000 amplifies fp32 rounding past the state
@@ -874,8 +889,8 @@ def test_randomised_operation_sequences(lib, i, Nc, Ng, Kc, L, sparse, f32, ops)
             k = min(len(o.lg_hist), 3)
             np.testing.assert_allclose(sh.read_loss_window(k), np.asarray(o.lg_hist[-k:]), rtol=5e-5, atol=2e-3)
         elif op == "read":
-            assert_states_close(util.oracle_state(o), util.device_state(sh), worst=WORST)
-    assert_states_close(util.oracle_state(o), util.device_state(sh), worst=WORST)
+            assert_states_close(util.oracle_state(o), util.device_state(sh), fresh=fresh)
+    assert_states_close(util.oracle_state(o), util.device_state(sh), fresh=fresh)
     np.testing.assert_array_equal(sh.read(_capi.COUNT1), P["counts_pc"][0])
     sh.close()
 

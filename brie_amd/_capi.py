@@ -20,7 +20,7 @@ MAX_KC = 64          # 0..8 in registers, 9..64 with the W tile in LDS + an MFMA
 MAX_KG = 64
 
 EXPORTS = [
-    "brie_create", "brie_destroy", "brie_upload", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
+    "brie_create", "brie_destroy", "brie_upload", "brie_upload_typed", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
     "brie_step_end", "brie_set_gene_mask", "brie_read_loss_window", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
@@ -30,9 +30,11 @@ EXPORTS = [
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
-    "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16",
+    "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
 ]
 COMM_ID_BYTES = 128
+#: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
+TYPED_DTYPES = {"float64": 1, "int32": 2, "int64": 3, "uint8": 4, "uint16": 5, "int16": 6, "uint32": 7}
 
 
 class BrieProblem(ctypes.Structure):
@@ -76,6 +78,7 @@ def load_library(path=None):
     lib.brie_create.argtypes = [ctypes.POINTER(BrieProblem), ctypes.POINTER(vp)]
     lib.brie_destroy.argtypes = [vp]
     lib.brie_upload.argtypes = [vp, ctypes.c_int, vp, i64, i64, i64]
+    lib.brie_upload_typed.argtypes = [vp, ctypes.c_int, vp, i32, i64, i64, i64]
     lib.brie_upload_sparse.argtypes = [vp, ctypes.c_int, i32, vp, vp, vp, i64, i64, i64]
     lib.brie_add_pseudo_count.argtypes = [vp, f32]
     lib.brie_init_state.argtypes = [vp, f32, f32]
@@ -120,6 +123,7 @@ def load_library(path=None):
     lib.brie_loglik_mc.argtypes = [vp, i32, vp, i64]
     lib.brie_get_loss.argtypes = [vp, i32, i32, vp]
     lib.brie_host_convert_u16.argtypes = [vp, i64, i64, i64, vp, ctypes.POINTER(i32)]
+    lib.brie_host_convert_slab.argtypes = [vp, i32, i64, i64, i64, vp, ctypes.POINTER(i32)]
     lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
@@ -252,6 +256,22 @@ def host_convert_u16(a):
     return out, bool(flag.value)
 
 
+def host_convert_slab(a):
+    """One slab of the typed ingest (brie_host_convert_slab): the array as u16 when it holds nothing but integers in
+    [0, 65535], else as the float32 cast; returns (converted, went_as_float32)."""
+    lib = load_library()
+    a = np.ascontiguousarray(a)
+    dt = 0 if a.dtype == np.float32 else TYPED_DTYPES[a.dtype.name]
+    buf = np.empty(a.shape, np.float32)
+    flag = ctypes.c_int32()
+    if a.size:
+        _check(lib, lib.brie_host_convert_slab(a.ctypes.data_as(ctypes.c_void_p), dt, a.shape[0], a.shape[1], a.shape[1],
+                                               buf.ctypes.data_as(ctypes.c_void_p), ctypes.byref(flag)))
+    if flag.value:
+        return buf, True
+    return buf.view(np.uint16).ravel()[:a.size].reshape(a.shape).copy(), False
+
+
 def host_register(a):
     """Page-lock a numpy array in place (hipHostRegister); ctypes drops the GIL for the duration of the call."""
     lib = load_library()
@@ -358,6 +378,13 @@ class Shard(object):
             return
         if hasattr(x, "tocsc"):                                       # other scipy sparse formats
             return self.upload(which, x.tocsc())
+        if (which in (COUNT1, COUNT2, COUNT3) and isinstance(x, np.ndarray) and x.ndim == 2 and x.dtype.name in TYPED_DTYPES
+                and x.strides[1] == x.itemsize and x.strides[0] % x.itemsize == 0 and x.strides[0] >= x.shape[1] * x.itemsize):
+            # integer / float64 layers: converted by the library's ingest threads instead of a numpy astype pass
+            _check(self.lib, self.lib.brie_upload_typed(self._h, which, x.ctypes.data_as(ctypes.c_void_p),
+                                                        TYPED_DTYPES[x.dtype.name], x.shape[0], x.shape[1],
+                                                        x.strides[0] // x.itemsize))
+            return
         ptr, rows, cols, ld, keep = _matrix_pointer(x)
         _check(self.lib, self.lib.brie_upload(self._h, which, ptr, rows, cols, ld))
         del keep

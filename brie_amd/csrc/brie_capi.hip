@@ -670,14 +670,14 @@ int ingest_threads() {
     return std::max(1, std::min(8, n));
 }
 
-// rows x cols floats (row pitch ld) -> u16; returns nonzero when some value is not a non-negative integer <= 65535
-// (negative zero counts as "not": its sign bit would be lost)
 // (host code only: the device pass of this translation unit knows no x86 function multiversioning)
 #if defined(__HIP_DEVICE_COMPILE__) || !defined(__x86_64__)
 #define BRIE_HOST_SIMD_CLONES __attribute__((noinline))
 #else
 #define BRIE_HOST_SIMD_CLONES __attribute__((target_clones("arch=x86-64-v4", "arch=x86-64-v3", "default")))
 #endif
+// rows x cols floats (row pitch ld) -> u16; returns nonzero when some value is not a non-negative integer <= 65535
+// (negative zero counts as "not": its sign bit would be lost)
 BRIE_HOST_SIMD_CLONES uint32_t convert_rows_u16(const float *src, int64_t ld, int64_t rows, int64_t cols, uint16_t *dst) {
     uint32_t bad = 0;
     for (int64_t r = 0; r < rows; ++r) {
@@ -697,6 +697,97 @@ BRIE_HOST_SIMD_CLONES uint32_t convert_rows_u16(const float *src, int64_t ld, in
     }
     return bad;
 }
+// The other element types a caller may hold its count layers in (the reference casts whatever it is given with
+// .astype(np.float32), io_utils.py:18 / model_wrap.py:111): the same two conversions per type -- exact u16 when every
+// value of the slab is an integer in [0, 65535], else the float32 cast the reference would have made.
+BRIE_HOST_SIMD_CLONES uint32_t convert_rows_u16_f64(const double *src, int64_t ld, int64_t rows, int64_t cols, uint16_t *dst) {
+    uint32_t bad = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const double *s = src + r * ld;
+        uint16_t *d = dst + r * cols;
+        uint32_t b = 0;
+#pragma clang loop vectorize(enable) interleave(enable)
+        for (int64_t j = 0; j < cols; ++j) {
+            const double v = s[j];
+            uint64_t bits;
+            memcpy(&bits, &v, sizeof(bits));
+            const int32_t iv = static_cast<int32_t>(v < 65536.0 ? (v > -1.0 ? v : -1.0) : 65536.0);
+            b |= static_cast<uint32_t>(static_cast<double>(iv) != v) | static_cast<uint32_t>(bits >> 63) | static_cast<uint32_t>(iv > 65535);
+            d[j] = static_cast<uint16_t>(iv);
+        }
+        bad |= b;
+    }
+    return bad;
+}
+#define BRIE_CONVERT_INT(NAME, T)                                                                                          \
+    BRIE_HOST_SIMD_CLONES uint32_t NAME(const T *src, int64_t ld, int64_t rows, int64_t cols, uint16_t *dst) {            \
+        uint32_t bad = 0;                                                                                                  \
+        for (int64_t r = 0; r < rows; ++r) {                                                                               \
+            const T *s = src + r * ld;                                                                                     \
+            uint16_t *d = dst + r * cols;                                                                                  \
+            uint32_t b = 0;                                                                                                \
+            _Pragma("clang loop vectorize(enable) interleave(enable)") for (int64_t j = 0; j < cols; ++j) {                \
+                const T v = s[j];                                                                                          \
+                b |= static_cast<uint32_t>(v < static_cast<T>(0)) | static_cast<uint32_t>(static_cast<uint64_t>(v) > 65535u); \
+                d[j] = static_cast<uint16_t>(v);                                                                           \
+            }                                                                                                              \
+            bad |= b;                                                                                                      \
+        }                                                                                                                  \
+        return bad;                                                                                                        \
+    }
+BRIE_CONVERT_INT(convert_rows_u16_i32, int32_t)
+BRIE_CONVERT_INT(convert_rows_u16_i64, int64_t)
+BRIE_CONVERT_INT(convert_rows_u16_u32, uint32_t)
+BRIE_CONVERT_INT(convert_rows_u16_i16, int16_t)
+BRIE_CONVERT_INT(convert_rows_u16_u16, uint16_t)
+BRIE_CONVERT_INT(convert_rows_u16_u8, uint8_t)
+#undef BRIE_CONVERT_INT
+template <typename T>
+void cast_rows_f32(const T *src, int64_t ld, int64_t rows, int64_t cols, float *dst) {
+    for (int64_t r = 0; r < rows; ++r) {
+        const T *s = src + r * ld;
+        float *d = dst + r * cols;
+        for (int64_t j = 0; j < cols; ++j) d[j] = static_cast<float>(s[j]);       // round to nearest, as astype(float32)
+    }
+}
+size_t dtype_size(int32_t dtype) {
+    switch (dtype) {
+        case BRIE_DT_F32: case BRIE_DT_I32: case BRIE_DT_U32: return 4;
+        case BRIE_DT_F64: case BRIE_DT_I64: return 8;
+        case BRIE_DT_I16: case BRIE_DT_U16: return 2;
+        case BRIE_DT_U8: return 1;
+        default: return 0;
+    }
+}
+// rows of a typed source -> `pin`: u16 (returns 0) or, when the slab holds anything else, float32 (returns 1)
+int convert_slab(const void *src, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, void *pin) {
+    uint16_t *d16 = static_cast<uint16_t *>(pin);
+    float *d32 = static_cast<float *>(pin);
+#define BRIE_SLAB(T, FN)                                                                 \
+    {                                                                                    \
+        const T *s = static_cast<const T *>(src);                                        \
+        if (FN(s, ld, rows, cols, d16) == 0) return 0;                                   \
+        cast_rows_f32<T>(s, ld, rows, cols, d32);                                        \
+        return 1;                                                                        \
+    }
+    switch (dtype) {
+        case BRIE_DT_F64: BRIE_SLAB(double, convert_rows_u16_f64)
+        case BRIE_DT_I32: BRIE_SLAB(int32_t, convert_rows_u16_i32)
+        case BRIE_DT_I64: BRIE_SLAB(int64_t, convert_rows_u16_i64)
+        case BRIE_DT_U32: BRIE_SLAB(uint32_t, convert_rows_u16_u32)
+        case BRIE_DT_I16: BRIE_SLAB(int16_t, convert_rows_u16_i16)
+        case BRIE_DT_U16: BRIE_SLAB(uint16_t, convert_rows_u16_u16)
+        case BRIE_DT_U8: BRIE_SLAB(uint8_t, convert_rows_u16_u8)
+        default: {
+            const float *s = static_cast<const float *>(src);
+            if (convert_rows_u16(s, ld, rows, cols, d16) == 0) return 0;
+            for (int64_t r = 0; r < rows; ++r)                       // fractional / huge / negative: the values themselves
+                memcpy(d32 + r * cols, s + r * ld, static_cast<size_t>(cols) * sizeof(float));
+            return 1;
+        }
+    }
+#undef BRIE_SLAB
+}
 
 bool use_staged_ingest(const brie_handle *h, const void *src, int64_t elems) {
     const char *m = getenv("BRIE_INGEST");               // "direct" / "staged": force (A/B runs, tests)
@@ -714,7 +805,9 @@ bool use_staged_ingest(const brie_handle *h, const void *src, int64_t elems) {
     return elems >= min_elems;
 }
 
-int staged_count_upload(brie_handle *h, float *dev, const float *src, int64_t ld) {
+int staged_count_upload(brie_handle *h, float *dev, const void *src_any, int32_t dtype, int64_t ld) {
+    const char *src = static_cast<const char *>(src_any);
+    const size_t esz = dtype_size(dtype);
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     std::lock_guard<std::mutex> lock(g_ingest.mu);
     const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
@@ -754,11 +847,7 @@ int staged_count_upload(brie_handle *h, float *dev, const float *src, int64_t ld
             if (k >= 2) e = hipEventSynchronize(ln.ev[b]);            // the copy out of this page-locked slab is done
             if (e != hipSuccess) break;
             const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
-            const float *rows_src = src + r0 * ld;
-            const uint32_t bad = convert_rows_u16(rows_src, ld, rows, Ng, static_cast<uint16_t *>(ln.pin[b]));
-            if (bad)                                                  // fractional / huge / negative: the values themselves
-                for (int64_t r = 0; r < rows; ++r)
-                    memcpy(static_cast<float *>(ln.pin[b]) + r * Ng, rows_src + r * ld, static_cast<size_t>(Ng) * sizeof(float));
+            const int bad = convert_slab(src + static_cast<size_t>(r0) * ld * esz, dtype, ld, rows, Ng, ln.pin[b]);
             const size_t bytes = static_cast<size_t>(rows) * Ng * (bad ? sizeof(float) : sizeof(uint16_t));
             e = hipMemcpyAsync(ln.dev[b], ln.pin[b], bytes, hipMemcpyHostToDevice, ln.stream);
             if (e == hipSuccess) e = hipEventRecord(ln.ev[b], ln.stream);
@@ -1026,7 +1115,7 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     if (R * C > 0) {
         const bool cellgene = (which <= BRIE_COUNT3) || which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG;
         if (which <= BRIE_COUNT3 && use_staged_ingest(h, src, R * C)) {
-            if ((rc = staged_count_upload(h, dev, src, ld)) != BRIE_OK) return rc;
+            if ((rc = staged_count_upload(h, dev, src, BRIE_DT_F32, ld)) != BRIE_OK) return rc;
         } else if (cellgene) {
             if ((rc = copy_cellgene(h, dev, src, nullptr, ld)) != BRIE_OK) return rc;
         } else {
@@ -1038,6 +1127,38 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
     if (which >= BRIE_COUNT1 && which <= BRIE_COUNT3) h->have_c[which - BRIE_COUNT1] = true;
     if (which == BRIE_XC) h->have_xc = true;
     if (which == BRIE_Z_LOC || which == BRIE_Z_STD_LOG) h->have_state = true;
+    return BRIE_OK;
+}
+
+// A count layer in the element type the caller holds it in (the reference casts on the host: .astype(np.float32)).
+// Always host memory; converted by the staged pipeline's threads (u16 slabs when integral, else the float32 cast).
+int brie_upload_typed(brie_handle *h, int which, const void *src, int32_t dtype, int64_t rows, int64_t cols, int64_t ld) {
+    if (!h || (!src && rows * cols > 0)) return fail(BRIE_ERR_INVALID, "null argument");
+    if (which < BRIE_COUNT1 || which > BRIE_COUNT3 || which - BRIE_COUNT1 >= h->p.n_layers)
+        return fail(BRIE_ERR_INVALID, "brie_upload_typed takes a count layer (got array %d)", which);
+    if (dtype_size(dtype) == 0) return fail(BRIE_ERR_INVALID, "dtype %d (see brie_dtype)", dtype);
+    if (rows != h->p.Nc || cols != h->p.Ng)
+        return fail(BRIE_ERR_INVALID, "layer must be (%lld, %lld), got (%lld, %lld)", (long long)h->p.Nc,
+                    (long long)h->p.Ng, (long long)rows, (long long)cols);
+    if (ld < cols) return fail(BRIE_ERR_INVALID, "ld=%lld < cols=%lld", (long long)ld, (long long)cols);
+    if (dtype == BRIE_DT_F32) return brie_upload(h, which, static_cast<const float *>(src), rows, cols, ld);
+    int rc = set_device(h);
+    if (rc != BRIE_OK) return rc;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) {
+        if (at.type == hipMemoryTypeDevice) return fail(BRIE_ERR_UNSUPPORTED, "typed layers are converted on the host: pass host memory");
+    } else {
+        (void)hipGetLastError();
+    }
+    if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
+    if (h->cs != brie::kCountF32 || h->compact_tried) {               // a fresh layer restarts the storage decision
+        if ((rc = expand_counts(h)) != BRIE_OK) return rc;
+        h->compact_tried = false;
+        const char *cst = getenv("BRIE_COUNT_STORAGE");
+        h->allow_compact = !(cst && strcmp(cst, "f32") == 0);
+    }
+    if ((rc = staged_count_upload(h, h->c[which - BRIE_COUNT1], src, dtype, ld)) != BRIE_OK) return rc;
+    h->have_c[which - BRIE_COUNT1] = true;
     return BRIE_OK;
 }
 
@@ -1905,6 +2026,16 @@ int brie_host_convert_u16(const float *src, int64_t rows, int64_t cols, int64_t 
     uint32_t any = 0;
     for (uint32_t b : bad) any |= b;
     *not_integral = any ? 1 : 0;
+    return BRIE_OK;
+}
+
+// one slab of the typed ingest on the host alone (tests): dst receives rows x cols u16 (*is_f32 = 0) or float32 (= 1)
+int brie_host_convert_slab(const void *src, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, void *dst, int32_t *is_f32) {
+    if (!is_f32 || rows < 0 || cols < 0 || ld < cols || dtype_size(dtype) == 0) return fail(BRIE_ERR_INVALID, "bad argument");
+    *is_f32 = 0;
+    if (rows * cols == 0) return BRIE_OK;
+    if (!src || !dst) return fail(BRIE_ERR_INVALID, "null argument");
+    *is_f32 = convert_slab(src, dtype, ld, rows, cols, dst);
     return BRIE_OK;
 }
 

@@ -50,6 +50,9 @@ def _dense_f32(x):
     layers are handed to the library as they are and densified on the device (brie_upload_sparse)."""
     if hasattr(x, "tocsc") or hasattr(x, "data_ptr"):
         return x
+    if (isinstance(x, np.ndarray) and x.ndim == 2 and x.dtype.name in _capi.TYPED_DTYPES and x.size
+            and x.strides[1] == x.itemsize and x.strides[0] % x.itemsize == 0 and x.strides[0] >= x.shape[1] * x.itemsize):
+        return x                  # integer / float64 layers (row views included) go up as they are: brie_upload_typed
     return np.ascontiguousarray(x, dtype=np.float32)
 
 

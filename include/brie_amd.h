@@ -113,6 +113,17 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
 int brie_upload(brie_handle *h, int which, const float *src,
                 int64_t rows, int64_t cols, int64_t ld);
 
+/* A count layer in the element type the caller holds it in (the reference casts whatever it gets on the host,
+ * .astype(np.float32): io_utils.py:18, model_wrap.py:111 -- a single-threaded pass over 4-8 GB at configs[2]).  Host
+ * memory only; the staged pipeline's threads convert row slabs to u16 when they hold nothing but integers in
+ * [0, 65535], else to the float32 the reference's cast would give; the layer ends up bit-identical to
+ * brie_upload(astype(float32)).  `ld` in ELEMENTS of the source type. */
+typedef enum brie_dtype {
+    BRIE_DT_F32 = 0, BRIE_DT_F64 = 1, BRIE_DT_I32 = 2, BRIE_DT_I64 = 3, BRIE_DT_U8 = 4, BRIE_DT_U16 = 5, BRIE_DT_I16 = 6,
+    BRIE_DT_U32 = 7
+} brie_dtype;
+int brie_upload_typed(brie_handle *h, int which, const void *src, int32_t dtype, int64_t rows, int64_t cols, int64_t ld);
+
 /* A count layer given as scipy-style compressed sparse (format 0 = CSC: indptr per gene, indices =
  * cells; 1 = CSR: indptr per cell, indices = genes; int64 indptr, int32 indices, fp32 data; host or
  * device pointers).  Densified ON THE DEVICE (duplicates summed) -- the reference densifies on the
@@ -243,6 +254,9 @@ int brie_host_unregister(void *ptr);
  * brie_host_convert_u16 is the host half on its own (tests, host-bandwidth measurements; no GPU involved):
  * dst[r][c] = (uint16) src[r*ld + c], *not_integral = 1 when some value is not a non-negative integer <= 65535. */
 int brie_host_convert_u16(const float *src, int64_t rows, int64_t cols, int64_t ld, uint16_t *dst, int32_t *not_integral);
+/* ... and one slab of a typed source (brie_dtype): dst receives rows x cols u16 (*is_f32 = 0: every value an integer in
+ * [0, 65535]) or the float32 cast of the values (*is_f32 = 1); dst must hold rows x cols x 4 bytes. */
+int brie_host_convert_slab(const void *src, int32_t dtype, int64_t rows, int64_t cols, int64_t ld, void *dst, int32_t *is_f32);
 
 /* Noise-draw counter (one draw id per loss evaluation). */
 int brie_get_draw(brie_handle *h, uint32_t *draw);

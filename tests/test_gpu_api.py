@@ -265,7 +265,11 @@ def test_count_layers_in_any_container_give_the_same_fit(lib):
     P = make_problem(Nc, Ng, Kc=1, L=2, seed=6)
     variants = {
         "float32": lambda c: c,
-        "int32": lambda c: c.astype(np.int32),
+        "int32": lambda c: c.astype(np.int32),               # integer / float64 layers: brie_upload_typed, no numpy cast
+        "int64": lambda c: c.astype(np.int64),
+        "uint16": lambda c: c.astype(np.uint16),
+        "float64": lambda c: c.astype(np.float64),
+        "int32_row_view": lambda c: np.concatenate([c, c], axis=1).astype(np.int32)[:, :Ng],   # row pitch > row length
         "float64_fortran": lambda c: np.asfortranarray(c.astype(np.float64)),
         "coo": lambda c: sp.coo_matrix(c),
         "csr": lambda c: sp.csr_matrix(c),

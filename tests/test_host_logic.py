@@ -268,6 +268,35 @@ def test_staged_ingest_host_half_converts_exactly_or_says_so(built_lib):
     assert _capi.host_convert_u16(np.zeros((0, 5), np.float32))[0].shape == (0, 5)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64", "int32", "int64", "uint8", "uint16", "int16", "uint32"])
+def test_typed_ingest_conversion_equals_the_reference_cast(built_lib, dtype):
+    """brie_upload_typed's host half (brie_host_convert_slab): a count layer held as integers or float64 is never cast
+    by numpy first.  Integers in [0, 65535] travel as exact u16; anything else as the float32 the reference's
+    `.astype(np.float32)` (io_utils.py:18, model_wrap.py:111) would give."""
+    from brie_amd import _capi
+    rng = np.random.default_rng(11)
+    hi = {"uint8": 255, "int16": 30000}.get(dtype, 65535)
+    a = rng.integers(0, 40, (23, 517)).astype(dtype)
+    a[3, 5], a[22, 516] = hi, 1
+    out, as_f32 = _capi.host_convert_slab(a)
+    assert not as_f32 and out.dtype == np.uint16
+    np.testing.assert_array_equal(out, a.astype(np.uint16))
+    odd = []                                                    # values that do not fit u16: the float32 cast instead
+    if dtype.startswith("float"):
+        odd = [0.25, -1.0, 70000.0, np.nan, -0.0, 1e30 if dtype == "float64" else 3e38, 16777217.0]
+    elif dtype in ("int32", "int64", "int16"):
+        odd = [-1, -30000] + ([70000, 2 ** 31 - 1] if dtype != "int16" else []) + ([2 ** 40 + 1] if dtype == "int64" else [])
+    elif dtype == "uint32":
+        odd = [65536, 2 ** 32 - 1]
+    for val in odd:
+        b = a.copy()
+        b[11, 200] = val
+        out, as_f32 = _capi.host_convert_slab(b)
+        assert as_f32 and out.dtype == np.float32, val
+        want = b.astype(np.float32)
+        assert np.array_equal(out, want, equal_nan=True) and np.array_equal(np.signbit(out), np.signbit(want)), val
+
+
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):

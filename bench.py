@@ -115,8 +115,8 @@ def psi_delta_check(seed=11):
     """'PSI delta vs CPU ref' on BASELINE configs[0] (200 x 500, +1 covariate) after the WHOLE BRIE2.fit default
     schedule (6 x 166 Adam steps, fresh optimiser per stage, model_TFProb.py:234-241): HIP vs the CPU restatement in
     fp64, next to what the reference's own fp32 precision (the same restatement in fp32) does on that trajectory.
-    The parity rule these numbers are held to is tests/util.py::psi_parity_assert; all configs and both default
-    schedules are in profiles/psi_delta_r02.json."""
+    The parity rule these numbers are held to is tests/util.py::psi_parity_rule; 512-gene samples of configs[1] /
+    configs[2] and both default schedules are in profiles/psi_delta_r03.json."""
     from brie_amd import _capi
     from oracle.c_oracle import COracle
     from tests import util
@@ -132,14 +132,18 @@ def psi_delta_check(seed=11):
         sh.reset_optimizer()
         sh.step(n, lr, 1, trace=False)
     d = np.abs(sh.read(_capi.PSI) - o64.Psi)
-    d32 = np.abs(o32.Psi - o64.Psi)
     covered = (P["counts"][0] + P["counts"][1]) > 0
-    sh.close()
     out = {"workload": "200x500 Kc=1, 996 staged steps (BRIE2.fit defaults), same init + noise stream, vs fp64 CPU oracle"}
-    out.update(util.psi_parity_assert(d, d32, "bench psi check"))
+    rep = util.psi_parity_of(sh, o32, o64, what="bench psi check")
+    sh.close()
+    out.update({"max": rep["all_entries"]["max"], "p99": rep["all_entries"]["p99"],
+                "frac_gt_1e-4": rep["all_entries"]["frac_gt_1e-4"], "fp32_oracle": rep["all_entries"]["fp32_oracle"]})
+    out["displaced_genes"] = rep["displaced_genes"]
+    out["outside_displaced_genes"] = rep.get("undisplaced_genes")
     out["covered_entries"] = {"max": float(d[covered].max()), "frac_gt_1e-4": float((d[covered] > 1e-4).mean())}
     out["share_of_exceedances_with_zero_coverage"] = float(((d > 1e-4) & ~covered).sum() / max(1, (d > 1e-4).sum()))
-    out["rule"] = "tests/util.py::psi_parity_assert (bounded by the fp32 oracle's own distance from fp64); holds"
+    out["rule"] = ("tests/util.py::psi_parity_rule (displaced genes, and entries outside them, bounded by what the fp32 "
+                   "oracle -- the reference's own precision -- does on the same trajectory); holds")
     return out
 
 

@@ -185,6 +185,11 @@ def per_gene(psi, par, covered):
     return out
 
 
+def util_params(p):
+    return {"Wc_loc": np.asarray(p["Wc_loc"], np.float64), "intercept": np.asarray(p["intercept"], np.float64).reshape(-1),
+            "sigma_log": np.asarray(p["sigma_log"], np.float64).reshape(-1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_r03.json"))
@@ -233,6 +238,12 @@ def main():
             entry["pairs"]["%s_vs_%s" % (a, b)] = summary(psi[a], psi[b], covered)
         if "hip" in psi:
             entry["where_the_exceedances_sit"] = per_gene(psi, par, covered)
+            from tests import util
+            try:                                     # the frozen rule of the test-suite on this case
+                entry["parity_rule"] = dict(util.psi_parity_rule(psi, {k: util_params(par[k]) for k in ("hip", "o32", "o64")}, case),
+                                            holds=True)
+            except AssertionError as exc:
+                entry["parity_rule"] = {"holds": False, "violated": repr(exc)}
         result["cases"][case] = entry
         f = entry["pairs"]
         g = entry.get("where_the_exceedances_sit", {})

@@ -10,7 +10,7 @@ Kc=3) through properties that do not need the oracle to process 10^9 elements:
 import numpy as np
 import pytest
 
-from tests.util import psi_parity_assert
+from tests.util import psi_parity_of
 
 pytestmark = pytest.mark.gpu
 
@@ -118,7 +118,7 @@ def test_full_size_config2(lib):
     print("C2 PSI delta after 180 staged steps: HIP max %.3g p99.9 %.3g frac>1e-4 %.3g | fp32 oracle max %.3g "
           "p99.9 %.3g frac %.3g" % (d.max(), np.percentile(d, 99.9), (d > 1e-4).mean(), d32.max(),
                                      np.percentile(d32, 99.9), (d32 > 1e-4).mean()))
-    psi_parity_assert(d, d32)
+    psi_parity_of(sh, o32, o64, cols=slice(g0, g0 + 4), what="C2 staged")
     sh.close()
 
 
@@ -297,7 +297,7 @@ def test_full_size_config3_staged_schedule_psi(lib):
     d = np.abs(sh.read(_capi.PSI)[:, g0:g0 + 4] - o.Psi)
     d32 = np.abs(o32.Psi - o.Psi)
     # the parity rule (tests/util.py): no more entries beyond 1e-4 than the reference's own fp32 precision produces
-    print("C3 PSI delta after 150 staged steps:", psi_parity_assert(d, d32, "C3 staged"))
+    print("C3 PSI delta after 150 staged steps:", psi_parity_of(sh, o32, o, cols=slice(g0, g0 + 4), what="C3 staged"))
     np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:g0 + 4], o.Wc_loc, atol=5e-4)
     sh.close()
 
@@ -354,3 +354,47 @@ def test_full_size_config3_properties(lib):
     np.testing.assert_array_equal(tr_a, tr_b)
     assert digest(sh) == dig_a
     sh.close()
+
+
+def test_psi_parity_rule_on_a_512_gene_sample_of_configs2_after_the_full_default_schedule(lib):
+    """the parity claim on a real sample.  512 genes of the configs[2] recipe over ALL 50 000 cells,
+    the whole BRIE2.fit default schedule (6 x 166 Adam steps, fresh optimiser per stage, MC_size 1; model_TFProb.py:
+    234-241), HIP against the C restatement in fp64 and in fp32 -- and the frozen rule of tests/util.py::psi_parity_rule.
+    The two oracle runs take 15 minutes each on 8 cores, so they come from profiles/_psi_cache (written by
+    `python profiles/psi_delta.py --oracles-only`; it travels with the working tree); without the cache the same test
+    runs on a 64-gene sample with the oracles computed on the spot.
+    Also asserted: ENTRY-level exceedance ratio HIP / fp32-oracle <= 1.5 outside the displaced genes (measured 0.80 - 1.0;
+    over all entries it is 9: ONE displaced gene of the HIP run holds 34 884 of its 35 210 entries beyond 1e-4, the fp32
+    oracle displaces two other genes -- see DESIGN.md section 2)."""
+    import os
+    from brie_amd import _capi
+    from oracle.c_oracle import COracle
+    from tests import util
+    cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "_psi_cache")
+    files = {k: os.path.join(cache, "c3_api_512_%s.npz" % k) for k in ("float32", "float64")}
+    have = all(os.path.exists(f) for f in files.values())
+    Nc, Ng, Kc, seed = 50000, (512 if have else 64), 3, 11          # SEED / shapes of profiles/psi_delta.py::CASES
+    P = util.problem(Nc, Ng, Kc, 2, theta=1.5)
+    sh = util.device_shard(P, Nc, Ng, Kc, seed)
+    for n, lr in util.staged_schedule(1000):
+        sh.reset_optimizer()
+        sh.step(n, lr, 1, trace=False)
+    psi = {"hip": sh.read(_capi.PSI)}
+    par = {"hip": util.run_params(sh)}
+    sh.close()
+    for key, dt, name in (("o32", np.float32, "float32"), ("o64", np.float64, "float64")):
+        if have:
+            z = np.load(files[name])
+            psi[key] = z["psi"]
+            par[key] = {"Wc_loc": np.asarray(z["Wc_loc"], np.float64), "intercept": np.asarray(z["intercept"], np.float64).reshape(-1),
+                        "sigma_log": np.asarray(z["sigma_log"], np.float64).reshape(-1)}
+        else:
+            o = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=dt)
+            for n, lr in util.staged_schedule(1000):
+                o.reset_optimizer()
+                o.minimize(n, lr, 1)
+            psi[key], par[key] = np.asarray(o.Psi, np.float32), util.run_params(o)
+    rep = util.psi_parity_rule(psi, par, "configs[2] sample, %d genes x %d cells, 996 steps" % (Ng, Nc))
+    print("sample of %d genes (%s):" % (Ng, "cached oracles" if have else "oracles computed here"), rep)
+    u = rep["undisplaced_genes"]
+    assert u["gt_1e-4"]["hip"] <= 1.5 * u["gt_1e-4"]["fp32_oracle"] + 50, u

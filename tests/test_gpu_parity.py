@@ -2,14 +2,15 @@
 
 Tolerances (floating point path; north star: PSI within 1e-4 of the CPU path):
   * noise stream eps: 2e-6 absolute (fp32 Box-Muller vs fp64-rounded oracle)
-  * a few Adam steps: 99.9 % of every state array within 2e-5, max within 1e-3.
-    (Adam's first updates are lr*g/(|g|+eps'): an element whose gradient is
-    ~1e-5 amplifies fp32 rounding differences by ~lr*1e-7/|g|, so the max is
-    bounded separately from the bulk.)
-  * PSI after a staged fit: tests/util.py::psi_parity_assert -- the entries beyond
-    1e-4 of the fp64 oracle are counted and bounded by what the fp32 oracle (the
-    reference's own precision) produces on the same trajectory
-    (evidence: profiles/psi_delta_r02.json).
+  * a few Adam steps: assert_states_close -- 99.9 % of every state array within 5e-6,
+    every element within 1e-3 except at most one sign-flipped element per array
+    (Adam's first update of a fresh optimiser is +-lr whatever |g| is, so an
+    element with g ~ 0 moves on the sign of a rounding error), itself bounded by
+    2.2 lr per fresh optimiser; sized by 1 000 soak cases (profiles/r3c_soak_record.json).
+  * PSI after a staged fit: tests/util.py::psi_parity_rule -- displaced genes and,
+    outside them, entries beyond 1e-4 of the fp64 oracle are counted and bounded by
+    what the fp32 oracle (the reference's own precision) produces on the same
+    trajectory (evidence: profiles/psi_delta_r03.json).
 """
 import numpy as np
 import pytest
@@ -23,16 +24,18 @@ pytestmark = pytest.mark.gpu
 _RECORD = None            # tests/tools/soak_randomised.py sets a list: (array, n, p99.9, max, n beyond `worst`) per call
 
 
-def assert_states_close(so, sd, bulk=2e-5, worst=1e-3, lr=0.01, fresh=1):
-    """State arrays of the oracle and of the device after a few Adam steps (the short-horizon parity rule).
+def assert_states_close(so, sd, bulk=5e-6, worst=1e-3, lr=0.01, fresh=1):
+    """State arrays of the oracle and of the device after a few Adam steps (the short-horizon parity rule), sized by
+    what 1 000 soak cases of the two random families need (profiles/r3c_soak_record.json: 6 545 comparisons; the
+    99.9 % quantile of an array of >= 1000 elements never above 1.9e-6; 6 comparisons with ONE element beyond 1e-3,
+    the largest 2.3e-3).
 
-      bulk    99.9 % of every array within `bulk` (2e-5);
+      bulk    99.9 % of every array of >= 1000 elements within `bulk` (5e-6; smaller arrays fall under `worst` alone);
       worst   every element within `worst` (1e-3) -- EXCEPT sign flips: Keras Adam's first update of a fresh optimiser
               is lr * g / (|g| + 1e-7), i.e. +-lr whatever |g| is, so an element whose gradient is ~0 (zero coverage,
               mu on its prior mean: |g| ~ 1e-8) moves by +lr or -lr on the SIGN of a rounding error.  Such an element
               may sit up to 2 lr apart per fresh optimiser in the sequence (`fresh`; + 10 % for the steps that follow),
-              and there may be at most max(1, 1e-4 n) of them per array.  (1 000 soak cases of the two random families
-              need exactly this: profiles/r3c_soak.log -- before, two of them were explained in a log.)"""
+              and there may be at most max(1, 1e-4 n) of them per array."""
     for k in util.STATE_KEYS:
         if so[k].size == 0:
             continue
@@ -41,7 +44,8 @@ def assert_states_close(so, sd, bulk=2e-5, worst=1e-3, lr=0.01, fresh=1):
         if _RECORD is not None:
             _RECORD.append((k, int(d.size), float(np.percentile(d, 99.9)), float(d.max()), n_out))
             continue
-        assert np.percentile(d, 99.9) < bulk, (k, float(np.percentile(d, 99.9)))
+        if d.size >= 1000:
+            assert np.percentile(d, 99.9) < bulk, (k, float(np.percentile(d, 99.9)))
         assert n_out <= max(1, int(1e-4 * d.size)), (k, "elements beyond %g" % worst, n_out, float(d.max()))
         assert d.max() < max(worst, 2.2 * lr * fresh), (k, float(d.max()))
 
@@ -133,7 +137,7 @@ def test_psi_after_staged_fit(lib, Nc, Ng, Kc, L, MC, min_iter):
     d_o32 = np.abs(o32.Psi - o64.Psi)
     print("PSI delta vs fp64 oracle: HIP max %.3g p99 %.3g | fp32 oracle max %.3g p99 %.3g"
           % (d_dev.max(), np.percentile(d_dev, 99), d_o32.max(), np.percentile(d_o32, 99)))
-    util.psi_parity_assert(d_dev, d_o32, "Psi")            # the parity rule, stated once (tests/util.py)
+    print(util.psi_parity_of(sh, o32, o64, what="Psi"))     # the parity rule, stated once (tests/util.py)
     # same rule for the interval width and the prior width: bulk tight, worst element bounded by
     # what the reference's own precision (fp32 oracle) does on the same trajectory
     for name, dev, ref64, ref32 in (("Psi95CI", sh.read(_capi.PSI95CI), o64.Psi95CI, o32.Psi95CI),
@@ -162,9 +166,7 @@ def test_psi_after_full_default_schedule(lib, Kc):
             o.minimize(n, lr, 1)
         sh.reset_optimizer()
         sh.step(n, lr, 1, trace=False)
-    d = np.abs(sh.read(_capi.PSI) - o64.Psi)
-    d32 = np.abs(o32.Psi - o64.Psi)
-    print("996 steps, Kc=%d:" % Kc, util.psi_parity_assert(d, d32, "Psi after 996 steps"))
+    print("996 steps, Kc=%d:" % Kc, util.psi_parity_of(sh, o32, o64, what="Psi after 996 steps"))
     sh.close()
 
 

@@ -22,14 +22,14 @@ for case in T._random_cases(n_shapes, seed=seed):
         shape_fn(None, *case)
     except Exception as e:      # noqa
         fails += 1
-        print("SHAPE CASE FAILED", case, "->", str(e).splitlines()[0][:300] if str(e) else traceback.format_exc()[-400:], flush=True)
+        print("SHAPE CASE FAILED", case, "->", " | ".join(l for l in str(e).splitlines() if l.strip())[:600] or traceback.format_exc()[-600:], flush=True)
 print("shape cases done:", n_shapes, "failures so far:", fails, flush=True)
 for case in T._op_sequences(n_seq, seed=seed + 1):
     try:
         seq_fn(None, *case)
     except Exception as e:      # noqa
         fails += 1
-        print("SEQUENCE FAILED", case, "->", str(e).splitlines()[0][:300] if str(e) else traceback.format_exc()[-400:], flush=True)
+        print("SEQUENCE FAILED", case, "->", " | ".join(l for l in str(e).splitlines() if l.strip())[:600] or traceback.format_exc()[-600:], flush=True)
 print("sequences done:", n_seq, "total failures:", fails, flush=True)
 if RECORD:
     rec = T._RECORD

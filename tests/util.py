@@ -66,32 +66,86 @@ def staged_schedule(min_iter):
     return [(int(min_iter / 6), lr) for lr in LEARNING_RATES]
 
 
-def psi_parity_assert(d, d32, what=""):
-    """THE parity rule of the floating-point path (north star: PSI within 1e-4).
+PSI_TOL = 1e-4                  # north star: PSI within 1e-4 of the CPU path
+GENE_SHIFT = 4 * PSI_TOL        # a shift of a gene's OWN parameter (Wc_loc column, intercept, sigma_log) that moves Psi by
+                                # PSI_TOL where sigmoid' is largest (1/4): such a gene is "displaced" as a whole
 
-    d   = |Psi_hip - Psi_o64|   HIP path vs the fp64 oracle (the precision-independent answer)
-    d32 = |Psi_o32 - Psi_o64|   the reference's own precision (fp32 oracle) vs the same answer, same entries
 
-    Keras Adam moves every entry by lr * m / (sqrt(v) + eps): where a gradient passes through ~0 the SIGN of an
-    fp32 rounding error decides an O(lr) move (a fresh optimiser's first step is +-lr whatever |g| is), so any two
-    fp32 evaluations of the reference's arithmetic -- TF on another CPU included -- differ by more than 1e-4 on a
-    fraction of the entries.  Measured after the full default schedules (profiles/psi_delta_r02.json): that fraction
-    is the same for HIP-vs-fp64 and fp32-oracle-vs-fp64 (C3: 3e-5 vs 1e-5, >90 % of them zero-coverage entries;
-    the 200-cell configs[0]: 6e-3 vs 5e-3 at 996 steps, 2.4e-2 vs 2.4e-2 at 4998), and strict IEEE math on the
-    device does not change it.  So parity = "as close to the precision-independent answer as the reference's own
-    fp32 arithmetic gets on the same trajectory":
-      1. bulk:        p99(d) <= max(1e-4, 1.5 p99(d32));
-      2. exceedances: #(d > 1e-4) <= 3 #(d32 > 1e-4) + max(5e-5 n, 20)   (the exceedances come in per-gene clusters --
-                      a gene's Wc_loc / intercept / sigma trajectory shifts all its cells -- so between two fp32
-                      evaluations their count fluctuates far more than Poisson: factor 3 and a small floor);
-      3. worst entry: max d <= max(2e-3, 3 max d32)   (a fifth of what ONE flipped +-lr step can do: 0.25 * 2 * 0.02)."""
-    d, d32 = np.asarray(d, np.float64).ravel(), np.asarray(d32, np.float64).ravel()
-    n, n32 = int((d > 1e-4).sum()), int((d32 > 1e-4).sum())
-    assert np.percentile(d, 99) <= max(1e-4, 1.5 * np.percentile(d32, 99)), \
-        (what, "p99", float(np.percentile(d, 99)), float(np.percentile(d32, 99)))
-    assert n <= 3 * n32 + max(5e-5 * d.size, 20), (what, "entries beyond 1e-4: HIP %d, fp32 oracle %d of %d" % (n, n32, d.size))
-    assert d.max() <= max(2e-3, 3 * d32.max()), (what, "max", float(d.max()), float(d32.max()))
-    return {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "p99.9": float(np.percentile(d, 99.9)),
-            "frac_gt_1e-4": n / d.size, "fp32_oracle": {"max": float(d32.max()), "p99": float(np.percentile(d32, 99)),
-                                                         "p99.9": float(np.percentile(d32, 99.9)),
-                                                         "frac_gt_1e-4": n32 / d32.size}}
+def run_params(obj, cols=None):
+    """The per-gene parameters of a run -- an oracle (OracleBRIE2 / COracle) or a device shard -- as float64:
+    dict(Wc_loc (Kc, Ng), intercept (Ng,), sigma_log (Ng,)); `cols`: gene slice of a larger shard."""
+    if hasattr(obj, "read"):
+        from brie_amd import _capi
+        W, b, lam = obj.read(_capi.WC_LOC), obj.read(_capi.INTERCEPT), obj.read(_capi.SIGMA_LOG)
+    else:
+        W, b, lam = obj.Wc_loc, obj.intercept, obj.sigma_log
+    W, b, lam = np.asarray(W, np.float64), np.asarray(b, np.float64).reshape(-1), np.asarray(lam, np.float64).reshape(-1)
+    if cols is not None:
+        W, b, lam = W[:, cols], b[cols], lam[cols]
+    return {"Wc_loc": W, "intercept": b, "sigma_log": lam}
+
+
+def gene_shift(pa, pb):
+    """max over a gene's own parameters of |difference| between two runs, (Ng,)."""
+    w = np.abs(pa["Wc_loc"] - pb["Wc_loc"])
+    w = w.max(0) if w.size else np.zeros(pa["intercept"].shape[0])
+    return np.maximum(w, np.maximum(np.abs(pa["intercept"] - pb["intercept"]), np.abs(pa["sigma_log"] - pb["sigma_log"])))
+
+
+def psi_parity_rule(psi, par, what=""):
+    """THE parity rule of the floating-point path (north star: PSI within 1e-4 of the CPU path),
+    frozen in round 3 on 512-gene x all-cell samples of configs[1] / configs[2] and the 200-cell configs[0], both default
+    schedules (profiles/psi_delta_r03.json).
+
+    psi[k], par[k] for k in 'hip' (the HIP path), 'o32' (the CPU restatement in fp32 = the reference's precision),
+    'o64' (the same in fp64 = the precision-independent answer); same init, same noise stream.
+
+    Why not "every entry within 1e-4": Keras Adam moves a parameter by lr * m / (sqrt(v) + eps); the first step of each of
+    the six fresh optimisers is +-lr whatever |g| is, so where a gradient is ~0 the SIGN of an fp32 rounding error decides
+    an O(lr) move.  Any two fp32 evaluations of the reference's arithmetic differ by more than 1e-4 somewhere.  The evidence
+    says where: when the sign event hits one of a gene's OWN parameters (a Wc_loc entry, its intercept, its sigma) all
+    Nc cells of that gene move together -- at configs[2] ONE such gene of 512 carries 34 884 of the HIP path's 35 210
+    entries beyond 1e-4, and the fp32 oracle has two other such genes -- and everywhere else the two fp32 runs have the
+    same handful of entries beyond 1e-4 (326 vs 327 of 25.4 M).  So the rule counts displaced GENES and, outside them,
+    ENTRIES, each against what the reference's own precision does on the same trajectory:
+
+      displaced gene: own-parameter shift vs the fp64 run > GENE_SHIFT = 4e-4 (moves Psi by 1e-4 where sigmoid' = 1/4).
+      1. genes:    #displaced(hip) <= 1.5 #displaced(o32) + max(3, 1 % of the genes);
+      2. entries of genes displaced in NEITHER run:  #(d > 1e-4) <= 1.5 #(d32 > 1e-4) + max(1e-5 n, 50);
+      3. their bulk:   p99(d) <= max(1e-4, 1.5 p99(d32));
+      4. their worst:  max d <= max(2e-3, 3 max d32)   (a fifth of what one flipped +-lr step of a CELL's own Z_loc can do);
+      5. a displaced gene is displaced by a bounded amount: shift <= 0.15 (the sum of the six stage learning rates is 0.051;
+         observed <= 0.092 on 200-cell data, <= 0.016 at 10k+ cells)."""
+    P = {k: np.asarray(psi[k], np.float64) for k in ("hip", "o32", "o64")}
+    d, d32 = np.abs(P["hip"] - P["o64"]), np.abs(P["o32"] - P["o64"])
+    s_h, s_o = gene_shift(par["hip"], par["o64"]), gene_shift(par["o32"], par["o64"])
+    disp_h, disp_o = s_h > GENE_SHIFT, s_o > GENE_SHIFT
+    Ng = d.shape[1]
+    keep = ~(disp_h | disp_o)
+    rep = {"genes": Ng, "displaced_genes": {"hip": int(disp_h.sum()), "fp32_oracle": int(disp_o.sum())},
+           "largest_gene_shift": {"hip": float(s_h.max()), "fp32_oracle": float(s_o.max())},
+           "all_entries": {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "frac_gt_1e-4": float((d > PSI_TOL).mean()),
+                           "fp32_oracle": {"max": float(d32.max()), "p99": float(np.percentile(d32, 99)),
+                                           "frac_gt_1e-4": float((d32 > PSI_TOL).mean())}}}
+    assert disp_h.sum() <= 1.5 * disp_o.sum() + max(3, 0.01 * Ng), (what, "displaced genes", rep["displaced_genes"])
+    assert s_h.max() <= 0.15, (what, "gene shift", float(s_h.max()))
+    if keep.any():
+        dk, dk32 = d[:, keep], d32[:, keep]
+        n, n32 = int((dk > PSI_TOL).sum()), int((dk32 > PSI_TOL).sum())
+        rep["undisplaced_genes"] = {"genes": int(keep.sum()), "entries": int(dk.size), "gt_1e-4": {"hip": n, "fp32_oracle": n32},
+                                    "p99": {"hip": float(np.percentile(dk, 99)), "fp32_oracle": float(np.percentile(dk32, 99))},
+                                    "max": {"hip": float(dk.max()), "fp32_oracle": float(dk32.max())}}
+        assert n <= 1.5 * n32 + max(1e-5 * dk.size, 50), (what, "entries beyond 1e-4 outside displaced genes", n, n32, dk.size)
+        assert np.percentile(dk, 99) <= max(PSI_TOL, 1.5 * np.percentile(dk32, 99)), (what, "p99", rep["undisplaced_genes"]["p99"])
+        assert dk.max() <= max(2e-3, 3 * dk32.max()), (what, "max", rep["undisplaced_genes"]["max"])
+    return rep
+
+
+def psi_parity_of(sh, o32, o64, cols=None, what=""):
+    """psi_parity_rule for a device shard against the two oracles (`cols`: the oracles hold only this gene slice)."""
+    from brie_amd import _capi
+    psi_h = sh.read(_capi.PSI)
+    if cols is not None:
+        psi_h = psi_h[:, cols]
+    return psi_parity_rule({"hip": psi_h, "o32": o32.Psi, "o64": o64.Psi},
+                           {"hip": run_params(sh, cols), "o32": run_params(o32), "o64": run_params(o64)}, what)

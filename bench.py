@@ -624,7 +624,8 @@ def main(argv=None):
             out["psi_delta_vs_cpu_ref"] = psi_delta_check()
         if not args.no_cpu_baseline:
             from oracle.brie_oracle_torch import time_reference_shape
-            cores = min(6, os.cpu_count() or 1)          # reference default --nproc 6 (bin/quant.py:183)
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = min(6, usable)                        # reference default --nproc 6 (bin/quant.py:183)
             n_gene = min(int(math.ceil(500000 / float(Nc))), sample_layers[0].shape[1])
             nb = max(1, min(3, sample_layers[0].shape[1] // n_gene))
 
@@ -648,7 +649,9 @@ def main(argv=None):
                 from oracle.c_oracle import COracle
                 from oracle.brie_oracle import add_pseudo_count
                 co = COracle(add_pseudo_count(sample_layers), Xc_host, effLen=None if L == 2 else eff_host, seed=seed)
-                co.set_threads(os.cpu_count() or 1)       # (torch.distributed.run exports OMP_NUM_THREADS=1)
+                # all cores THIS PROCESS may run on (a box reports 256 CPUs and grants 6 of them); set explicitly because
+                # torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks
+                co.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
                 co.minimize(2, 0.005, args.mc)
                 t0 = time.perf_counter()
                 co.minimize(3, 0.005, args.mc)

@@ -1543,7 +1543,11 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     f.partials = h->partials; f.W = h->W; f.m_W = h->m_W; f.v_W = h->v_W; f.b = h->b; f.m_b = h->m_b; f.v_b = h->v_b;
     f.lam = h->lam; f.m_lam = h->m_lam; f.v_lam = h->v_lam; f.ld = h->ld;
     f.gene_active = h->gene_active; f.ring_kl = h->ring_kl; f.ring_ll = h->ring_ll;
-    f.Ng = a.Ng; f.Kc = h->kernel_kc; f.n_chunks = h->n_chunks;
+    // gene POSITIONS the finalize walks: up to the end of the last real quad.  With the active quads packed to the front
+    // a full quad can land in the last position, whose genes 1..3 sit at positions >= Ng when Ng % 4 != 0 -- bounded by
+    // Ng, their carried losses were dropped from the trace and the loss ring (soak sequence 61 of call r3c).  The padding
+    // genes this adds are frozen by construction (mask 0) and carry zeros.
+    f.Ng = (a.Ng + brie::kVec - 1) / brie::kVec * brie::kVec; f.Kc = h->kernel_kc; f.n_chunks = h->n_chunks;
     f.train_b = h->cell_mode ? 0 : h->p.train_intercept;        // cell mode: the (1,Ng) vectors are not parameters
     f.train_lam = h->cell_mode ? 0 : h->p.train_sigma;
 

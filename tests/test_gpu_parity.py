@@ -737,6 +737,40 @@ def test_packing_active_quads_is_bit_identical(lib, monkeypatch):
     np.testing.assert_array_equal(a[7], P["counts_pc"][2])
 
 
+@pytest.mark.parametrize("Ng", [257, 258, 1027])
+def test_packing_with_a_ragged_last_quad_keeps_every_frozen_loss(lib, monkeypatch, Ng):
+    """Ng % 4 != 0: packing the active quads to the front moves a FULL quad into the last position, whose genes 1..3 then
+    sit at positions >= Ng.  The per-gene finalize used to stop at position Ng and dropped the carried losses of those
+    (frozen) genes from the trace and the loss ring -- found by soak sequence 61 of call r3c (profiles/r3d_soak_seq61_failure.log).
+    Trace, loss window and state against the oracle, and bit-identical to the unpacked run."""
+    Nc, Kc = 130, 3
+    P = util.problem(Nc, Ng, Kc, 3, seed=361)
+    rng = np.random.default_rng(961)
+    mask = rng.random(Ng) < 0.5
+    mask[Ng - 1] = True                                   # the ragged quad itself stays active and moves forward
+    full = [q for q in range(Ng // 4) if not mask[4 * q:4 * q + 4].any()]
+    assert full, "the mask must freeze at least one whole quad"
+    outs = []
+    for pack in ("1", "0"):
+        monkeypatch.setenv("BRIE_PACK_ACTIVE", pack)
+        o = util.oracle_model(P, Nc, Ng, Kc, 101, np.float32)
+        sh = util.device_shard(P, Nc, Ng, Kc, 101)
+        np.testing.assert_allclose(sh.step(2, 0.01, 2), o.minimize(P["counts_pc"], P["Xc"], 2, 0.01, 2), rtol=5e-5)
+        o.gene_active = mask.copy()
+        sh.set_gene_mask(mask)
+        tr, tr_o = sh.step(3, 0.01, 2), o.minimize(P["counts_pc"], P["Xc"], 3, 0.01, 2)
+        np.testing.assert_allclose(tr, tr_o, rtol=5e-5)
+        win = sh.read_loss_window(4)
+        np.testing.assert_allclose(win, np.asarray(o.lg_hist[-4:]), rtol=5e-5, atol=2e-3)
+        assert (win[-1][~mask] != 0).all()                # every frozen gene still carries its last loss
+        outs.append((tr, win, util.device_state(sh)))
+        sh.close()
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-6)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for k in util.STATE_KEYS:
+        np.testing.assert_array_equal(outs[0][2][k], outs[1][2][k])
+
+
 def _random_cases(n, seed=20261001):
     """Seeded sweep over shapes and model switches (the same list on every run)."""
     rng = np.random.default_rng(seed)

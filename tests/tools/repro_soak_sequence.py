@@ -1,6 +1,6 @@
 """Reproduce soak sequence 61 (seed 31338) step by step and show WHERE the loss trace departs from the oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import util, test_gpu_parity as T
 from brie_amd import _capi

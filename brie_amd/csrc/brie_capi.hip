@@ -812,7 +812,7 @@ int staged_count_upload(brie_handle *h, float *dev, const void *src_any, int32_t
     std::lock_guard<std::mutex> lock(g_ingest.mu);
     const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
     const int64_t slab_elems = std::max<int64_t>(Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 21));   // 8 MB of fp32
-    const int64_t R = std::max<int64_t>(1, slab_elems / Ng);
+    const int64_t R = std::max<int64_t>(1, std::min<int64_t>(Nc, slab_elems / Ng));      // (small layers: small slabs, small pool)
     const int64_t n_slabs = (Nc + R - 1) / R;
     const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
     const size_t slab_bytes = static_cast<size_t>(R) * Ng * sizeof(float);
@@ -861,8 +861,11 @@ int staged_count_upload(brie_handle *h, float *dev, const void *src_any, int32_t
         if (e != hipSuccess) { (void)hipGetLastError(); err.store(static_cast<int>(e)); }
     };
     std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back(lane_fn, t);
-    lane_fn(0);
+    std::vector<int> inline_lanes{0};                     // lanes this thread walks itself: its own, and any whose thread
+    for (int t = 1; t < T; ++t) {                         // could not be created (no exception may cross the C ABI)
+        try { pool.emplace_back(lane_fn, t); } catch (...) { inline_lanes.push_back(t); }
+    }
+    for (int t : inline_lanes) lane_fn(t);
     for (std::thread &th : pool) th.join();
     (void)hipSetDevice(device);
     if (err.load() != 0)
@@ -1965,7 +1968,7 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
     h->io_pending = true;
     h->io_rc = BRIE_OK;
     const int device = h->p.device;
-    h->io_thread = std::thread([h, Nc, Ng, ld, slab_rows, device, psi, z_std, psi95ci, z_loc]() {
+    auto body = [h, Nc, Ng, ld, slab_rows, device, psi, z_std, psi95ci, z_loc]() {
         float *outs[4] = {psi, z_std, psi95ci, z_loc};
         auto bad = [h](const char *what, hipError_t e) {
             h->io_rc = BRIE_ERR_HIP;
@@ -2000,7 +2003,12 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
                 if (e != hipSuccess) { bad("copy", e); return; }
             }
         }
-    });
+    };
+    try {
+        h->io_thread = std::thread(body);
+    } catch (...) {               // no thread to be had: export on the caller's thread (no exception may cross the C ABI)
+        body();
+    }
     return BRIE_OK;
 }
 
@@ -2024,8 +2032,11 @@ int brie_host_convert_u16(const float *src, int64_t rows, int64_t cols, int64_t 
         const int64_t a = rows * t / T, b = rows * (t + 1) / T;
         bad[static_cast<size_t>(t)] = convert_rows_u16(src + a * ld, ld, b - a, cols, dst + a * cols);
     };
-    for (int t = 1; t < T; ++t) pool.emplace_back(part, t);
-    part(0);
+    std::vector<int> inline_parts{0};
+    for (int t = 1; t < T; ++t) {
+        try { pool.emplace_back(part, t); } catch (...) { inline_parts.push_back(t); }
+    }
+    for (int t : inline_parts) part(t);
     for (std::thread &th : pool) th.join();
     uint32_t any = 0;
     for (uint32_t b : bad) any |= b;

@@ -805,6 +805,33 @@ bool use_staged_ingest(const brie_handle *h, const void *src, int64_t elems) {
     return elems >= min_elems;
 }
 
+// the lanes of the staged host <-> device pipelines (ingest and result export share them); caller holds g_ingest.mu
+int ensure_lane_pool(int device, size_t slab_bytes, int T) {
+    if (g_ingest.device == device && g_ingest.slab_bytes >= slab_bytes && static_cast<int>(g_ingest.lanes.size()) >= T)
+        return BRIE_OK;
+    g_ingest.release();
+    g_ingest.lanes.resize(static_cast<size_t>(T));
+    g_ingest.device = device;
+    g_ingest.slab_bytes = slab_bytes;
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (IngestLane &ln : g_ingest.lanes) {
+        // highest priority: the short kernels of a slab must get compute units as they free up, also next to a long
+        // kernel on the handle's stream (the result export runs under the 500-draw loss_gene pass)
+        hipError_t e = hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, prio_hi);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+            e = hipHostMalloc(&ln.pin[b], slab_bytes, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc(&ln.dev[b], slab_bytes);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev[b], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {
+            g_ingest.release();
+            return fail(BRIE_ERR_HIP, "staging lanes: %s", hipGetErrorString(e));
+        }
+    }
+    return BRIE_OK;
+}
+
 int staged_count_upload(brie_handle *h, float *dev, const void *src_any, int32_t dtype, int64_t ld) {
     const char *src = static_cast<const char *>(src_any);
     const size_t esz = dtype_size(dtype);
@@ -816,23 +843,9 @@ int staged_count_upload(brie_handle *h, float *dev, const void *src_any, int32_t
     const int64_t n_slabs = (Nc + R - 1) / R;
     const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
     const size_t slab_bytes = static_cast<size_t>(R) * Ng * sizeof(float);
-    if (g_ingest.device != h->p.device || g_ingest.slab_bytes < slab_bytes || static_cast<int>(g_ingest.lanes.size()) < T) {
-        g_ingest.release();
-        g_ingest.lanes.resize(static_cast<size_t>(T));
-        g_ingest.device = h->p.device;
-        g_ingest.slab_bytes = slab_bytes;
-        for (IngestLane &ln : g_ingest.lanes) {
-            hipError_t e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
-            for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-                e = hipHostMalloc(&ln.pin[b], slab_bytes, hipHostMallocDefault);
-                if (e == hipSuccess) e = hipMalloc(&ln.dev[b], slab_bytes);
-                if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev[b], hipEventDisableTiming);
-            }
-            if (e != hipSuccess) {
-                g_ingest.release();
-                return fail(BRIE_ERR_HIP, "staged ingest buffers: %s", hipGetErrorString(e));
-            }
-        }
+    {
+        int rc_pool = ensure_lane_pool(h->p.device, slab_bytes, T);
+        if (rc_pool != BRIE_OK) return rc_pool;
     }
     HIP_TRY(hipStreamSynchronize(h->stream));             // earlier work on the layer (memset, a previous upload)
     std::atomic<int> err{0};
@@ -1948,6 +1961,123 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         if (pe && pe[0] == '0') HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
         else HIP_TRY(hipStreamCreateWithPriority(&h->io_stream, hipStreamNonBlocking, prio_hi));
         HIP_TRY(hipEventCreateWithFlags(&h->io_event, hipEventDisableTiming));
+    }
+    // Host destinations in PAGEABLE memory (what BRIE_RV passes): the staged export below.  A copy into pageable memory
+    // is pinned or staged page by page by the runtime, at a speed that is the box's (16 GB in 0.29 s on one, the tail
+    // behind loss_gene 0.08 s ... 0.26 s over the boxes of round 3).  Mirror image of the staged ingest: T threads each
+    // own a lane of the shared pool and walk every T-th row slab -- export_slab writes the slab's outputs into the
+    // lane's device buffer, one asynchronous copy brings them into its page-locked buffer, and while that copy runs the
+    // thread memcpy's the PREVIOUS slab from the other page-locked buffer into the caller's arrays.
+    {
+        float *outs0[4] = {psi, z_std, psi95ci, z_loc};
+        bool pageable = true;
+        for (float *q : outs0) {
+            if (!q) continue;
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, q) == hipSuccess) pageable = pageable && at.type == hipMemoryTypeUnregistered;
+            else (void)hipGetLastError();
+        }
+        const char *em = getenv("BRIE_EGRESS");                       // "direct" / "staged": force (A/B runs, tests)
+        const char *me = getenv("BRIE_EGRESS_MIN_ELEMS");
+        const int64_t min_elems = me ? atoll(me) : (int64_t(1) << 24);
+        const bool staged = pageable && !(em && strcmp(em, "direct") == 0) &&
+                            ((em && strcmp(em, "staged") == 0) || Nc * Ng >= min_elems);
+        if (staged) {
+            int n_out = 0;
+            for (float *q : outs0) n_out += q ? 1 : 0;
+            HIP_TRY(hipEventRecord(h->io_event, h->stream));          // the state is final once the main stream got here
+            h->io_pending = true;
+            h->io_rc = BRIE_OK;
+            const int device = h->p.device;
+            auto body = [h, Nc, Ng, ld, device, psi, z_std, psi95ci, z_loc, n_out]() {
+                float *outs[4] = {psi, z_std, psi95ci, z_loc};
+                std::lock_guard<std::mutex> lock(g_ingest.mu);
+                const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
+                const int64_t slab_elems = std::max<int64_t>(4 * Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 21));
+                const int64_t R = std::max<int64_t>(1, std::min<int64_t>(Nc, slab_elems / (4 * Ng)));   // rows per slab, 4 outputs
+                const int64_t n_slabs = (Nc + R - 1) / R;
+                const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
+                const size_t slab_bytes = static_cast<size_t>(R) * Ng * 4 * sizeof(float);
+                hipError_t e0 = hipSetDevice(device);
+                if (e0 != hipSuccess || ensure_lane_pool(device, slab_bytes, T) != BRIE_OK) {
+                    h->io_rc = BRIE_ERR_HIP;
+                    h->io_err = e0 != hipSuccess ? hipGetErrorString(e0) : g_last_error;
+                    return;
+                }
+                std::atomic<int> err{0};
+                auto lane_fn = [&](int t) {
+                    IngestLane &ln = g_ingest.lanes[static_cast<size_t>(t)];
+                    hipError_t e = hipSetDevice(device);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(ln.stream, h->io_event, 0);
+                    // slab k of this lane sits in buffer k & 1; `land` copies a completed slab into the caller's arrays
+                    auto land = [&](int64_t s, int b) {
+                        const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
+                        const float *p = static_cast<const float *>(ln.pin[b]);
+                        int i_out = 0;
+                        for (int i = 0; i < 4; ++i) {
+                            if (!outs[i]) continue;
+                            const float *src = p + static_cast<size_t>(i_out++) * R * Ng;
+                            if (ld == Ng) memcpy(outs[i] + r0 * ld, src, static_cast<size_t>(rows) * Ng * sizeof(float));
+                            else
+                                for (int64_t r = 0; r < rows; ++r)
+                                    memcpy(outs[i] + (r0 + r) * ld, src + r * Ng, static_cast<size_t>(Ng) * sizeof(float));
+                        }
+                    };
+                    int64_t k = 0, prev = -1;
+                    for (int64_t s = t; s < n_slabs && e == hipSuccess && err.load() == 0; s += T, ++k) {
+                        const int b = static_cast<int>(k & 1);
+                        const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
+                        float *base = static_cast<float *>(ln.dev[b]);
+                        brie::ExportSlabArgs a{};
+                        a.mu = h->mu; a.rho = h->rho;
+                        int i_out = 0;
+                        float *slabs[4];
+                        for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i_out++) * R * Ng : nullptr;
+                        a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
+                        a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+                        a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
+                        a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
+                        // (buffer b was landed two slabs ago, before this kernel is enqueued: see below)
+                        hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
+                                           dim3(256), 0, ln.stream, a);
+                        e = hipGetLastError();
+                        // one copy for all outputs of the slab: they are contiguous at pitch R x Ng
+                        if (e == hipSuccess)
+                            e = hipMemcpyAsync(ln.pin[b], ln.dev[b], (static_cast<size_t>(n_out - 1) * R + rows) * Ng * sizeof(float),
+                                               hipMemcpyDeviceToHost, ln.stream);
+                        if (e == hipSuccess) e = hipEventRecord(ln.ev[b], ln.stream);
+                        if (e != hipSuccess) break;
+                        if (prev >= 0) {                                   // while that copy runs: land the previous slab
+                            e = hipEventSynchronize(ln.ev[b ^ 1]);
+                            if (e == hipSuccess) land(prev, b ^ 1);
+                        }
+                        prev = s;
+                    }
+                    if (e == hipSuccess && prev >= 0) {
+                        e = hipEventSynchronize(ln.ev[static_cast<int>((k - 1) & 1)]);
+                        if (e == hipSuccess) land(prev, static_cast<int>((k - 1) & 1));
+                    }
+                    if (e != hipSuccess) { (void)hipGetLastError(); err.store(static_cast<int>(e)); }
+                };
+                std::vector<std::thread> pool;
+                std::vector<int> inline_lanes{0};
+                for (int t = 1; t < T; ++t) {
+                    try { pool.emplace_back(lane_fn, t); } catch (...) { inline_lanes.push_back(t); }
+                }
+                for (int t : inline_lanes) lane_fn(t);
+                for (std::thread &th : pool) th.join();
+                if (err.load() != 0) {
+                    h->io_rc = BRIE_ERR_HIP;
+                    h->io_err = std::string("staged export: ") + hipGetErrorString(static_cast<hipError_t>(err.load()));
+                }
+            };
+            try {
+                h->io_thread = std::thread(body);
+            } catch (...) {
+                body();
+            }
+            return BRIE_OK;
+        }
     }
     // slabs of ~64 M elements per output: the export kernel of a slab (microseconds to milliseconds) and its copies
     // are enqueued in order on the i/o stream, the copy engine streams while the main stream keeps computing

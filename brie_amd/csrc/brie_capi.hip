@@ -136,7 +136,7 @@ struct brie_handle {
     float *row_scratch = nullptr;   // scratch for per-gene row sets
     float *io_scratch = nullptr;    // (Nc, ld) staging buffer of brie_read, allocated on first use and kept
     // asynchronous result read-back (brie_read_results_async): second stream + slab staging
-    hipStream_t io_stream = nullptr;
+    hipStream_t io_stream = nullptr, io_stream2 = nullptr;     // slab k of an export runs on stream k & 1
     hipEvent_t io_event = nullptr;
     float *io_slab = nullptr;
     size_t io_slab_elems = 0;
@@ -176,6 +176,7 @@ int io_wait(brie_handle *h) {
         if (h->io_thread.joinable()) h->io_thread.join();
         h->io_pending = false;
         HIP_TRY(hipStreamSynchronize(h->io_stream));
+        if (h->io_stream2) HIP_TRY(hipStreamSynchronize(h->io_stream2));
         if (h->io_rc != BRIE_OK) {
             const int rc = h->io_rc;
             h->io_rc = BRIE_OK;
@@ -1044,6 +1045,7 @@ int brie_destroy(brie_handle *h) {
     // worker and its stream finish BEFORE anything is freed
     if (h->io_thread.joinable()) h->io_thread.join();
     if (h->io_stream) hipStreamSynchronize(h->io_stream);
+    if (h->io_stream2) hipStreamSynchronize(h->io_stream2);
     h->io_pending = false;
     if (h->stream) hipStreamSynchronize(h->stream);
     float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
@@ -1061,6 +1063,7 @@ int brie_destroy(brie_handle *h) {
     if (h->io_scratch) hipFree(h->io_scratch);
     if (h->win_scratch) hipFree(h->win_scratch);
     if (h->io_stream) hipStreamDestroy(h->io_stream);
+    if (h->io_stream2) hipStreamDestroy(h->io_stream2);
     if (h->io_event) hipEventDestroy(h->io_event);
     if (h->io_slab) hipFree(h->io_slab);
     (void)free_tier_tables(h);
@@ -1958,126 +1961,14 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const char *pe = getenv("BRIE_IO_STREAM_PRIORITY");         // "0": default priority (A/B runs)
-        if (pe && pe[0] == '0') HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
-        else HIP_TRY(hipStreamCreateWithPriority(&h->io_stream, hipStreamNonBlocking, prio_hi));
+        if (pe && pe[0] == '0') {
+            HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
+            HIP_TRY(hipStreamCreateWithFlags(&h->io_stream2, hipStreamNonBlocking));
+        } else {
+            HIP_TRY(hipStreamCreateWithPriority(&h->io_stream, hipStreamNonBlocking, prio_hi));
+            HIP_TRY(hipStreamCreateWithPriority(&h->io_stream2, hipStreamNonBlocking, prio_hi));
+        }
         HIP_TRY(hipEventCreateWithFlags(&h->io_event, hipEventDisableTiming));
-    }
-    // Host destinations in PAGEABLE memory (what BRIE_RV passes): the staged export below.  A copy into pageable memory
-    // is pinned or staged page by page by the runtime, at a speed that is the box's (16 GB in 0.29 s on one, the tail
-    // behind loss_gene 0.08 s ... 0.26 s over the boxes of round 3).  Mirror image of the staged ingest: T threads each
-    // own a lane of the shared pool and walk every T-th row slab -- export_slab writes the slab's outputs into the
-    // lane's device buffer, one asynchronous copy brings them into its page-locked buffer, and while that copy runs the
-    // thread memcpy's the PREVIOUS slab from the other page-locked buffer into the caller's arrays.
-    {
-        float *outs0[4] = {psi, z_std, psi95ci, z_loc};
-        bool pageable = true;
-        for (float *q : outs0) {
-            if (!q) continue;
-            hipPointerAttribute_t at;
-            if (hipPointerGetAttributes(&at, q) == hipSuccess) pageable = pageable && at.type == hipMemoryTypeUnregistered;
-            else (void)hipGetLastError();
-        }
-        const char *em = getenv("BRIE_EGRESS");                       // "direct" / "staged": force (A/B runs, tests)
-        const char *me = getenv("BRIE_EGRESS_MIN_ELEMS");
-        const int64_t min_elems = me ? atoll(me) : (int64_t(1) << 24);
-        const bool staged = pageable && !(em && strcmp(em, "direct") == 0) &&
-                            ((em && strcmp(em, "staged") == 0) || Nc * Ng >= min_elems);
-        if (staged) {
-            int n_out = 0;
-            for (float *q : outs0) n_out += q ? 1 : 0;
-            HIP_TRY(hipEventRecord(h->io_event, h->stream));          // the state is final once the main stream got here
-            h->io_pending = true;
-            h->io_rc = BRIE_OK;
-            const int device = h->p.device;
-            auto body = [h, Nc, Ng, ld, device, psi, z_std, psi95ci, z_loc, n_out]() {
-                float *outs[4] = {psi, z_std, psi95ci, z_loc};
-                std::lock_guard<std::mutex> lock(g_ingest.mu);
-                const char *se = getenv("BRIE_INGEST_SLAB_ELEMS");
-                const int64_t slab_elems = std::max<int64_t>(4 * Ng, se && atoll(se) > 0 ? atoll(se) : (int64_t(1) << 21));
-                const int64_t R = std::max<int64_t>(1, std::min<int64_t>(Nc, slab_elems / (4 * Ng)));   // rows per slab, 4 outputs
-                const int64_t n_slabs = (Nc + R - 1) / R;
-                const int T = static_cast<int>(std::min<int64_t>(ingest_threads(), n_slabs));
-                const size_t slab_bytes = static_cast<size_t>(R) * Ng * 4 * sizeof(float);
-                hipError_t e0 = hipSetDevice(device);
-                if (e0 != hipSuccess || ensure_lane_pool(device, slab_bytes, T) != BRIE_OK) {
-                    h->io_rc = BRIE_ERR_HIP;
-                    h->io_err = e0 != hipSuccess ? hipGetErrorString(e0) : g_last_error;
-                    return;
-                }
-                std::atomic<int> err{0};
-                auto lane_fn = [&](int t) {
-                    IngestLane &ln = g_ingest.lanes[static_cast<size_t>(t)];
-                    hipError_t e = hipSetDevice(device);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(ln.stream, h->io_event, 0);
-                    // slab k of this lane sits in buffer k & 1; `land` copies a completed slab into the caller's arrays
-                    auto land = [&](int64_t s, int b) {
-                        const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
-                        const float *p = static_cast<const float *>(ln.pin[b]);
-                        int i_out = 0;
-                        for (int i = 0; i < 4; ++i) {
-                            if (!outs[i]) continue;
-                            const float *src = p + static_cast<size_t>(i_out++) * R * Ng;
-                            if (ld == Ng) memcpy(outs[i] + r0 * ld, src, static_cast<size_t>(rows) * Ng * sizeof(float));
-                            else
-                                for (int64_t r = 0; r < rows; ++r)
-                                    memcpy(outs[i] + (r0 + r) * ld, src + r * Ng, static_cast<size_t>(Ng) * sizeof(float));
-                        }
-                    };
-                    int64_t k = 0, prev = -1;
-                    for (int64_t s = t; s < n_slabs && e == hipSuccess && err.load() == 0; s += T, ++k) {
-                        const int b = static_cast<int>(k & 1);
-                        const int64_t r0 = s * R, rows = std::min(R, Nc - r0);
-                        float *base = static_cast<float *>(ln.dev[b]);
-                        brie::ExportSlabArgs a{};
-                        a.mu = h->mu; a.rho = h->rho;
-                        int i_out = 0;
-                        float *slabs[4];
-                        for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i_out++) * R * Ng : nullptr;
-                        a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
-                        a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
-                        a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
-                        a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
-                        // (buffer b was landed two slabs ago, before this kernel is enqueued: see below)
-                        hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
-                                           dim3(256), 0, ln.stream, a);
-                        e = hipGetLastError();
-                        // one copy for all outputs of the slab: they are contiguous at pitch R x Ng
-                        if (e == hipSuccess)
-                            e = hipMemcpyAsync(ln.pin[b], ln.dev[b], (static_cast<size_t>(n_out - 1) * R + rows) * Ng * sizeof(float),
-                                               hipMemcpyDeviceToHost, ln.stream);
-                        if (e == hipSuccess) e = hipEventRecord(ln.ev[b], ln.stream);
-                        if (e != hipSuccess) break;
-                        if (prev >= 0) {                                   // while that copy runs: land the previous slab
-                            e = hipEventSynchronize(ln.ev[b ^ 1]);
-                            if (e == hipSuccess) land(prev, b ^ 1);
-                        }
-                        prev = s;
-                    }
-                    if (e == hipSuccess && prev >= 0) {
-                        e = hipEventSynchronize(ln.ev[static_cast<int>((k - 1) & 1)]);
-                        if (e == hipSuccess) land(prev, static_cast<int>((k - 1) & 1));
-                    }
-                    if (e != hipSuccess) { (void)hipGetLastError(); err.store(static_cast<int>(e)); }
-                };
-                std::vector<std::thread> pool;
-                std::vector<int> inline_lanes{0};
-                for (int t = 1; t < T; ++t) {
-                    try { pool.emplace_back(lane_fn, t); } catch (...) { inline_lanes.push_back(t); }
-                }
-                for (int t : inline_lanes) lane_fn(t);
-                for (std::thread &th : pool) th.join();
-                if (err.load() != 0) {
-                    h->io_rc = BRIE_ERR_HIP;
-                    h->io_err = std::string("staged export: ") + hipGetErrorString(static_cast<hipError_t>(err.load()));
-                }
-            };
-            try {
-                h->io_thread = std::thread(body);
-            } catch (...) {
-                body();
-            }
-            return BRIE_OK;
-        }
     }
     // slabs of ~64 M elements per output: the export kernel of a slab (microseconds to milliseconds) and its copies
     // are enqueued in order on the i/o stream, the copy engine streams while the main stream keeps computing
@@ -2095,6 +1986,7 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
     // the state is final once everything enqueued so far on the main stream has run
     HIP_TRY(hipEventRecord(h->io_event, h->stream));
     HIP_TRY(hipStreamWaitEvent(h->io_stream, h->io_event, 0));
+    HIP_TRY(hipStreamWaitEvent(h->io_stream2, h->io_event, 0));
     h->io_pending = true;
     h->io_rc = BRIE_OK;
     const int device = h->p.device;
@@ -2107,31 +1999,45 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         };
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { bad("hipSetDevice", e); return; }
-        int k = 0;
-        for (int64_t r0 = 0; r0 < Nc; r0 += slab_rows, ++k) {
-            const int64_t rows = std::min(slab_rows, Nc - r0);
-            float *base = h->io_slab + static_cast<size_t>(k & 1) * slab_rows * Ng * 4;
+        // Slab k lives in buffer k & 1 and on stream k & 1.  The export kernel of slab k + 1 is enqueued BEFORE the copies
+        // of slab k start: a copy into pageable memory blocks this thread, and next to the 500-draw loss_gene pass the
+        // short export kernel waits milliseconds for compute units -- with kernel and copies of all slabs on ONE stream the
+        // copy engine idled through every one of those waits (tail behind loss_gene 0.22 s; profiles/r3g_*).  Stream order
+        // still protects the buffers: kernel k + 2 follows the copies of slab k on their common stream.
+        const bool one_stream = getenv("BRIE_IO_ONE_STREAM") != nullptr;             // A/B runs: round 2's order
+        const int64_t n_slabs = (Nc + slab_rows - 1) / slab_rows;
+        auto slab_ptr = [&](int64_t k, int i) {
+            return h->io_slab + static_cast<size_t>(k & 1) * slab_rows * Ng * 4 + static_cast<size_t>(i) * slab_rows * Ng;
+        };
+        auto stream_of = [&](int64_t k) { return (one_stream || (k & 1) == 0) ? h->io_stream : h->io_stream2; };
+        auto launch = [&](int64_t k) {
+            const int64_t r0 = k * slab_rows, rows = std::min(slab_rows, Nc - r0);
             brie::ExportSlabArgs a{};
             a.mu = h->mu; a.rho = h->rho;
-            float *slabs[4];
-            for (int i = 0; i < 4; ++i) slabs[i] = outs[i] ? base + static_cast<size_t>(i) * slab_rows * Ng : nullptr;
-            a.psi = slabs[0]; a.zstd = slabs[1]; a.ci = slabs[2]; a.zloc = slabs[3];
+            a.psi = outs[0] ? slab_ptr(k, 0) : nullptr; a.zstd = outs[1] ? slab_ptr(k, 1) : nullptr;
+            a.ci = outs[2] ? slab_ptr(k, 2) : nullptr; a.zloc = outs[3] ? slab_ptr(k, 3) : nullptr;
             a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
             a.Ng = static_cast<int32_t>(Ng); a.gene_blocks = h->gene_blocks;
             a.r0 = static_cast<int32_t>(r0); a.rows = static_cast<int32_t>(rows);
             hipLaunchKernelGGL(brie::export_slab, dim3(grid_1d(static_cast<int64_t>(h->gene_blocks) * rows * brie::kWave)),
-                               dim3(256), 0, h->io_stream, a);
-            if ((e = hipGetLastError()) != hipSuccess) { bad("export_slab", e); return; }
+                               dim3(256), 0, stream_of(k), a);
+            return hipGetLastError();
+        };
+        if ((e = launch(0)) != hipSuccess) { bad("export_slab", e); return; }
+        for (int64_t k = 0; k < n_slabs; ++k) {
+            if (!one_stream && k + 1 < n_slabs && (e = launch(k + 1)) != hipSuccess) { bad("export_slab", e); return; }
+            const int64_t r0 = k * slab_rows, rows = std::min(slab_rows, Nc - r0);
             for (int i = 0; i < 4; ++i) {
                 if (!outs[i]) continue;
                 if (ld == Ng)
-                    e = hipMemcpyAsync(outs[i] + r0 * ld, slabs[i], static_cast<size_t>(rows) * Ng * sizeof(float),
-                                       hipMemcpyDefault, h->io_stream);
+                    e = hipMemcpyAsync(outs[i] + r0 * ld, slab_ptr(k, i), static_cast<size_t>(rows) * Ng * sizeof(float),
+                                       hipMemcpyDefault, stream_of(k));
                 else
-                    e = hipMemcpy2DAsync(outs[i] + r0 * ld, ld * sizeof(float), slabs[i], Ng * sizeof(float),
-                                         Ng * sizeof(float), rows, hipMemcpyDefault, h->io_stream);
+                    e = hipMemcpy2DAsync(outs[i] + r0 * ld, ld * sizeof(float), slab_ptr(k, i), Ng * sizeof(float),
+                                         Ng * sizeof(float), rows, hipMemcpyDefault, stream_of(k));
                 if (e != hipSuccess) { bad("copy", e); return; }
             }
+            if (one_stream && k + 1 < n_slabs && (e = launch(k + 1)) != hipSuccess) { bad("export_slab", e); return; }
         }
     };
     try {

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
-"""Result export (Psi / Z_std / Psi95CI / Z_loc -> pageable host arrays, 16 GB at configs[2]) A/B in ONE process:
-the staged lanes (export kernel -> device slab -> page-locked slab -> memcpy by the lane's thread; BRIE_EGRESS=staged)
-against the runtime's copies into pageable memory (BRIE_EGRESS=direct), alone and underneath the 500-draw loss_gene pass
--- the last phase of every fit (what BRIE_RV reads, model_wrap.py:28-35).
+"""Result export (Psi / Z_std / Psi95CI / Z_loc -> pageable host arrays, 16 GB at configs[2]) A/B in ONE process, alone
+and underneath the 500-draw loss_gene pass -- the last phase of every fit (what BRIE_RV reads, model_wrap.py:28-35).
 
-    python profiles/egress_ab.py --out gpurun_out/egress_ab.json [--threads 2,4,6]
+    python profiles/egress_ab.py --modes two_streams,one_stream --out gpurun_out/egress_ab.json
+
+two_streams (default of the library): slab k on stream k & 1, export kernel of slab k + 1 enqueued before the copies of
+slab k; one_stream: BRIE_IO_ONE_STREAM=1, round 2's order.  (Call r3g measured a third variant -- staged lanes with
+page-locked slabs and host memcpy threads, the mirror of the ingest -- at 0.27-0.30 s tail against 0.22 s and removed it:
+profiles/r3g_staged_egress_ab_rejected.json.)
 """
 import argparse
 import json
@@ -22,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c3")
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--threads", default="")
+    ap.add_argument("--modes", default="one_stream,two_streams")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "egress_ab.json"))
     args = ap.parse_args()
     import torch
@@ -51,13 +54,12 @@ def main():
         b.fill(0)                                                   # first touch, as BRIE2.fit does during the optimisation
     ref = None
     rows = []
-    plan = [("direct", None), ("staged", None)] * args.reps + [("staged", int(t)) for t in args.threads.split(",") if t]
+    plan = [(m, None) for m in args.modes.split(",")] * args.reps
     for mode, thr in plan:
-        os.environ["BRIE_EGRESS"] = mode
-        if thr:
-            os.environ["BRIE_INGEST_THREADS"] = str(thr)
+        if mode == "one_stream":
+            os.environ["BRIE_IO_ONE_STREAM"] = "1"
         else:
-            os.environ.pop("BRIE_INGEST_THREADS", None)
+            os.environ.pop("BRIE_IO_ONE_STREAM", None)
         t0 = time.perf_counter(); sh.read_results_async(*bufs); sh.read_wait(); t_alone = time.perf_counter() - t0
         t0 = time.perf_counter(); sh.read_results_async(*bufs); sh.loss_gene(500); t_lg = time.perf_counter() - t0
         sh.read_wait(); t_both = time.perf_counter() - t0

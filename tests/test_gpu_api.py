@@ -289,13 +289,13 @@ def test_count_layers_in_any_container_give_the_same_fit(lib):
             np.testing.assert_array_equal(a, b, err_msg=name)
 
 
-@pytest.mark.parametrize("egress", ["direct", "staged"])
+@pytest.mark.parametrize("egress", ["two_streams", "one_stream"])
 @pytest.mark.parametrize("Ng", [300, 1028, 1031])
 def test_async_result_export_equals_the_plain_reads(lib, Ng, egress, monkeypatch):
-    """brie_read_results_async: one pass over the state, slab by slab on a second stream, overlapping loss_gene;
+    """brie_read_results_async: one pass over the state, slab by slab next to the main stream, overlapping loss_gene;
     the four matrices equal brie_read's, a state-changing call waits for the pending export first.
-    egress "staged": pageable destinations through the lanes of the staging pool (export kernel -> device slab ->
-    page-locked slab -> memcpy by the lane's thread), here with 3-row slabs so that every lane walks many, ragged last."""
+    "two_streams" (default): slab k on stream k & 1, its export kernel enqueued before the copies of slab k - 1 start;
+    "one_stream": round 2's order (BRIE_IO_ONE_STREAM, A/B runs)."""
     from brie_amd import _capi
     from tests import util
     Nc, Kc = 70, 1
@@ -305,20 +305,17 @@ def test_async_result_export_equals_the_plain_reads(lib, Ng, egress, monkeypatch
     twin = util.device_shard(P, Nc, Ng, Kc, 3)                         # the same fit without any asynchronous export
     twin.step(7, 0.01, 1)
     monkeypatch.setenv("BRIE_IO_SLAB_ELEMS", str(Ng * 16))            # 16-row slabs: 5 slabs, the last one ragged
-    monkeypatch.setenv("BRIE_EGRESS", egress)
-    monkeypatch.setenv("BRIE_INGEST_SLAB_ELEMS", str(Ng * 4 * 3))     # staged: 3-row slabs of four outputs
-    monkeypatch.setenv("BRIE_INGEST_THREADS", "4")
+    if egress == "one_stream":
+        monkeypatch.setenv("BRIE_IO_ONE_STREAM", "1")
     want = {w: sh.read(w) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
     got = {w: np.full((Nc, Ng), np.nan, np.float32) for w in want}
-    if egress == "direct":
-        _capi.host_register(got[_capi.PSI])                            # one page-locked destination, three pageable
+    _capi.host_register(got[_capi.PSI])                                # one page-locked destination, three pageable
     sh.read_results_async(got[_capi.PSI], got[_capi.Z_STD], got[_capi.PSI95CI], got[_capi.Z_LOC])
     lg = sh.loss_gene(3)                                               # runs NEXT TO the export (it only reads the state)
     np.testing.assert_array_equal(lg, twin.loss_gene(3))
     sh.step(2, 0.01, 1)                                                # must not run before the export has finished
     sh.read_wait()
-    if egress == "direct":
-        _capi.host_unregister(got[_capi.PSI])
+    _capi.host_unregister(got[_capi.PSI])
     for w in want:
         np.testing.assert_array_equal(got[w], want[w])
     assert np.all(np.isfinite(lg)) and not np.array_equal(sh.read(_capi.PSI), want[_capi.PSI])

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--min-iter", type=int, default=1000)
     ap.add_argument("--mc", type=int, default=1)
     ap.add_argument("--no-prefetch", action="store_true")
+    ap.add_argument("--ab-export", type=int, default=0,
+                    help="N: run N fits in this process, alternating the export order (BRIE_IO_ONE_STREAM = round 2's single "
+                         "stream / unset = kernel of slab k + 1 ahead of the copies of slab k on two streams)")
     args = ap.parse_args()
     import torch
     import bench
@@ -40,6 +43,24 @@ def main():
     del gen
     torch.cuda.empty_cache()
 
+    for rep in range(args.ab_export):
+        mode = "one_stream" if rep % 2 == 0 else "two_streams"
+        if mode == "one_stream":
+            os.environ["BRIE_IO_ONE_STREAM"] = "1"
+        else:
+            os.environ.pop("BRIE_IO_ONE_STREAM", None)
+        t0 = time.perf_counter()
+        m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, effLen=eff, seed=5)
+        m.fit(host, Xc=Xc_h, min_iter=args.min_iter, max_iter=args.min_iter, MC_size=args.mc, pseudo_count=0.01, verbose=False)
+        rv = brie_amd.BRIE_RV(m)
+        tm = m.timing
+        print(json.dumps({"export": mode, "total_s": round(time.perf_counter() - t0, 3), "loss_gene_s": round(tm["loss_gene_s"], 3),
+                          "read_wait_s": round(tm["read_wait_s"], 3), "stage_s": [round(x, 3) for x in tm["stage_s"]],
+                          "upload_s": round(tm["of_which_upload_s"], 3)}), flush=True)
+        m.close()
+        del rv
+    if args.ab_export:
+        return
     out = {"config": cfg["desc"], "min_iter": args.min_iter, "MC_size": args.mc, "prefetch_results": not args.no_prefetch}
     t0 = time.perf_counter()
     m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, effLen=eff, seed=5)

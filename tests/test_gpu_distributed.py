@@ -124,3 +124,50 @@ def test_fitBRIE_gene_sharded_world2_real_engine(lib, tmp_path):
     np.testing.assert_array_equal(r[0]["Psi_full"], ref.Psi)
     np.testing.assert_array_equal(np.concatenate([r[0]["Psi_shard"], r[1]["Psi_shard"]], axis=1), ref.Psi)
     assert r[1]["Psi_full"].size == 0
+
+
+# (on the CPU oracle this schedule extends once -- windowed drop 1552 -- and stops -- drop 210 < 300: trace length 40)
+CFIT = dict(min_iter=120, max_iter=240, add_iter=20, epsilon_conv=300.0, n_loss_gene=3, verbose=False, seed=4, LRT_index=[])
+
+
+def _coupled_fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import brie_amd
+    from brie_amd.sharding import GeneComm
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    P = make_problem(FNC, FNG, Kc=1, L=2, seed=23, depth=6.0)
+    Xg = np.random.default_rng(2).standard_normal((FNG, 2)).astype(np.float32)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    # emulate_batches=True is ignored by a coupled model (it cannot be cut into independent batches): it stays ONE
+    # sharded fit with a per-step all-reduce and must take its stopping decisions on the loss summed over the ranks
+    res = brie_amd.fitBRIE(ad, Xc=P["Xc"], Xg=Xg, comm=GeneComm(), emulate_batches=True, **CFIT)
+    np.savez(os.path.join(out_dir, "cfit%d.npz" % rank), losses=res.losses, sigma=res.sigma, gene_coeff=res.gene_coeff,
+             loss_gene=res.loss_gene, cell_coeff=res.cell_coeff)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coupled_sharded_fitBRIE_with_emulate_batches_stops_like_the_single_process_fit(lib, tmp_path):
+    """with emulate_batches=True a coupled sharded fit used to decide its convergence extensions on
+    the rank-LOCAL loss -- the ranks could extend a different number of rounds and their per-step all-reduces no longer
+    paired up (a hang).  Two ranks, Kg = 2, a schedule in which extension rounds do happen: both ranks and the
+    single-process fit take the same number of rounds and agree on the results."""
+    import brie_amd
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    mp.spawn(_coupled_fit_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    P = make_problem(FNC, FNG, Kc=1, L=2, seed=23, depth=6.0)
+    Xg = np.random.default_rng(2).standard_normal((FNG, 2)).astype(np.float32)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1]})
+    ref = brie_amd.fitBRIE(ad, Xc=P["Xc"], Xg=Xg, **CFIT)
+    r = [np.load(tmp_path / ("cfit%d.npz" % k)) for k in range(2)]
+    assert len(r[0]["losses"]) == len(r[1]["losses"]) == len(ref.losses)
+    assert 20 < len(ref.losses) < 140                                   # extended beyond the last stage, stopped before max_iter
+    np.testing.assert_allclose(r[0]["losses"], r[1]["losses"], rtol=1e-6)       # the summed trace both ranks decided on
+    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=1e-4)
+    for key in ("sigma", "gene_coeff", "loss_gene", "cell_coeff"):
+        np.testing.assert_array_equal(r[0][key], r[1][key])                       # gathered / replicated: same on both ranks
+        np.testing.assert_allclose(r[0][key], getattr(ref, key), rtol=2e-3, atol=2e-3, err_msg=key)

@@ -593,8 +593,9 @@ def main(argv=None):
     torch.cuda.empty_cache()
 
     # ---- rank 0's host-side legs; the other ranks wait on sockets (wait_for_rank0 below)
-    if rank == 0:
-        out["roofline"].update(hbm_traffic(args, world, storage_main))
+    # (the device arrays the closed shard left for a successor are released first: the whole-fit figure below allocates
+    #  like a fresh process, and the counter runs further down are other processes on this GPU)
+    _capi.trim_memory()
     if e2e_inputs is not None:
         # Secondary, PCIe-inclusive figure (never `value`): the reference's unit of work through the public API --
         # host count layers in, BRIE2.fit with the default schedule (996 staged steps + 500-draw loss_gene), host
@@ -615,6 +616,9 @@ def main(argv=None):
         mdl.close()
         del e2e_inputs, rv
 
+    _capi.trim_memory()
+    if rank == 0:
+        out["roofline"].update(hbm_traffic(args, world, storage_main))
     if rank == 0 and psi_quad is not None:
         # PSI delta ON THE TIMED WORKLOAD: genes are independent and the noise stream is keyed by the global gene
         # index, so the CPU oracle run on one gene quad over all Nc cells is an exact reference for those genes

@@ -25,7 +25,7 @@ EXPORTS = [
     "brie_step_end", "brie_set_gene_mask", "brie_read_loss_window", "brie_set_target", "brie_loss_gene", "brie_read", "brie_get_draw",
     "brie_set_draw", "brie_synchronize", "brie_profile_enable", "brie_profile_read",
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
-    "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts", "brie_device_memory",
+    "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts", "brie_device_memory", "brie_trim_memory",
     "brie_last_error", "brie_abi_version",
     "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
@@ -289,6 +289,12 @@ def device_memory(device=0):
     free, total = ctypes.c_int64(), ctypes.c_int64()
     _check(lib, lib.brie_device_memory(int(device), ctypes.byref(free), ctypes.byref(total)))
     return free.value, total.value
+
+
+def trim_memory():
+    """Release the device arrays the last closed shard left for its successor (brie_trim_memory)."""
+    lib = load_library()
+    _check(lib, lib.brie_trim_memory())
 
 
 def shard_bytes(Nc, Ng, n_layers, Kc=0):

@@ -186,6 +186,79 @@ int io_wait(brie_handle *h) {
     return BRIE_OK;
 }
 
+// ---- the cell x gene arrays of the last destroyed handle, kept for the next one of the same size ----------------------
+// hipMalloc / hipFree of the 4 - 12 GB arrays of a shard are usually milliseconds and sometimes seconds (1.5 - 5.4 s in 3
+// of ~40 creations of round 3, 3.0 s for the 96 GB of configs[4]: profiles/r3a_ingest_ab_c3.json, r3k_bench_c5_whole_n1.json).
+// Sequential fits of one size -- fitBRIE's super-batches, a fit after a bench, the models of an LRT that cannot share a
+// handle -- give the arrays back and ask for the same sizes a moment later.  ONE generation is kept: the blocks of the
+// last destroyed handle, all of one size on one device; a handle of another size, brie_device_memory and
+// brie_trim_memory release them, and so does an allocation failure before it is reported.  BRIE_DEVICE_CACHE=0: off.
+struct BigBlockCache {
+    std::mutex mu;
+    int device = -1;
+    size_t bytes = 0;
+    std::vector<void *> blocks;
+    static constexpr size_t kMinBytes = size_t(256) << 20;
+    static constexpr size_t kMaxBlocks = 12;
+    static bool enabled() {
+        static const bool on = [] { const char *e = getenv("BRIE_DEVICE_CACHE"); return !(e && e[0] == '0'); }();
+        return on;
+    }
+    void trim_locked() {
+        if (blocks.empty()) return;
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        (void)hipSetDevice(device);
+        for (void *q : blocks) (void)hipFree(q);
+        (void)hipSetDevice(cur);
+        blocks.clear();
+        bytes = 0;
+        device = -1;
+    }
+    void trim() { std::lock_guard<std::mutex> l(mu); trim_locked(); }
+    void *take(int dev, size_t n) {
+        std::lock_guard<std::mutex> l(mu);
+        if (blocks.empty() || dev != device || n != bytes) return nullptr;
+        void *q = blocks.back();
+        blocks.pop_back();
+        return q;
+    }
+    void give(int dev, size_t n, void *q) {
+        if (!q) return;
+        std::lock_guard<std::mutex> l(mu);
+        if (!enabled() || n < kMinBytes) { (void)hipFree(q); return; }
+        if (!blocks.empty() && (dev != device || n != bytes)) trim_locked();     // another size: the old generation goes
+        if (blocks.size() >= kMaxBlocks) { (void)hipFree(q); return; }
+        device = dev; bytes = n;
+        blocks.push_back(q);
+    }
+    // before a handle of (dev, n) allocates: blocks of any other size are of no use to it
+    void prepare(int dev, size_t n) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!blocks.empty() && (dev != device || n != bytes)) trim_locked();
+    }
+};
+BigBlockCache g_blocks;
+
+// a cell x gene array: from the cache when the last handle left one of this size, else hipMalloc (after an allocation
+// failure the cache is released and the allocation tried once more)
+int alloc_mat(float **p, size_t elems, int device, hipStream_t s) {
+    if (elems == 0) { *p = nullptr; return BRIE_OK; }
+    const size_t bytes = elems * sizeof(float);
+    void *q = g_blocks.take(device, bytes);
+    if (!q) {
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            g_blocks.trim();
+            HIP_TRY(hipMalloc(&q, bytes));
+        }
+    }
+    *p = static_cast<float *>(q);
+    HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
+    return BRIE_OK;
+}
+
 int alloc_f32(float **p, size_t elems, hipStream_t s) {
     if (elems == 0) { *p = nullptr; return BRIE_OK; }
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), elems * sizeof(float)));
@@ -414,7 +487,10 @@ int try_compact_counts(brie_handle *h) {
             hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->c[l])); h->c[l] = nullptr; }
+    {   // the fp32 layers have done their job: to the block cache (the next handle of this size starts with them)
+        const size_t mat_bytes = static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float);
+        for (int l = 0; l < h->p.n_layers; ++l) { g_blocks.give(h->p.device, mat_bytes, h->c[l]); h->c[l] = nullptr; }
+    }
     h->cs = cs;
     return BRIE_OK;
 }
@@ -457,7 +533,10 @@ int expand_counts(brie_handle *h) {
     if (h->cs == brie::kCountF32) return BRIE_OK;
     const int64_t n = h->p.Nc * h->ld;
     for (int l = 0; l < h->p.n_layers; ++l) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->c[l]), static_cast<size_t>(n) * sizeof(float)));
+        {
+            int rc_a = alloc_mat(&h->c[l], static_cast<size_t>(n), h->p.device, h->stream);
+            if (rc_a != BRIE_OK) return rc_a;
+        }
         launch_expand(h, l, h->c[l], h->pc, l < 2 ? 1 : 0);
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -948,8 +1027,12 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     const size_t vec = static_cast<size_t>(h->ld);
 #define A(ptr, n)                                            \
     if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) { brie_destroy(h); return rc; }
-    for (int l = 0; l < p->n_layers; ++l) A(h->c[l], mat);
-    A(h->mu, mat); A(h->rho, mat); A(h->m_mu, mat); A(h->v_mu, mat); A(h->m_rho, mat); A(h->v_rho, mat);
+#define AM(ptr)                                              \
+    if ((rc = alloc_mat(&(ptr), mat, p->device, h->stream)) != BRIE_OK) { brie_destroy(h); return rc; }
+    g_blocks.prepare(p->device, mat * sizeof(float));
+    for (int l = 0; l < p->n_layers; ++l) AM(h->c[l]);
+    AM(h->mu); AM(h->rho); AM(h->m_mu); AM(h->v_mu); AM(h->m_rho); AM(h->v_rho);
+#undef AM
     A(h->Xc, static_cast<size_t>(p->Nc) * p->Kc);
     A(h->W, vec * p->Kc); A(h->m_W, vec * p->Kc); A(h->v_W, vec * p->Kc);
     A(h->b, vec); A(h->m_b, vec); A(h->v_b, vec);
@@ -1048,7 +1131,12 @@ int brie_destroy(brie_handle *h) {
     if (h->io_stream2) hipStreamSynchronize(h->io_stream2);
     h->io_pending = false;
     if (h->stream) hipStreamSynchronize(h->stream);
-    float *ptrs[] = {h->c[0], h->c[1], h->c[2], h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->Xc,
+    {   // the cell x gene arrays go to the one-generation cache (next handle of this size), everything else is freed
+        const size_t mat_bytes = static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float);
+        float *mats[] = {h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho, h->c[0], h->c[1], h->c[2]};
+        for (float *q : mats) g_blocks.give(h->p.device, mat_bytes, q);
+    }
+    float *ptrs[] = {h->Xc,
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
                      h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gpart, h->gene_active,
@@ -2269,8 +2357,14 @@ int64_t sim_slab_elems() {
 }
 }  // namespace
 
+int brie_trim_memory(void) {
+    g_blocks.trim();
+    return BRIE_OK;
+}
+
 int brie_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes) {
     if (!free_bytes || !total_bytes) return fail(BRIE_ERR_INVALID, "null argument");
+    g_blocks.trim();                       // what the last handle left behind counts as free
     HIP_TRY(hipSetDevice(device));
     size_t f = 0, t = 0;
     HIP_TRY(hipMemGetInfo(&f, &t));

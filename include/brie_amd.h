@@ -304,6 +304,13 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  * 288 GB instead of for 500k elements. */
 int brie_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes);
 
+/* brie_destroy keeps the cell x gene arrays of the handle (>= 256 MB each) for the next handle of the SAME size on the
+ * same device -- sequential fits of one size (the super-batches above, one fit after another in a service) otherwise
+ * pay hipFree + hipMalloc of tens of GB again, which is milliseconds on a good day and seconds on a bad one.  One
+ * generation only: a handle of another size, brie_device_memory, an allocation failure inside the library and this
+ * call release them.  BRIE_DEVICE_CACHE=0 switches the cache off. */
+int brie_trim_memory(void);
+
 /* Count simulator -- brie/models/simulator.py:7-75.  Stateless; every array is C-order (Nc, Ng) fp32 in host or
  * device memory (copied through HBM in row slabs), genes are addressed globally (gene_offset) so a gene shard
  * simulates exactly its columns of the whole matrix.  All draws come from the library's Philox stream keyed by

@@ -345,6 +345,36 @@ def test_async_result_export_equals_the_plain_reads(lib, Ng, egress, monkeypatch
     sh.close()
 
 
+def test_successor_shard_reuses_the_device_arrays_and_starts_clean(lib):
+    """brie_destroy keeps the cell x gene arrays (>= 256 MB each) for the next handle of the same size
+    (include/brie_amd.h, brie_trim_memory): the successor must start from zeroed arrays -- same results as the first --,
+    a handle of another size or brie_device_memory must give the memory back."""
+    from brie_amd import _capi
+    from tests import util
+    Nc, Ng, Kc = 70000, 1000, 1                       # 70000 x 1024 x 4 B = 287 MB per array: above the cache's minimum
+    P = util.problem(Nc, Ng, Kc, 2, seed=77)
+    _capi.trim_memory()
+    free0 = _capi.device_memory()[0]
+
+    def run():
+        sh = util.device_shard(P, Nc, Ng, Kc, 9)
+        tr = sh.step(4, 0.01, 1)
+        out = (tr, sh.read(_capi.Z_LOC), sh.loss_gene(2))
+        sh.close()
+        return out
+    a = run()
+    b = run()                                         # on the arrays the first one left behind
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    assert abs(_capi.device_memory()[0] - free0) < (64 << 20)      # the query releases what was kept
+    small = util.device_shard(util.problem(64, 72, 1, 2), 64, 72, 1, 3)           # another size: nothing of the old generation survives
+    small.step(1, 0.01, 1)
+    small.close()
+    c = run()
+    np.testing.assert_array_equal(a[1], c[1])
+    _capi.trim_memory()
+
+
 def test_BRIE2_fit_streams_results_out(lib):
     import brie_amd
     from brie_amd import _capi

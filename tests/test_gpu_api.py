@@ -352,8 +352,8 @@ def test_successor_shard_reuses_the_device_arrays_and_starts_clean(lib):
     from brie_amd import _capi
     from tests import util
     Nc, Ng, Kc = 70000, 1000, 1                       # 70000 x 1024 x 4 B = 287 MB per array: above the cache's minimum
-    rng = np.random.default_rng(77)                   # (plain Poisson counts: the generative recipe takes 30 s at this size)
-    P = {"counts": [rng.poisson(1.0, (Nc, Ng)).astype(np.float32) for _ in range(2)], "effLen": None,
+    rng = np.random.default_rng(77)                   # (plain small integers: the generative recipe takes 30 s at this size)
+    P = {"counts": [rng.integers(0, 4, (Nc, Ng), dtype=np.uint8).astype(np.float32) for _ in range(2)], "effLen": None,
          "Xc": rng.standard_normal((Nc, Kc)).astype(np.float32)}
     _capi.trim_memory()
     free0 = _capi.device_memory()[0]

@@ -1,5 +1,5 @@
 """Soak run of the two seeded random test families of tests/test_gpu_parity.py with OTHER seeds than the committed
-lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed]
+lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed] [n_wide_sequences]
 Prints every failing case with the assertion message; exit code = number of failures."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -24,13 +24,28 @@ for case in T._random_cases(n_shapes, seed=seed):
         fails += 1
         print("SHAPE CASE FAILED", case, "->", " | ".join(l for l in str(e).splitlines() if l.strip())[:600] or traceback.format_exc()[-600:], flush=True)
 print("shape cases done:", n_shapes, "failures so far:", fails, flush=True)
-for case in T._op_sequences(n_seq, seed=seed + 1):
+def wide_sequences(n, seed):
+    """Sequences over ARBITRARY shapes (the committed family draws from short lists): any Nc in 1..400, any Ng in 1..1300
+    -- every residue mod 4 and mod 256 --, Kc 0..12."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        ops = [str(rng.choice(["step", "step", "mask", "unmask", "reset", "loss_gene", "tiling", "window", "read"]))
+               for _ in range(8)]
+        out.append((1000 + i, int(rng.integers(1, 401)), int(rng.integers(1, 1301)), int(rng.integers(0, 13)),
+                    int(rng.choice([2, 3])), bool(rng.random() < 0.5), bool(rng.random() < 0.5), tuple(ops)))
+    return out
+
+
+n_wide = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+sequences = list(T._op_sequences(n_seq, seed=seed + 1)) + wide_sequences(n_wide, seed + 2)
+for case in sequences:
     try:
         seq_fn(None, *case)
     except Exception as e:      # noqa
         fails += 1
         print("SEQUENCE FAILED", case, "->", " | ".join(l for l in str(e).splitlines() if l.strip())[:600] or traceback.format_exc()[-600:], flush=True)
-print("sequences done:", n_seq, "total failures:", fails, flush=True)
+print("sequences done:", n_seq, "+ wide", n_wide, "total failures:", fails, flush=True)
 if RECORD:
     rec = T._RECORD
     big = [r for r in rec if r[1] >= 1000]

@@ -2,7 +2,7 @@
 
 Tolerances (floating point path; north star: PSI within 1e-4 of the CPU path):
   * noise stream eps: 2e-6 absolute (fp32 Box-Muller vs fp64-rounded oracle)
-  * a few Adam steps: assert_states_close -- 99.9 % of every state array within 5e-6,
+  * a few Adam steps: assert_states_close -- 99.9 % of every state array within 1e-5,
     every element within 1e-3 except at most one sign-flipped element per array
     (Adam's first update of a fresh optimiser is +-lr whatever |g| is, so an
     element with g ~ 0 moves on the sign of a rounding error), itself bounded by
@@ -24,13 +24,14 @@ pytestmark = pytest.mark.gpu
 _RECORD = None            # tests/tools/soak_randomised.py sets a list: (array, n, p99.9, max, n beyond `worst`) per call
 
 
-def assert_states_close(so, sd, bulk=5e-6, worst=1e-3, lr=0.01, fresh=1):
+def assert_states_close(so, sd, bulk=1e-5, worst=1e-3, lr=0.01, fresh=1):
     """State arrays of the oracle and of the device after a few Adam steps (the short-horizon parity rule), sized by
     what 1 000 soak cases of the two random families need (profiles/r3c_soak_record.json: 6 545 comparisons; the
     99.9 % quantile of an array of >= 1000 elements never above 1.9e-6; 6 comparisons with ONE element beyond 1e-3,
-    the largest 2.3e-3).
+    the largest 2.3e-3) and 2 400 more in assert mode (profiles/r3f_soak_assert_mode.log, r3n_soak_wide.log: the
+    largest 99.9 % quantile 7.6e-6, the Wc_loc of a ONE-cell problem).
 
-      bulk    99.9 % of every array of >= 1000 elements within `bulk` (5e-6; smaller arrays fall under `worst` alone);
+      bulk    99.9 % of every array of >= 1000 elements within `bulk` (1e-5; smaller arrays fall under `worst` alone);
       worst   every element within `worst` (1e-3) -- EXCEPT sign flips: Keras Adam's first update of a fresh optimiser
               is lr * g / (|g| + 1e-7), i.e. +-lr whatever |g| is, so an element whose gradient is ~0 (zero coverage,
               mu on its prior mean: |g| ~ 1e-8) moves by +lr or -lr on the SIGN of a rounding error.  Such an element

@@ -1,5 +1,5 @@
 """Soak run of the two seeded random test families of tests/test_gpu_parity.py with OTHER seeds than the committed
-lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed] [n_wide_sequences]
+lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed] [n_wide_sequences] [n_wide_shapes]
 Prints every failing case with the assertion message; exit code = number of failures."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -17,13 +17,28 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 424242
 shape_fn = T.test_randomised_shapes_and_switches
 seq_fn = T.test_randomised_operation_sequences
 fails = 0
-for case in T._random_cases(n_shapes, seed=seed):
+def wide_shapes(n, seed):
+    """The shape / switch family over ARBITRARY shapes: any Nc in 1..520, any Ng in 1..1100, any Kc / Kg of the kind."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin", "wide_cell", "wide_xg"][i % 9]
+        L = int(rng.choice([2, 3]))
+        Kc = int(rng.integers(9, 65)) if kind.startswith("wide") else int(rng.integers(0, 9))
+        Kg = int(rng.integers(1, 65)) if kind.endswith("xg") else 0
+        out.append((5000 + i, kind, int(rng.integers(1, 521)), int(rng.integers(1, 1101)), Kc, Kg, L,
+                    int(rng.choice([1, 2, 3, 5])), bool(L == 3 or rng.random() < 0.3)))
+    return out
+
+
+n_wide_shapes = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+for case in list(T._random_cases(n_shapes, seed=seed)) + wide_shapes(n_wide_shapes, seed + 3):
     try:
         shape_fn(None, *case)
     except Exception as e:      # noqa
         fails += 1
         print("SHAPE CASE FAILED", case, "->", " | ".join(l for l in str(e).splitlines() if l.strip())[:600] or traceback.format_exc()[-600:], flush=True)
-print("shape cases done:", n_shapes, "failures so far:", fails, flush=True)
+print("shape cases done:", n_shapes, "+ wide", n_wide_shapes, "failures so far:", fails, flush=True)
 def wide_sequences(n, seed):
     """Sequences over ARBITRARY shapes (the committed family draws from short lists): any Nc in 1..400, any Ng in 1..1300
     -- every residue mod 4 and mod 256 --, Kc 0..12."""

@@ -691,7 +691,11 @@ def main(argv=None):
     if rank == 0:
         print(json.dumps(out), flush=True)
     if not came_back:
-        os._exit(0 if rank == 0 else 3)
+        # the stuck leg is reported in the line (allgather.native_error); every rank leaves with code 0 so that the
+        # launcher does not tear rank 0 down before its line is out -- the other ranks give it a moment first
+        if rank != 0:
+            time.sleep(5.0)
+        os._exit(0)
     if dist is not None:
         dist.barrier(group=side)
         dist.destroy_process_group()

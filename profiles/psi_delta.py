@@ -57,7 +57,18 @@ CASES = {
                        desc="configs[2]: 128 genes over all cells, brie-quant schedule: 4998 steps, MC_size 3"),
     "c2_cli_128": dict(Nc=10000, Ng=128, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3,
                        desc="configs[1]: 128 genes over all cells, brie-quant schedule: 4998 steps, MC_size 3"),
+    # round 3, AFTER the rule was frozen on the seven cases above: other data, other initial state, other noise stream
+    # (out-of-sample check of tests/util.py::psi_parity_rule -- nothing was tuned on these)
+    "c3_api_512_s2": dict(Nc=50000, Ng=512, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1, data_seed=8675309, seed=23,
+                          desc="configs[2] shape, OTHER data seed / model seed: 512 genes over all cells, 996 steps, MC_size 1"),
+    "c2_api_512_s2": dict(Nc=10000, Ng=512, Kc=1, L=3, theta=1.5, min_iter=1000, MC=1, data_seed=8675309, seed=23,
+                          desc="configs[1] shape, OTHER data seed / model seed: 512 genes over all cells, 996 steps, MC_size 1"),
+    "c2_cli_128_s2": dict(Nc=10000, Ng=128, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3, data_seed=8675309, seed=23,
+                          desc="configs[1] shape, OTHER seeds: 128 genes over all cells, 4998 steps, MC_size 3"),
+    "c3_cli_128_s2": dict(Nc=50000, Ng=128, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=8675309, seed=23,
+                          desc="configs[2] shape, OTHER seeds: 128 genes over all cells, 4998 steps, MC_size 3"),
 }
+HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2")
 R03 = ("c1_api", "c1_kc0_api", "c1_cli", "c2_api_512", "c3_api_512", "c2_cli_128", "c3_cli_128")
 PARAMS = ("Wc_loc", "intercept", "sigma_log")
 QUICK = ("c1_api", "c1_kc0_api", "c2_api", "c3_api")
@@ -68,7 +79,12 @@ VARIANTS = {"hip": [], "hip_adam": ["BRIE_STRICT_ADAM=1"], "hip_strict": ["BRIE_
 def problem(case):
     from tests import util
     c = CASES[case]
-    return util.problem(c["Nc"], c["Ng"], c["Kc"], c["L"], theta=c["theta"]), c
+    kw = {"seed": c["data_seed"]} if "data_seed" in c else {}
+    return util.problem(c["Nc"], c["Ng"], c["Kc"], c["L"], theta=c["theta"], **kw), c
+
+
+def model_seed(case):
+    return CASES[case].get("seed", SEED)
 
 
 def schedule(min_iter):
@@ -87,7 +103,7 @@ def run_oracle(case, dtype, want_params=False):
     from oracle.c_oracle import COracle
     P, c = problem(case)
     t0 = time.time()
-    o = COracle(P["counts_pc"], P["Xc"], effLen=P["effLen"], seed=SEED, dtype=dtype)
+    o = COracle(P["counts_pc"], P["Xc"], effLen=P["effLen"], seed=model_seed(case), dtype=dtype)
     for n, lr in schedule(c["min_iter"]):
         o.reset_optimizer()
         o.minimize(n, lr, c["MC"])
@@ -105,7 +121,7 @@ def run_hip_worker(case, out):
     from brie_amd import _capi
     from tests import util
     P, c = problem(case)
-    sh = util.device_shard(P, c["Nc"], c["Ng"], c["Kc"], SEED)
+    sh = util.device_shard(P, c["Nc"], c["Ng"], c["Kc"], model_seed(case))
     t0 = time.time()
     for n, lr in schedule(c["min_iter"]):
         sh.reset_optimizer()
@@ -231,7 +247,7 @@ def main():
             os.remove(tmp)
         pairs = [(v, "o64") for v in psi if v.startswith("hip")] + [(v, "o32") for v in psi if v.startswith("hip")] + \
                 [("o32", "o64")] + [("hip", v) for v in psi if v.startswith("hip_")]
-        entry = {"desc": c["desc"], "shape": [c["Nc"], c["Ng"]], "Kc": c["Kc"], "count_layers": c["L"],
+        entry = {"desc": c["desc"], "model_seed": model_seed(case), "data_seed": c.get("data_seed", 20240617), "shape": [c["Nc"], c["Ng"]], "Kc": c["Kc"], "count_layers": c["L"],
                  "steps": 6 * int(c["min_iter"] / 6), "MC_size": c["MC"],
                  "zero_coverage_fraction": float(1 - covered.mean()), "hip_seconds": secs, "pairs": {}}
         for a, b in pairs:

@@ -15,6 +15,40 @@ from tests.util import psi_parity_of
 pytestmark = pytest.mark.gpu
 
 STEPS = 12
+PER_GENE = 5e-6          # Wc_loc / intercept / sigma_log of a quad after 12 steps (sums over all cells); needed: 1.43e-6
+
+
+def _quad_states_close(tag, dev, ref, psi=None):
+    """Short-horizon parity of one gene quad over ALL cells against the fp32 oracle (6 - 12 Adam steps of ONE fresh
+    optimiser), sized by what the 18 quads of this file need (profiles/r3q_fullsize_needs.log: per-gene vectors within
+    1.43e-6; 99.9 % quantile of Z_loc / Z_std_log 1.67e-6; at most 3 of 400 000 elements beyond 1e-4, the largest 2.4e-4;
+    Psi 99.9 % 2.98e-7, one element at 2.5e-5):
+      * the per-gene vectors Wc_loc / intercept / sigma_log (a handful of numbers): every one within PER_GENE = 5e-6;
+      * Z_loc / Z_std_log over all cells: the rule of tests/test_gpu_parity.py::assert_states_close with the bulk bound
+        at 5e-6 (99.9 %), at most max(2, 2e-5 n) elements beyond 1e-4, none beyond 1e-3 but sign flips of a ~0 gradient;
+      * Psi: a quarter of the Z_loc bounds (|dPsi| <= |dZ_loc| / 4), the bulk at 1e-6.
+    Prints what the case needed (pytest -s)."""
+    from tests.test_gpu_parity import assert_states_close
+    so = {k: np.asarray(ref[k]) for k in ref}
+    sd = {k: np.asarray(dev[k]) for k in dev}
+    for k in ("Wc_loc", "intercept", "sigma_log"):
+        d = np.abs(sd[k].astype(np.float64) - so[k])
+        print("%s %s: max %.3g" % (tag, k, d.max() if d.size else 0.0))
+        assert d.size == 0 or d.max() < PER_GENE, (tag, k, float(d.max()))
+    for k in ("Z_loc", "Z_std_log"):
+        d = np.abs(sd[k].astype(np.float64) - so[k])
+        print("%s %s: p99.9 %.3g max %.3g n>=1e-4 %d n>=1e-3 %d of %d" % (tag, k, np.percentile(d, 99.9), d.max(),
+                                                                   (d >= 1e-4).sum(), (d >= 1e-3).sum(), d.size))
+        assert (d >= 1e-4).sum() <= max(2, int(2e-5 * d.size)), (tag, k, int((d >= 1e-4).sum()))
+    so.setdefault("Wg_loc", np.zeros((0,)))
+    sd.setdefault("Wg_loc", np.zeros((0,)))
+    assert_states_close(so, sd, bulk=5e-6, lr=0.01, fresh=1)
+    if psi is not None:
+        d = np.abs(psi[0].astype(np.float64) - psi[1])
+        print("%s Psi: p99.9 %.3g max %.3g n>=2.5e-5 %d" % (tag, np.percentile(d, 99.9), d.max(), (d >= 2.5e-5).sum()))
+        assert np.percentile(d, 99.9) < 1e-6, (tag, float(np.percentile(d, 99.9)))
+        assert (d >= 2.5e-5).sum() <= max(2, int(2e-5 * d.size)), (tag, int((d >= 2.5e-5).sum()))
+        assert (d >= 2.5e-4).sum() <= max(1, int(1e-4 * d.size)) and d.max() < 0.25 * 2.2 * 0.01, (tag, float(d.max()))
 
 
 def _generate(torch, dev, cfg, seed, with_eff=False):
@@ -82,13 +116,11 @@ def test_full_size_config2(lib):
             o = OracleBRIE2(Nc, 4, Kc, effLen=eff_h[cols], seed=seed, gene_offset=g0, dtype=np.float32)
             tr = o.minimize(cnt, Xc_h, steps, 0.01, mc)
             lsum += float(tr[0])
-            for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
-                                       ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
-                                       ("sigma_log", lam[:, cols], o.sigma_log)):
-                d = np.abs(dev_arr - ref)
-                assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (mc, g0, name, float(d.max()))
-            d = np.abs(psi[:, cols] - o.Psi)
-            assert d.max() < 5e-4 and np.percentile(d, 99) < 1e-5, (mc, g0, float(d.max()))
+            _quad_states_close("C2 mc%d g%d" % (mc, g0),
+                               {"Z_loc": zloc[:, cols], "Z_std_log": zsl[:, cols], "Wc_loc": W[:, cols],
+                                "intercept": b[:, cols], "sigma_log": lam[:, cols]},
+                               {"Z_loc": o.Z_loc, "Z_std_log": o.Z_std_log, "Wc_loc": o.Wc_loc, "intercept": o.intercept,
+                                "sigma_log": o.sigma_log}, psi=(psi[:, cols], o.Psi))
         if mc == 1:
             # gene-shard invariance (what a rank of an 8-way split holds: 628 genes starting at a quad boundary)
             s0, s1 = 1256, 1884
@@ -153,13 +185,11 @@ def test_full_size_config3(lib):
         cnt = add_pseudo_count([layers[l][:, cols].cpu().numpy() for l in range(2)])
         o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
         tr = o.minimize(cnt, Xc_h, STEPS, 0.01, 1)
-        for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
-                                   ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
-                                   ("sigma_log", lam[:, cols], o.sigma_log)):
-            d = np.abs(dev_arr - ref)
-            assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (g0, name, float(d.max()))
-        d = np.abs(psi[:, cols] - o.Psi)
-        assert d.max() < 5e-4 and np.percentile(d, 99) < 1e-5, (g0, float(d.max()))
+        _quad_states_close("C3 g%d" % g0,
+                           {"Z_loc": zloc[:, cols], "Z_std_log": zsl[:, cols], "Wc_loc": W[:, cols],
+                            "intercept": b[:, cols], "sigma_log": lam[:, cols]},
+                           {"Z_loc": o.Z_loc, "Z_std_log": o.Z_std_log, "Wc_loc": o.Wc_loc, "intercept": o.intercept,
+                            "sigma_log": o.sigma_log}, psi=(psi[:, cols], o.Psi))
 
     # --- gene-shard invariance at the 8-GPU shard size (BASELINE configs[3]: 2500 genes per GPU)
     s0, s1 = 7500, 10000
@@ -207,11 +237,11 @@ def test_full_size_config3_wide_design_on_the_tile_kernel(lib):
         cnt = add_pseudo_count([layers[l][:, cols].cpu().numpy() for l in range(2)])
         o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
         tr = o.minimize(cnt, Xc_h, STEPS, 0.01, 1)
-        for name, dev_arr, ref in (("Z_loc", zloc[:, cols], o.Z_loc), ("Z_std_log", zsl[:, cols], o.Z_std_log),
-                                   ("Wc_loc", W[:, cols], o.Wc_loc), ("intercept", b[:, cols], o.intercept),
-                                   ("sigma_log", lam[:, cols], o.sigma_log)):
-            d = np.abs(dev_arr - ref)
-            assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3, (g0, name, float(d.max()))
+        _quad_states_close("C3 Kc48 g%d" % g0,
+                           {"Z_loc": zloc[:, cols], "Z_std_log": zsl[:, cols], "Wc_loc": W[:, cols],
+                            "intercept": b[:, cols], "sigma_log": lam[:, cols]},
+                           {"Z_loc": o.Z_loc, "Z_std_log": o.Z_std_log, "Wc_loc": o.Wc_loc, "intercept": o.intercept,
+                            "sigma_log": o.sigma_log})
     s0, s1 = 7500, 10000
     part = _capi.Shard(Nc, s1 - s0, Kc, n_layers=2, seed=seed, gene_offset=s0)
     for l in range(2):
@@ -256,10 +286,15 @@ def test_max_size_config5_single_gpu(lib):
     o = OracleBRIE2(Nc, 4, Kc, seed=seed, gene_offset=g0, dtype=np.float32)
     o.minimize(cnt, Xc.cpu().numpy(), steps, 0.01, 1)
     zloc = sh.read(_capi.Z_LOC)
-    d = np.abs(zloc[:, g0:] - o.Z_loc)
-    assert np.percentile(d, 99.9) < 5e-5 and d.max() < 2e-3
-    np.testing.assert_allclose(sh.read(_capi.WC_LOC)[:, g0:], o.Wc_loc, atol=2e-4)
     assert np.abs(zloc).max() <= 9.0 and np.all(np.isfinite(zloc))
+    z_quad = zloc[:, g0:].copy()
+    del zloc                                            # 12 GB on the host: one (Nc, Ng) array at a time
+    zsl_quad = sh.read(_capi.Z_STD_LOG)[:, g0:].copy()
+    _quad_states_close("C5 g%d" % g0,
+                       {"Z_loc": z_quad, "Z_std_log": zsl_quad, "Wc_loc": sh.read(_capi.WC_LOC)[:, g0:],
+                        "intercept": sh.read(_capi.INTERCEPT)[:, g0:], "sigma_log": sh.read(_capi.SIGMA_LOG)[:, g0:]},
+                       {"Z_loc": o.Z_loc, "Z_std_log": o.Z_std_log, "Wc_loc": o.Wc_loc, "intercept": o.intercept,
+                        "sigma_log": o.sigma_log})
     sh.close()
 
 

@@ -50,3 +50,52 @@ def test_world_size_mismatch_is_refused():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_native_communicator_leg_is_bounded_and_reported():
+    """The C-ABI communicator's gather has never run between two GPUs on the build's boxes: bench.py runs it LAST under a
+    watchdog.  A leg that hangs is reported (native_error) and the caller is told not to touch the process group again;
+    a leg that raises is reported too; a leg that works records its time and the comparison with the torch gather."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Native(object):
+        def allgather(self, buf):
+            return np.stack([buf, buf + 1.0])
+
+    class Comm(object):
+        backend = "nccl"
+
+        def __init__(self, mode):
+            self.mode, self.gate = mode, threading.Event()
+
+        def native_comm(self, local_rank):
+            if self.mode == "hang":
+                self.gate.wait()                       # never set: RCCL set-up that does not come back
+            if self.mode == "raise":
+                raise RuntimeError("ncclCommInitRank failed")
+            return None if self.mode == "absent" else Native()
+
+    local = np.arange(6, dtype=np.float32).reshape(2, 3)
+    ranges = [(0, 3), (3, 6)]
+    full = np.concatenate([local, local + 1.0], axis=1)
+    for mode in ("ok", "absent", "raise", "hang"):
+        info = {}
+        back = bench.native_allgather_leg(info, (Comm(mode), local, ranges, full), 0, 2, timeout_s=0.5)
+        if mode == "ok":
+            assert back and info["native_equals_torch"] is True and info["allgather_native_ms"] >= 0
+        elif mode == "absent":
+            assert back and "no native communicator" in info["native"]
+        elif mode == "raise":
+            assert back and "ncclCommInitRank failed" in info["native_error"]
+        else:
+            assert not back and "did not return" in info["native_error"]
+    os.environ["BRIE_BENCH_NATIVE_COMM"] = "0"
+    try:
+        info = {}
+        assert bench.native_allgather_leg(info, (Comm("hang"), local, ranges, full), 0, 2, timeout_s=0.5)
+        assert "skipped" in info["native"]
+    finally:
+        del os.environ["BRIE_BENCH_NATIVE_COMM"]

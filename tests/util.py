@@ -93,9 +93,11 @@ def gene_shift(pa, pb):
 
 
 def psi_parity_rule(psi, par, what=""):
-    """THE parity rule of the floating-point path (north star: PSI within 1e-4 of the CPU path),
-    frozen in round 3 on 512-gene x all-cell samples of configs[1] / configs[2] and the 200-cell configs[0], both default
-    schedules (profiles/psi_delta_r03.json).
+    """THE parity rule of the floating-point path (north star: PSI within 1e-4 of the CPU path).
+    Revision 2 (round 3).  Revision 1 was frozen on seven cases (profiles/psi_delta_r03.json) and then put to six
+    held-out cases with other seeds and another shape: it held on five and failed on one
+    (profiles/r3r_psi_delta_heldout.json, mid_cli_96_s3) -- which showed what it had lumped together, see "clustered".
+    Revision 2 was in turn checked on a second held-out set generated after it (profiles/psi_delta.py::HELD_OUT_2).
 
     psi[k], par[k] for k in 'hip' (the HIP path), 'o32' (the CPU restatement in fp32 = the reference's precision),
     'o64' (the same in fp64 = the precision-independent answer); same init, same noise stream.
@@ -106,38 +108,58 @@ def psi_parity_rule(psi, par, what=""):
     says where: when the sign event hits one of a gene's OWN parameters (a Wc_loc entry, its intercept, its sigma) all
     Nc cells of that gene move together -- at configs[2] ONE such gene of 512 carries 34 884 of the HIP path's 35 210
     entries beyond 1e-4, and the fp32 oracle has two other such genes -- and everywhere else the two fp32 runs have the
-    same handful of entries beyond 1e-4 (326 vs 327 of 25.4 M).  So the rule counts displaced GENES and, outside them,
-    ENTRIES, each against what the reference's own precision does on the same trajectory:
+    same handful of scattered entries beyond 1e-4.  Such gene-level events hit either fp32 run with the same frequency
+    (13 cases: 8 clusters in the HIP runs, 11 in the fp32 oracle's), but each carries hundreds of entries, so they are
+    counted as GENES, and only what is left is counted as ENTRIES -- each against what the reference's own precision does
+    on the same trajectory:
 
-      displaced gene: own-parameter shift vs the fp64 run > GENE_SHIFT = 4e-4 (moves Psi by 1e-4 where sigmoid' = 1/4).
-      1. genes:    #displaced(hip) <= 1.5 #displaced(o32) + max(3, 1 % of the genes);
-      2. entries of genes displaced in NEITHER run:  #(d > 1e-4) <= 1.5 #(d32 > 1e-4) + max(1e-5 n, 50);
+      displaced gene: own-parameter shift vs the fp64 run > GENE_SHIFT = 4e-4 (moves Psi by 1e-4 where sigmoid' = 1/4);
+      clustered gene: not displaced at the end of the fit, yet more than max(5, 0.1 % of its cells) beyond 1e-4: its cells
+                      moved TOGETHER -- a displacement that healed (Adam's second moment remembers it for ~1000 steps
+                      and the noisy trajectory does not re-converge entry by entry), or several own parameters just
+                      under the threshold adding up through the covariates (mid_cli_96_s3: shift 3.7e-4, Kc = 2);
+      moved gene = displaced or clustered;  quiet gene = moved in NEITHER run.
+      1. genes:    #moved(hip) <= 1.5 #moved(o32) + max(3, 1 % of the genes);
+      2. entries of quiet genes:  #(d > 1e-4) <= 1.5 #(d32 > 1e-4) + max(1e-5 n, 50);
       3. their bulk:   p99(d) <= max(1e-4, 1.5 p99(d32));
-      4. their worst:  max d <= max(2e-3, 3 max d32)   (a fifth of what one flipped +-lr step of a CELL's own Z_loc can do);
+      4. the worst entry of every gene not displaced in either run (clustered ones included):
+                       max d <= max(2e-3, 3 max d32)   (a fifth of what one flipped +-lr step of a CELL's own Z_loc can do);
       5. a displaced gene is displaced by a bounded amount: shift <= 0.15 (the sum of the six stage learning rates is 0.051;
          observed <= 0.092 on 200-cell data, <= 0.016 at 10k+ cells)."""
     P = {k: np.asarray(psi[k], np.float64) for k in ("hip", "o32", "o64")}
     d, d32 = np.abs(P["hip"] - P["o64"]), np.abs(P["o32"] - P["o64"])
     s_h, s_o = gene_shift(par["hip"], par["o64"]), gene_shift(par["o32"], par["o64"])
     disp_h, disp_o = s_h > GENE_SHIFT, s_o > GENE_SHIFT
-    Ng = d.shape[1]
-    keep = ~(disp_h | disp_o)
+    Nc, Ng = d.shape
+    cluster = max(5, int(1e-3 * Nc))
+    clus_h = ~disp_h & ((d > PSI_TOL).sum(0) > cluster)
+    clus_o = ~disp_o & ((d32 > PSI_TOL).sum(0) > cluster)
+    moved_h, moved_o = disp_h | clus_h, disp_o | clus_o
+    undisp = ~(disp_h | disp_o)
+    quiet = ~(moved_h | moved_o)
     rep = {"genes": Ng, "displaced_genes": {"hip": int(disp_h.sum()), "fp32_oracle": int(disp_o.sum())},
+           "clustered_genes": {"hip": int(clus_h.sum()), "fp32_oracle": int(clus_o.sum()), "more_cells_beyond_1e-4_than": cluster},
            "largest_gene_shift": {"hip": float(s_h.max()), "fp32_oracle": float(s_o.max())},
            "all_entries": {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "frac_gt_1e-4": float((d > PSI_TOL).mean()),
                            "fp32_oracle": {"max": float(d32.max()), "p99": float(np.percentile(d32, 99)),
                                            "frac_gt_1e-4": float((d32 > PSI_TOL).mean())}}}
-    assert disp_h.sum() <= 1.5 * disp_o.sum() + max(3, 0.01 * Ng), (what, "displaced genes", rep["displaced_genes"])
+    assert moved_h.sum() <= 1.5 * moved_o.sum() + max(3, 0.01 * Ng), (what, "moved genes", rep["displaced_genes"], rep["clustered_genes"])
     assert s_h.max() <= 0.15, (what, "gene shift", float(s_h.max()))
-    if keep.any():
+
+    def stats(keep):
         dk, dk32 = d[:, keep], d32[:, keep]
-        n, n32 = int((dk > PSI_TOL).sum()), int((dk32 > PSI_TOL).sum())
-        rep["undisplaced_genes"] = {"genes": int(keep.sum()), "entries": int(dk.size), "gt_1e-4": {"hip": n, "fp32_oracle": n32},
-                                    "p99": {"hip": float(np.percentile(dk, 99)), "fp32_oracle": float(np.percentile(dk32, 99))},
-                                    "max": {"hip": float(dk.max()), "fp32_oracle": float(dk32.max())}}
-        assert n <= 1.5 * n32 + max(1e-5 * dk.size, 50), (what, "entries beyond 1e-4 outside displaced genes", n, n32, dk.size)
-        assert np.percentile(dk, 99) <= max(PSI_TOL, 1.5 * np.percentile(dk32, 99)), (what, "p99", rep["undisplaced_genes"]["p99"])
-        assert dk.max() <= max(2e-3, 3 * dk32.max()), (what, "max", rep["undisplaced_genes"]["max"])
+        return {"genes": int(keep.sum()), "entries": int(dk.size),
+                "gt_1e-4": {"hip": int((dk > PSI_TOL).sum()), "fp32_oracle": int((dk32 > PSI_TOL).sum())},
+                "p99": {"hip": float(np.percentile(dk, 99)), "fp32_oracle": float(np.percentile(dk32, 99))},
+                "max": {"hip": float(dk.max()), "fp32_oracle": float(dk32.max())}}
+    if undisp.any():
+        u = rep["undisplaced_genes"] = stats(undisp)
+        assert u["max"]["hip"] <= max(2e-3, 3 * u["max"]["fp32_oracle"]), (what, "max", u["max"])
+    if quiet.any():
+        q = rep["quiet_genes"] = stats(quiet)
+        n, n32 = q["gt_1e-4"]["hip"], q["gt_1e-4"]["fp32_oracle"]
+        assert n <= 1.5 * n32 + max(1e-5 * q["entries"], 50), (what, "entries beyond 1e-4 in quiet genes", n, n32, q["entries"])
+        assert q["p99"]["hip"] <= max(PSI_TOL, 1.5 * q["p99"]["fp32_oracle"]), (what, "p99", q["p99"])
     return rep
 
 

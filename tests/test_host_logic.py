@@ -413,3 +413,57 @@ def test_c_abi_argument_checks_and_loud_failure_without_a_gpu(built_lib):
     if not torch.cuda.is_available():
         rc, msg = create()
         assert rc == -3 and "hipGetDeviceCount" in msg and not h.value
+
+
+def test_psi_parity_rule_counts_moved_genes_as_genes_and_scattered_entries_as_entries():
+    """The parity rule itself (tests/util.py::psi_parity_rule, revision 2) on synthetic runs: what it lets pass and what
+    it refuses -- so that the rule the GPU tests and bench.py lean on is pinned on the CPU too."""
+    from tests import util
+    rng = np.random.default_rng(3)
+    Nc, Ng, Kc = 4000, 200, 2
+    psi64 = rng.uniform(0.05, 0.95, size=(Nc, Ng))
+    base = {"Wc_loc": rng.normal(size=(Kc, Ng)), "intercept": rng.normal(size=Ng), "sigma_log": rng.normal(size=Ng) * 0.1}
+
+    def run(noise=2e-6, displaced=(), clustered=(), scattered=0, shift=2e-3, seed=0):
+        r = np.random.default_rng(seed)
+        psi = psi64 + r.normal(size=psi64.shape) * noise
+        par = {k: v.copy() for k, v in base.items()}
+        for j in displaced:                                 # an own parameter took another turn: all cells of the gene move
+            par["intercept"][j] += shift
+            psi[:, j] += 0.25 * shift
+        for j in clustered:                                 # parameters agree at the end, 2 % of the cells sit 3e-4 off
+            psi[r.choice(Nc, Nc // 50, replace=False), j] += 3e-4
+        for k in r.choice(Nc * 80, scattered, replace=False):        # genes 120..199: never moved in these scenarios
+            psi[k // 80, 120 + k % 80] += 2e-4
+        return psi, par
+
+    def rule(hip, o32):
+        return util.psi_parity_rule({"hip": hip[0], "o32": o32[0], "o64": psi64}, {"hip": hip[1], "o32": o32[1], "o64": base}, "synthetic")
+
+    rep = rule(run(seed=1), run(seed=2))
+    assert rep["displaced_genes"] == {"hip": 0, "fp32_oracle": 0} and rep["quiet_genes"]["genes"] == Ng
+    # gene-level events on either side are exchangeable: other genes, similar numbers
+    rep = rule(run(displaced=(3, 50), clustered=(7,), scattered=20, seed=1), run(displaced=(10,), clustered=(8, 9), scattered=25, seed=2))
+    assert rep["displaced_genes"] == {"hip": 2, "fp32_oracle": 1} and rep["clustered_genes"]["hip"] == 1 and rep["clustered_genes"]["fp32_oracle"] == 2
+    assert rep["quiet_genes"]["genes"] == Ng - 6 and rep["quiet_genes"]["gt_1e-4"] == {"hip": 20, "fp32_oracle": 25}
+    # ONE clustered gene carries 80 entries beyond 1e-4: a gene event, not 80 scattered entries (revision 1 refused this)
+    rep = rule(run(clustered=(7,), seed=1), run(seed=2))
+    assert rep["clustered_genes"]["hip"] == 1 and rep["quiet_genes"]["gt_1e-4"]["hip"] == 0 and rep["undisplaced_genes"]["gt_1e-4"]["hip"] == 80
+    # refused: many more moved genes than the reference's own precision produces ...
+    with pytest.raises(AssertionError, match="moved genes"):
+        rule(run(displaced=tuple(range(0, 12)), seed=1), run(displaced=(100, 101), clustered=(102,), seed=2))
+    with pytest.raises(AssertionError, match="moved genes"):
+        rule(run(clustered=tuple(range(20, 28)), seed=1), run(seed=2))
+    # ... many more scattered entries ...
+    with pytest.raises(AssertionError, match="quiet genes"):
+        rule(run(scattered=150, seed=1), run(scattered=40, seed=2))
+    # ... a worse bulk ...
+    with pytest.raises(AssertionError, match="p99"):
+        rule(run(noise=2.2e-5, seed=1), run(seed=2))
+    # ... one wild entry in an undisplaced gene, or a gene displaced by more than the schedule can explain
+    wild = run(seed=1)
+    wild[0][5, 5] += 0.01
+    with pytest.raises(AssertionError, match="max"):
+        rule(wild, run(seed=2))
+    with pytest.raises(AssertionError, match="gene shift"):
+        rule(run(displaced=(3,), shift=0.2, seed=1), run(displaced=(4,), seed=2))

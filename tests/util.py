@@ -121,7 +121,8 @@ def psi_parity_rule(psi, par, what=""):
       moved gene = displaced or clustered;  quiet gene = moved in NEITHER run.
       1. genes:    #moved(hip) <= 1.5 #moved(o32) + max(3, 1 % of the genes);
       2. entries of quiet genes:  #(d > 1e-4) <= 1.5 #(d32 > 1e-4) + max(1e-5 n, 50);
-      3. their bulk:   p99(d) <= max(1e-4, 1.5 p99(d32));
+      3. their bulk:   p99(d) <= 1.5 p99(d32) + 1e-5   (revision 1's "max(1e-4, 1.5 p99(d32))" is implied by the
+                       definition of a quiet gene and was replaced; observed ratio <= 1.48 on the thirteen cases);
       4. the worst entry of every gene not displaced in either run (clustered ones included):
                        max d <= max(2e-3, 3 max d32)   (a fifth of what one flipped +-lr step of a CELL's own Z_loc can do);
       5. a displaced gene is displaced by a bounded amount: shift <= 0.15 (the sum of the six stage learning rates is 0.051;
@@ -159,7 +160,7 @@ def psi_parity_rule(psi, par, what=""):
         q = rep["quiet_genes"] = stats(quiet)
         n, n32 = q["gt_1e-4"]["hip"], q["gt_1e-4"]["fp32_oracle"]
         assert n <= 1.5 * n32 + max(1e-5 * q["entries"], 50), (what, "entries beyond 1e-4 in quiet genes", n, n32, q["entries"])
-        assert q["p99"]["hip"] <= max(PSI_TOL, 1.5 * q["p99"]["fp32_oracle"]), (what, "p99", q["p99"])
+        assert q["p99"]["hip"] <= 1.5 * q["p99"]["fp32_oracle"] + 1e-5, (what, "p99", q["p99"])
     return rep
 
 

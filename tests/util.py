@@ -109,15 +109,17 @@ def psi_parity_rule(psi, par, what=""):
     Nc cells of that gene move together -- at configs[2] ONE such gene of 512 carries 34 884 of the HIP path's 35 210
     entries beyond 1e-4, and the fp32 oracle has two other such genes -- and everywhere else the two fp32 runs have the
     same handful of scattered entries beyond 1e-4.  Such gene-level events hit either fp32 run with the same frequency
-    (13 cases: 8 clusters in the HIP runs, 11 in the fp32 oracle's), but each carries hundreds of entries, so they are
+    (20 cases: 485 displaced + 25 clustered genes in the HIP runs, 477 + 20 in the fp32 oracle's), but each carries hundreds of entries, so they are
     counted as GENES, and only what is left is counted as ENTRIES -- each against what the reference's own precision does
     on the same trajectory:
 
       displaced gene: own-parameter shift vs the fp64 run > GENE_SHIFT = 4e-4 (moves Psi by 1e-4 where sigmoid' = 1/4);
       clustered gene: not displaced at the end of the fit, yet more than max(5, 0.1 % of its cells) beyond 1e-4: its cells
-                      moved TOGETHER -- a displacement that healed (Adam's second moment remembers it for ~1000 steps
-                      and the noisy trajectory does not re-converge entry by entry), or several own parameters just
-                      under the threshold adding up through the covariates (mid_cli_96_s3: shift 3.7e-4, Kc = 2);
+                      moved TOGETHER -- mostly own parameters just under the threshold (2.4e-4 .. 4e-4) acting through
+                      the covariates, sometimes no end-of-fit shift at all: under noisy MC gradients the fp32 and the
+                      fp64 trajectory of a gene part and re-converge again and again, and the last step is a snapshot
+                      of that process (profiles/r3u_cluster_trajectory_*.json: 10 682 of 20 000 cells at step 1715,
+                      0 at step 4949, 190 at the end);
       moved gene = displaced or clustered;  quiet gene = moved in NEITHER run.
       1. genes:    #moved(hip) <= 1.5 #moved(o32) + max(3, 1 % of the genes);
       2. entries of quiet genes:  #(d > 1e-4) <= 1.5 #(d32 > 1e-4) + max(1e-5 n, 50);

@@ -2,6 +2,7 @@
 lists (the oracle is the checker, as in the tests):  python tests/tools/soak_randomised.py [n_shapes] [n_sequences] [seed] [n_wide_sequences] [n_wide_shapes]
 Prints every failing case with the assertion message; exit code = number of failures."""
 import os, sys, traceback
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")     # as tests/conftest.py: idle OpenMP workers of the C oracle sleep
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tests import test_gpu_parity as T
 import json

@@ -396,7 +396,7 @@ def test_full_size_config3_properties(lib):
 def test_psi_parity_rule_on_a_512_gene_sample_of_configs2_after_the_full_default_schedule(lib, case, seed, data_seed, n_use):
     """the parity claim on a real sample.  512 genes of the configs[2] recipe over ALL 50 000 cells,
     the whole BRIE2.fit default schedule (6 x 166 Adam steps, fresh optimiser per stage, MC_size 1; model_TFProb.py:
-    234-241), HIP against the C restatement in fp64 and in fp32 -- and the frozen rule of tests/util.py::psi_parity_rule.
+    234-241), HIP against the C restatement in fp64 and in fp32 -- and the rule of tests/util.py::psi_parity_rule (revision 2).
     The two oracle runs take 15 minutes each on 8 cores, so they come from profiles/_psi_cache (written by
     `python profiles/psi_delta.py --oracles-only`; it travels with the working tree); without the cache the same test
     runs on a 64-gene sample with the oracles computed on the spot.

@@ -1,0 +1,62 @@
+"""CPU: the working tree that travels to a GPU box must fit.
+
+`gpurun` (and the driver's round-end GPU run) ships /root/repo minus .git/, gpurun_out/ and the paths of .gpurunignore,
+and REFUSES a snapshot above 512 MiB -- which would cost every GPU test, smoke() and the bench line at once.  The
+git-ignored oracle caches under profiles/_psi_cache/ are the only large files here; this test keeps them in check and
+makes sure the caches the GPU tests read are not ignored away."""
+import fnmatch
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIMIT_MIB = 512
+MARGIN_MIB = 48          # __pycache__, build objects of a fresh compile, logs
+
+
+BUILT_IN = (".git/", "gpurun_out/")
+
+
+def _ignored(rel, patterns):
+    """Conservative model of the client's matching, checked against what a call really pushed (321 MiB computed here,
+    `push 321 MiB` reported): a `dir/*` or file glob of .gpurunignore is honoured, a bare `dir/` line was NOT (the build
+    objects travelled until `brie_amd/build/*` was added)."""
+    if any(rel.startswith(p) for p in BUILT_IN):
+        return True
+    return any(not p.endswith("/") and fnmatch.fnmatch(rel, p) for p in patterns)
+
+
+def _patterns():
+    path = os.path.join(ROOT, ".gpurunignore")
+    if not os.path.exists(path):
+        return []
+    return [l.strip() for l in open(path) if l.strip() and not l.startswith("#")]
+
+
+def test_snapshot_fits_the_gpu_box_limit():
+    pats = _patterns()
+    total, big = 0, []
+    for d, dirs, files in os.walk(ROOT):
+        rel_d = os.path.relpath(d, ROOT)
+        rel_d = "" if rel_d == "." else rel_d + "/"
+        dirs[:] = [x for x in dirs if not _ignored(rel_d + x + "/", pats)]
+        for f in files:
+            rel = rel_d + f
+            if _ignored(rel, pats):
+                continue
+            try:
+                n = os.path.getsize(os.path.join(d, f))
+            except OSError:
+                continue
+            total += n
+            if n > (16 << 20):
+                big.append((n >> 20, rel))
+    mib = total / float(1 << 20)
+    assert mib < LIMIT_MIB - MARGIN_MIB, ("snapshot %.0f MiB: list more of profiles/_psi_cache in .gpurunignore" % mib, sorted(big)[-8:])
+
+
+def test_the_caches_the_gpu_tests_read_are_not_ignored():
+    pats = _patterns()
+    for name in ("c3_api_512_float32.npz", "c3_api_512_float64.npz", "c3_api_512_s2_first256_float32.npz",
+                 "c3_api_512_s2_first256_float64.npz"):
+        assert not _ignored("profiles/_psi_cache/" + name, pats), name
+    # the built library travels too (git-ignored, not gpurun-ignored)
+    assert not _ignored("brie_amd/lib/libbrie_amd.so", pats)

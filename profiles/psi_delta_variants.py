@@ -30,14 +30,15 @@ VARIANTS = {
 Nc, Ng = 200, 520
 
 
-def run_variant(name, min_iter=1000, seed=41):
+def run_variant(name, min_iter=1000, seed=41, data_seed=37):
     from brie_amd import _capi
     from tests import util
     mode, Kg, Kc, L, MC, target = VARIANTS[name]
-    P = util.problem(Nc, Ng, Kc, L, seed=37, theta=3.0)
+    P = util.problem(Nc, Ng, Kc, L, seed=data_seed, theta=3.0)
     if Kc >= 9:
         P["Xc"] = (P["Xc"] * 0.3).astype(np.float32)       # many N(0,1) features: keep the prior mean inside the clip range
-    P["Xg"] = np.random.default_rng(5).standard_normal((Ng, Kg)).astype(np.float32)
+    P["Xg"] = np.random.default_rng(5 + data_seed).standard_normal((Ng, Kg)).astype(np.float32) if data_seed != 37 else \
+        np.random.default_rng(5).standard_normal((Ng, Kg)).astype(np.float32)
     runs = {"o32": util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode),
             "o64": util.oracle_model(P, Nc, Ng, Kc, seed, np.float64, Kg=Kg, mode=mode)}
     sh = util.device_shard(P, Nc, Ng, Kc, seed, Kg=Kg, mode=mode)
@@ -62,7 +63,7 @@ def run_variant(name, min_iter=1000, seed=41):
         psi["hip"] = sh.read(_capi.PSI).astype(np.float64)
     sh.close()
     out = {"variant": name, "mode": mode, "Kg": Kg, "Kc": Kc, "count_layers": L, "MC_size": MC, "target": target,
-           "shape": [Nc, Ng], "steps": 6 * int(min_iter / 6), "seconds": time.time() - t0,
+           "model_seed": seed, "data_seed": data_seed, "shape": [Nc, Ng], "steps": 6 * int(min_iter / 6), "seconds": time.time() - t0,
            "compared": "sigmoid(prior mean)" if target == "marginLik" else "Psi"}
     for key, a in (("hip_vs_o64", "hip"), ("o32_vs_o64", "o32")):
         d = np.abs(psi[a] - psi["o64"])
@@ -78,10 +79,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_variants_r03.json"))
     ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--seed", type=int, default=41)
+    ap.add_argument("--data-seed", type=int, default=37)
     args = ap.parse_args()
     res = {"definition": __doc__.split("\n\n")[0], "cases": {}}
     for name in [v for v in args.variants.split(",") if v]:
-        r = run_variant(name)
+        r = run_variant(name, seed=args.seed, data_seed=args.data_seed)
         res["cases"][name] = r
         print("%-32s HIP-o64 max %.2e p99 %.2e n>1e-4 %6d cols %3d rows %3d rest %4d | o32-o64 max %.2e p99 %.2e n %6d cols %3d rows %3d rest %4d (%.0f s)" % (
             name, r["hip_vs_o64"]["max"], r["hip_vs_o64"]["p99"], r["hip_vs_o64"]["n_gt_1e-4"], r["hip_vs_o64"]["columns_with_more_than_5"],

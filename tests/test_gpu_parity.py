@@ -972,10 +972,12 @@ def test_psi_after_full_default_schedule_model_variants(lib, variant):
     steps, fresh Adam per stage): HIP against the NumPy restatement in fp64, next to the same restatement in fp32.
     In the coupled models one sign event in a parameter shared by a row (a cell's Wg_loc entry, its intercept) reaches every
     gene of that cell, so fp32 and fp64 part widely -- 21 % of the entries beyond 1e-4 with two gene features, for the
-    fp32 oracle and for the HIP path alike (profiles/psi_delta_variants_r03.json: entry counts HIP / fp32 oracle 1.03,
-    0.57, 0.96, 1.08, 1.00; p99 1.03, 0.48, 0.86, 1.57, 0.95).  The gene-level rule of tests/util.py has no meaning here;
+    fp32 oracle and for the HIP path alike.  Which run draws the larger events is a coin toss at this size (200 x 520):
+    over two sets of seeds and six variants the entry counts HIP / fp32 oracle range from 0.27 to 2.05 (1.03, 0.57, 0.96,
+    1.08, 1.00 with the seeds used here; 0.27, 2.05, 1.17, 0.94, 1.02 with others), p99 from 0.48 to 2.0
+    (profiles/psi_delta_variants_r03.json, ..._seed59.json).  The gene-level rule of tests/util.py has no meaning here;
     what is asserted is that the HIP path is no further from the fp64 answer than the reference's own precision is, as a
-    distribution: count, bulk and worst entry (coarse factors: this family has one seed of evidence per variant)."""
+    distribution and within the factor 3 that two fp32 runs differ by among themselves: count, bulk and worst entry."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -984,6 +986,6 @@ def test_psi_after_full_default_schedule_model_variants(lib, variant):
     h, o = r["hip_vs_o64"], r["o32_vs_o64"]
     print(variant, "HIP vs fp64:", h, "| fp32 oracle vs fp64:", o)
     n = r["shape"][0] * r["shape"][1]
-    assert h["n_gt_1e-4"] <= 1.5 * o["n_gt_1e-4"] + max(1e-3 * n, 50), (variant, h["n_gt_1e-4"], o["n_gt_1e-4"])
-    assert h["p99"] <= 2.0 * o["p99"] + 1e-5, (variant, h["p99"], o["p99"])
+    assert h["n_gt_1e-4"] <= 3.0 * o["n_gt_1e-4"] + max(1e-3 * n, 50), (variant, h["n_gt_1e-4"], o["n_gt_1e-4"])
+    assert h["p99"] <= 3.0 * o["p99"] + 1e-5, (variant, h["p99"], o["p99"])
     assert h["max"] <= max(2e-3, 3.0 * o["max"]), (variant, h["max"], o["max"])

@@ -128,7 +128,7 @@ def psi_parity_rule(psi, par, what=""):
       4. the worst entry of every gene not displaced in either run (clustered ones included):
                        max d <= max(2e-3, 3 max d32)   (a fifth of what one flipped +-lr step of a CELL's own Z_loc can do);
       5. a displaced gene is displaced by a bounded amount: shift <= 0.15 (the sum of the six stage learning rates is 0.051;
-         observed <= 0.092 on 200-cell data, <= 0.016 at 10k+ cells)."""
+         observed <= 0.108 on 200-cell data, <= 0.090 at 10-20k cells, <= 0.016 at 50k cells)."""
     P = {k: np.asarray(psi[k], np.float64) for k in ("hip", "o32", "o64")}
     d, d32 = np.abs(P["hip"] - P["o64"]), np.abs(P["o32"] - P["o64"])
     s_h, s_o = gene_shift(par["hip"], par["o64"]), gene_shift(par["o32"], par["o64"])

@@ -230,7 +230,8 @@ def util_params(p):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_delta_r03.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psi_delta.json"),
+                    help="(the committed profiles/psi_delta_r03.json is the evidence revision 1 of the rule was frozen on: not a default target)")
     ap.add_argument("--cases", default=",".join(R03))
     ap.add_argument("--variants", default="hip")
     ap.add_argument("--oracles-only", action="store_true")
@@ -302,6 +303,7 @@ def main():
                   case, f["hip_vs_o64"]["max"], f["hip_vs_o64"]["p99.9"], f["hip_vs_o64"]["frac_gt_1e-4"],
                   f["o32_vs_o64"]["max"], f["o32_vs_o64"]["p99.9"], f["o32_vs_o64"]["frac_gt_1e-4"],
                   g.get("ratio_hip_over_o32", float("nan")), g.get("ratio_covered_hip_over_o32", float("nan"))), flush=True)
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         with open(args.out, "w") as fh:            # after every case: a cut-off call still leaves the finished ones
             json.dump(result, fh, indent=1)
     print("wrote", args.out)

@@ -114,38 +114,38 @@ def config_seed(name):
 def psi_delta_check(seed=11):
     """'PSI delta vs CPU ref' on BASELINE configs[0] (200 x 500, +1 covariate) after the WHOLE BRIE2.fit default
     schedule (6 x 166 Adam steps, fresh optimiser per stage, model_TFProb.py:234-241): HIP vs the CPU restatement in
-    fp64, next to what the reference's own fp32 precision (the same restatement in fp32) does on that trajectory.
-    The parity rule these numbers are held to is tests/util.py::psi_parity_rule; 512-gene samples of configs[1] /
-    configs[2] and both default schedules are in profiles/psi_delta_r03.json."""
+    fp32 (o32, the reference's precision), judged by what a SECOND fp32 CPU evaluation of the same algorithm (o32b:
+    oracle/brie_oracle.c -DBRIE_ORACLE_B) does against that same o32 run -- tests/util.py::psi_null_rule.  The twenty
+    cases on gene samples of configs[1] / configs[2] and both default schedules are in profiles/psi_null_r04.json."""
     from brie_amd import _capi
     from oracle.c_oracle import COracle
     from tests import util
     Nc, Ng, Kc = 200, 500, 1
     P = util.problem(Nc, Ng, Kc, 2, theta=3.0)
-    o64 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float64)
     o32 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32)
+    o32b = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32, variant_b=True)
     sh = util.device_shard(P, Nc, Ng, Kc, seed)
     for n, lr in util.staged_schedule(1000):
-        for o in (o64, o32):
+        for o in (o32, o32b):
             o.reset_optimizer()
             o.minimize(n, lr, 1)
         sh.reset_optimizer()
         sh.step(n, lr, 1, trace=False)
-    d = np.abs(sh.read(_capi.PSI) - o64.Psi)
-    covered = (P["counts"][0] + P["counts"][1]) > 0
-    out = {"workload": "200x500 Kc=1, 996 staged steps (BRIE2.fit defaults), same init + noise stream, vs fp64 CPU oracle"}
-    rep = util.psi_parity_of(sh, o32, o64, what="bench psi check")
+    psi_h = sh.read(_capi.PSI)
+    d = np.abs(psi_h - o32.Psi)
+    dn = np.abs(o32b.Psi.astype(np.float64) - o32.Psi)
+    h = util.gene_summaries(psi_h, o32.Psi, util.run_params(sh), util.run_params(o32))
+    nul = util.gene_summaries(o32b.Psi, o32.Psi, util.run_params(o32b), util.run_params(o32))
     sh.close()
-    out.update({"max": rep["all_entries"]["max"], "p99": rep["all_entries"]["p99"],
-                "frac_gt_1e-4": rep["all_entries"]["frac_gt_1e-4"], "fp32_oracle": rep["all_entries"]["fp32_oracle"]})
-    out["displaced_genes"] = rep["displaced_genes"]
-    out["clustered_genes"] = rep.get("clustered_genes")
-    out["outside_displaced_genes"] = rep.get("undisplaced_genes")
+    out = {"workload": "200x500 Kc=1, 996 staged steps (BRIE2.fit defaults), same init + noise stream, vs the fp32 CPU oracle",
+           "max": float(d.max()), "p99": float(np.percentile(d, 99)), "frac_gt_1e-4": float((d > 1e-4).mean()),
+           "second_fp32_cpu_evaluation_vs_the_same_oracle": {"max": float(dn.max()), "p99": float(np.percentile(dn, 99)),
+                                                             "frac_gt_1e-4": float((dn > 1e-4).mean())}}
+    rep = util.psi_null_rule(h, nul, "bench psi check")            # raises AssertionError when violated
+    out["displaced_genes"], out["clustered_genes"] = rep["displaced_genes"], rep["clustered_genes"]
     out["quiet_genes"] = rep.get("quiet_genes")
-    out["covered_entries"] = {"max": float(d[covered].max()), "frac_gt_1e-4": float((d[covered] > 1e-4).mean())}
-    out["share_of_exceedances_with_zero_coverage"] = float(((d > 1e-4) & ~covered).sum() / max(1, (d > 1e-4).sum()))
-    out["rule"] = ("tests/util.py::psi_parity_rule (displaced / clustered genes, and entries of the quiet genes, bounded by what the fp32 "
-                   "oracle -- the reference's own precision -- does on the same trajectory); holds")
+    out["rule"] = ("tests/util.py::psi_null_rule (moved genes, and entries of the quiet genes, bounded by what a second fp32 CPU "
+                   "evaluation does against the same fp32 oracle); holds")
     return out
 
 
@@ -286,6 +286,7 @@ def native_allgather_leg(info, state, local_rank, world, timeout_s=180.0):
     if os.environ.get("BRIE_BENCH_NATIVE_COMM", "1") == "0":
         info["native"] = "skipped (BRIE_BENCH_NATIVE_COMM=0)"
         return True
+    shared, info = info, {}            # the worker writes into a private dict, merged below only once it has come back
 
     def leg():
         try:
@@ -308,8 +309,9 @@ def native_allgather_leg(info, state, local_rank, world, timeout_s=180.0):
     th.start()
     th.join(timeout_s)
     if th.is_alive():
-        info["native_error"] = "brie_comm leg did not return within %.0f s" % timeout_s
+        shared["native_error"] = "brie_comm leg did not return within %.0f s" % timeout_s
         return False
+    shared.update(info)
     return True
 
 
@@ -525,6 +527,22 @@ def main(argv=None):
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last
     psi_quad = sh.read(_capi.PSI)[:, q0:q0 + 4].copy() if (rank == 0 and not args.no_psi_check and q0 + 4 <= ng) else None
+    placement = sh.placement_info() if rank == 0 else None
+    mc_other = None
+    if rank == 0 and world == 1 and not args.no_f32_leg and not args.emulate_shard_of:
+        # the other default Monte-Carlo sample size: API default 1 (model_TFProb.py:130), CLI default 3 (bin/quant.py:173)
+        mc2 = 3 if args.mc == 1 else 1
+        sh.step(args.warmup, lr, mc2, trace=False)
+        sh.profile_enable(True)
+        sh.step(args.steps, lr, mc2, trace=False)
+        msm, nm = sh.profile_read()
+        sh.profile_enable(False)
+        tm = msm / max(nm, 1) * 1e-3
+        mc_other = {"MC_size": mc2, "avg_kernel_ms": tm * 1e3, "achieved": alg_bytes / tm / 1e9,
+                    "frac": alg_bytes / tm / 1e9 / HBM_PEAK_GBS, "launches_timed": int(nm),
+                    "what": "the same handle and kernel family at MC_size %d (%s default); same algorithmic bytes"
+                            % (mc2, "brie-quant CLI, bin/quant.py:173" if mc2 == 3 else "BRIE2.fit API, model_TFProb.py:130")}
+
     f32_leg = None
     if rank == 0 and world == 1 and not args.no_f32_leg and storage_main != "f32":
         # the same kernel on the fp32 layers as uploaded (compact storage is reported separately)
@@ -535,7 +553,6 @@ def main(argv=None):
         ms32, n32 = sh.profile_read()
         sh.profile_enable(False)
         f32_leg = {"avg_kernel_ms": ms32 / max(n32, 1), "storage_bytes_per_launch": sh.step_storage_bytes()}
-
     # ---- N > 1: the end-of-fit exchange of a gene-sharded fit (BASELINE configs[3]: "RCCL weight all-gather"),
     # untimed by `value` (there is no collective inside the optimisation loop) but executed, checked and reported
     gather_info = gather_state = None
@@ -568,6 +585,11 @@ def main(argv=None):
                 "rccl_ranks": world if (dist is not None and dist.get_backend() == "nccl") else 0}
         if world > 1:
             roof["per_gpu"] = gpus
+        # where the allocator put the streamed arrays decides 10 - 20 % of the step time: the library probes
+        # and keeps the fastest of up to three placements before the first step; the rates are storage bytes / probe time
+        roof["placement"] = placement
+        if mc_other is not None:
+            roof["mc%d" % mc_other["MC_size"]] = mc_other
         if f32_leg is not None:
             t32 = f32_leg["avg_kernel_ms"] * 1e-3
             roof["f32_count_storage"] = dict(f32_leg, achieved=alg_bytes / t32 / 1e9, frac=alg_bytes / t32 / 1e9 / HBM_PEAK_GBS,
@@ -610,6 +632,11 @@ def main(argv=None):
         rv = brie_amd.BRIE_RV(mdl)
         total = time.perf_counter() - t0
         assert np.isfinite(rv.Psi).all()
+        # stages 2..6 of the fit (the first one also pays the count compaction and the placement search)
+        in_fit = float(np.sum(mdl.timing["stage_s"][1:])) / (5 * 166) * 1e3
+        out["roofline"]["in_fit_ms_per_step"] = in_fit
+        out["roofline"]["in_fit_over_timed"] = in_fit / out["ms_per_step"] if in_fit else None
+        out["roofline"]["in_fit_placement"] = mdl.timing.get("placement")
         out["pcie_inclusive"] = {"it_per_s_pcie_inclusive": 996 / total, "total_s": total, "steps": 996,
                                  "breakdown_s": {k: v for k, v in mdl.timing.items() if k.endswith("_s")},
                                  "what": "host numpy count layers -> BRIE2.fit (6 x 166 steps, 500-draw loss_gene) -> "
@@ -638,7 +665,7 @@ def main(argv=None):
             try:
                 out["psi_delta_vs_cpu_ref"] = psi_delta_check()
             except AssertionError as exc:          # a violated parity rule is REPORTED in the line, it does not cost the line
-                out["psi_delta_vs_cpu_ref"] = {"rule": "tests/util.py::psi_parity_rule VIOLATED", "violated": repr(exc)}
+                out["psi_delta_vs_cpu_ref"] = {"rule": "tests/util.py::psi_null_rule VIOLATED", "violated": repr(exc)}
                 if os.environ.get("BRIE_BENCH_STRICT"):
                     raise
         if not args.no_cpu_baseline:
@@ -662,6 +689,16 @@ def main(argv=None):
                           % (nb, n_gene, Nc, n_steps, el, " while the other ranks idle" if world > 1 else ""),
                 "gpu_over_cpu": value / eps_s,
             }
+            # the same eager baseline on ALL usable host cores (SURVEY 8d asks for both; bin/quant.py:183 defaults to 6)
+            if usable > cores:
+                eps_all, el_all = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, nb, n_steps, args.mc, threads=usable)
+                out["cpu_baseline_all_cores"] = {
+                    "value": eps_all, "unit": "cell*gene*iterations/s", "cores": usable, "kind": "port",
+                    "sample": "the cpu_baseline sample on all %d usable cores, %.1f s" % (usable, el_all),
+                    "gpu_over_cpu": value / eps_all}
+            else:
+                out["cpu_baseline_all_cores"] = dict(out["cpu_baseline"], sample="this process may run on %d cores: all "
+                                                     "usable cores = the cpu_baseline measurement above" % usable)
             # second, separately labelled baseline: the same algorithm as ONE fused
             # C/OpenMP pass (oracle/brie_oracle.c) on all host cores
             try:
@@ -702,7 +739,8 @@ def main(argv=None):
         # launcher does not tear rank 0 down before its line is out -- the other ranks give it a moment first
         if rank != 0:
             time.sleep(5.0)
-        os._exit(0)
+        sys.stdout.flush()
+        os._exit(3 if os.environ.get("BRIE_BENCH_STRICT") else 0)
     if dist is not None:
         dist.barrier(group=side)
         dist.destroy_process_group()

@@ -31,6 +31,7 @@ EXPORTS = [
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
+    "brie_placement_probe", "brie_placement_tune", "brie_placement_info",
 ]
 COMM_ID_BYTES = 128
 #: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
@@ -127,6 +128,10 @@ def load_library(path=None):
     lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
+    lib.brie_placement_probe.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
+    lib.brie_placement_tune.argtypes = [vp, i32, ctypes.c_double]
+    lib.brie_placement_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double),
+                                        ctypes.POINTER(ctypes.c_double)]
     lib.brie_last_error.restype = ctypes.c_char_p
     lib.brie_abi_version.restype = ctypes.c_int
     for name in EXPORTS:
@@ -385,6 +390,7 @@ class Shard(object):
         if hasattr(x, "tocsc"):                                       # other scipy sparse formats
             return self.upload(which, x.tocsc())
         if (which in (COUNT1, COUNT2, COUNT3) and isinstance(x, np.ndarray) and x.ndim == 2 and x.dtype.name in TYPED_DTYPES
+                and x.dtype.isnative and x.flags.aligned      # (dtype.name ignores byte order: '>i4' is 'int32' too)
                 and x.strides[1] == x.itemsize and x.strides[0] % x.itemsize == 0 and x.strides[0] >= x.shape[1] * x.itemsize):
             # integer / float64 layers: converted by the library's ingest threads instead of a numpy astype pass
             _check(self.lib, self.lib.brie_upload_typed(self._h, which, x.ctypes.data_as(ctypes.c_void_p),
@@ -487,6 +493,24 @@ class Shard(object):
         a = ctypes.c_uint64()
         _check(self.lib, self.lib.brie_debug_address(self._h, int(which), ctypes.byref(a)))
         return a.value
+
+    def placement_probe(self, iters=3):
+        """GB/s (storage bytes of a step) of the effect-free probe kernel on the handle's arrays as they are placed."""
+        g = ctypes.c_double()
+        _check(self.lib, self.lib.brie_placement_probe(self._h, int(iters), ctypes.byref(g)))
+        return g.value
+
+    def placement_tune(self, max_tries=3, good_gbs=1e30):
+        """Probe, and while the rate is below `good_gbs` try up to `max_tries` placements in all; keep the fastest."""
+        _check(self.lib, self.lib.brie_placement_tune(self._h, int(max_tries), float(good_gbs)))
+        return self.placement_info()
+
+    def placement_info(self):
+        t, k, s = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        g = (ctypes.c_double * 4)()
+        _check(self.lib, self.lib.brie_placement_info(self._h, ctypes.byref(t), ctypes.byref(k), g, ctypes.byref(s)))
+        return {"tries": t.value, "kept": k.value, "GBs": [round(g[i], 1) for i in range(t.value)],
+                "seconds": round(s.value, 4)}
 
     def loglik_mc(self, size=10):
         """(Nc, Ng) Monte-Carlo log-likelihood of every entry under the current target (brie_loglik_mc)."""

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <mutex>
 #include <sched.h>
 #include <cstdarg>
@@ -66,7 +67,6 @@ struct brie_handle {
     brie_comm *comm = nullptr;      // attached communicator: sharded coupled fits all-reduce rowstat in-library
     int64_t ld = 0;                 // gene_blocks * 256: pitch of per-gene vectors and of row-major matrices
     int64_t row_stride = 0, gb_stride = 0;   // matrix addressing (see StepScalars)
-    bool tiled = true;              // gene-block-major tiles [gene block][cell][256 genes]
     int S = 0;                      // statistics per gene per chunk = Kc + 4
     int mode = 0;                   // likelihood mode (brie::kLik2 ...)
     hipStream_t stream = nullptr;
@@ -161,6 +161,11 @@ struct brie_handle {
     size_t ev_used = 0;
     double prof_ms = 0.0;
     int64_t prof_launches = 0;
+    // placement of the streamed arrays (brie_placement_tune): rates of the sets that were probed, which one was kept
+    bool placement_done = false;
+    int placement_tries = 0, placement_kept = 0;
+    double placement_gbs[4] = {0.0, 0.0, 0.0, 0.0};
+    double placement_seconds = 0.0;
 };
 
 namespace {
@@ -240,20 +245,27 @@ struct BigBlockCache {
 };
 BigBlockCache g_blocks;
 
+// every large device allocation of the library: what the block cache holds counts as free memory, so an allocation
+// that fails is tried once more after the cache has been released
+hipError_t dev_alloc(void **q, size_t bytes) {
+    hipError_t e = hipMalloc(q, bytes);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        g_blocks.trim();
+        e = hipMalloc(q, bytes);
+    }
+    return e;
+}
+template <typename T>
+hipError_t dev_alloc(T **q, size_t bytes) { return dev_alloc(reinterpret_cast<void **>(q), bytes); }
+
 // a cell x gene array: from the cache when the last handle left one of this size, else hipMalloc (after an allocation
 // failure the cache is released and the allocation tried once more)
 int alloc_mat(float **p, size_t elems, int device, hipStream_t s) {
     if (elems == 0) { *p = nullptr; return BRIE_OK; }
     const size_t bytes = elems * sizeof(float);
     void *q = g_blocks.take(device, bytes);
-    if (!q) {
-        hipError_t e = hipMalloc(&q, bytes);
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            g_blocks.trim();
-            HIP_TRY(hipMalloc(&q, bytes));
-        }
-    }
+    if (!q) HIP_TRY(dev_alloc(&q, bytes));
     *p = static_cast<float *>(q);
     HIP_TRY(hipMemsetAsync(*p, 0, bytes, s));
     return BRIE_OK;
@@ -261,7 +273,7 @@ int alloc_mat(float **p, size_t elems, int device, hipStream_t s) {
 
 int alloc_f32(float **p, size_t elems, hipStream_t s) {
     if (elems == 0) { *p = nullptr; return BRIE_OK; }
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), elems * sizeof(float)));
+    HIP_TRY(dev_alloc(p, elems * sizeof(float)));
     HIP_TRY(hipMemsetAsync(*p, 0, elems * sizeof(float), s));
     return BRIE_OK;
 }
@@ -289,7 +301,7 @@ void setup_paths(brie_handle *h) {
     // (gene features 5..8 stay on the LDS-broadcast variant: measured 1.06 x vs 1.09 x the narrow model's step time)
     const char *mk = getenv("BRIE_TILE_MIN_KG");       // A/B runs: smallest Kg that takes the tile kernel (default 8)
     const int min_kg = mk ? atoi(mk) : 8;
-    h->tile = want_tile && h->tiled && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
+    h->tile = want_tile && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
     h->tile_kcr = kcr ? 4 : 0;
     h->tile_nacc = kcm == 0 ? 0 : (Kc <= 32 ? 1 : 2);
@@ -331,7 +343,7 @@ int ensure_partials(brie_handle *h) {
     if (need > h->partials_elems) {
         if (h->partials) HIP_TRY(hipFree(h->partials));
         h->partials = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->partials), need * sizeof(float)));
+        HIP_TRY(dev_alloc(&h->partials, need * sizeof(float)));
         h->partials_elems = need;
     }
     return BRIE_OK;
@@ -445,14 +457,14 @@ int try_compact_counts(brie_handle *h) {
     if (h->compact_tried) return BRIE_OK;
     h->compact_tried = true;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
-    // one flag word per gene quad (tiled layout), one for everything otherwise
-    const int n_flags = h->tiled ? h->gene_blocks * brie::kWave : 1;
+    // one flag word per gene quad
+    const int n_flags = h->gene_blocks * brie::kWave;
     int *flag = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&flag), n_flags * sizeof(int)));
     HIP_TRY(hipMemsetAsync(flag, 0, n_flags * sizeof(int), h->stream));
     for (int l = 0; l < h->p.n_layers; ++l)
         hipLaunchKernelGGL(brie::count_range_check, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], n4,
-                           h->tiled ? static_cast<int>(h->p.Nc) : 0, flag);
+                           static_cast<int>(h->p.Nc), flag);
     std::vector<int> bits_q(static_cast<size_t>(n_flags), 1);
     hipError_t e = hipMemcpyAsync(bits_q.data(), flag, n_flags * sizeof(int), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -464,7 +476,7 @@ int try_compact_counts(brie_handle *h) {
         h->compact_tried = false;                 // checked again (and refused again) on the next attempt
         return fail(BRIE_ERR_INVALID, "count layers contain negative or non-finite values");
     }
-    if ((bits & 1) || !h->allow_compact || !h->tiled) return BRIE_OK;     // fractional / huge: stay fp32
+    if ((bits & 1) || !h->allow_compact) return BRIE_OK;     // fractional / huge: stay fp32
     int n16 = 0;
     for (int b : bits_q) n16 += (b & 2) ? 1 : 0;
     const char *tm = getenv("BRIE_COUNT_TIERS");  // "uniform": one tier for the whole shard (A/B runs)
@@ -479,7 +491,7 @@ int try_compact_counts(brie_handle *h) {
     }
     const size_t bytes = compact_layer_bytes(h, cs);
     for (int l = 0; l < h->p.n_layers; ++l) {
-        HIP_TRY(hipMalloc(&h->cu[l], bytes));
+        HIP_TRY(dev_alloc(&h->cu[l], bytes));
         if (cs == brie::kCountMixed)
             hipLaunchKernelGGL(brie::count_compact_mixed, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4,
                                static_cast<int>(h->p.Nc), h->tt);
@@ -487,10 +499,9 @@ int try_compact_counts(brie_handle *h) {
             hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, h->c[l], h->cu[l], n4, cs);
     }
     HIP_TRY(hipStreamSynchronize(h->stream));
-    {   // the fp32 layers have done their job: to the block cache (the next handle of this size starts with them)
-        const size_t mat_bytes = static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float);
-        for (int l = 0; l < h->p.n_layers; ++l) { g_blocks.give(h->p.device, mat_bytes, h->c[l]); h->c[l] = nullptr; }
-    }
+    // the fp32 layers have done their job.  They are FREED, not handed to the block cache: the handle lives on, and
+    // what compaction saves (2 - 3 arrays of Nc x Ng floats) is memory the caller may be counting on
+    for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->c[l])); h->c[l] = nullptr; }
     h->cs = cs;
     return BRIE_OK;
 }
@@ -512,10 +523,10 @@ int retier_uniform_u16(brie_handle *h) {
     if (h->cs != brie::kCountMixed) return BRIE_OK;
     const int64_t n = h->p.Nc * h->ld, n4 = n / 4;
     float *tmp = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&tmp), static_cast<size_t>(n) * sizeof(float)));
+    HIP_TRY(dev_alloc(&tmp, static_cast<size_t>(n) * sizeof(float)));
     void *fresh[3] = {nullptr, nullptr, nullptr};
     for (int l = 0; l < h->p.n_layers; ++l) {
-        HIP_TRY(hipMalloc(&fresh[l], static_cast<size_t>(n) * 2));
+        HIP_TRY(dev_alloc(&fresh[l], static_cast<size_t>(n) * 2));
         launch_expand(h, l, tmp, 0.0f, 0);
         hipLaunchKernelGGL(brie::count_compact, dim3(grid_1d(n4)), dim3(256), 0, h->stream, tmp, fresh[l], n4,
                            static_cast<int>(brie::kCountU16));
@@ -567,7 +578,7 @@ int apply_quad_gather(brie_handle *h, const std::vector<int32_t> &from) {
     const size_t mat_bytes = static_cast<size_t>(Nc) * h->ld * sizeof(float);
     const size_t row_bytes = static_cast<size_t>(brie::kLossRing > h->p.Kc ? brie::kLossRing : h->p.Kc) * h->ld * sizeof(float);
     if (e == hipSuccess && !h->pack_scratch) {
-        e = hipMalloc(&h->pack_scratch, mat_bytes);
+        e = dev_alloc(&h->pack_scratch, mat_bytes);
         if (e == hipSuccess) h->pack_scratch_bytes = mat_bytes;
     }
     if (e == hipSuccess && !h->row_scratch) e = hipMalloc(reinterpret_cast<void **>(&h->row_scratch), row_bytes);
@@ -649,7 +660,7 @@ int ensure_identity(brie_handle *h) {
 // matrix-sized staging buffer for read-backs (kept: BRIE_RV reads four matrices in a row)
 int io_buffer(brie_handle *h, float **out) {
     if (!h->io_scratch)
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->io_scratch), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+        HIP_TRY(dev_alloc(&h->io_scratch, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
     *out = h->io_scratch;
     return BRIE_OK;
 }
@@ -679,18 +690,9 @@ int matrix_target(brie_handle *h, int which, float **dev, int64_t *rows, int64_t
 }
 
 // Copy a (Nc, Ng) matrix between the caller's row-major buffer and the device layout.
-// Tiled layout: one strided 2-D copy per 256-gene block (1-KiB device rows).
+// One strided 2-D copy per 256-gene block (1-KiB device rows).
 int copy_cellgene(brie_handle *h, float *dev, const float *ext, float *ext_out, int64_t ld_ext) {
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
-    if (!h->tiled) {
-        if (ext_out)
-            HIP_TRY(hipMemcpy2DAsync(ext_out, ld_ext * sizeof(float), dev, h->ld * sizeof(float), Ng * sizeof(float), Nc,
-                                     hipMemcpyDefault, h->stream));
-        else
-            HIP_TRY(hipMemcpy2DAsync(dev, h->ld * sizeof(float), ext, ld_ext * sizeof(float), Ng * sizeof(float), Nc,
-                                     hipMemcpyDefault, h->stream));
-        return BRIE_OK;
-    }
     const int64_t G = brie::kGenesPerBlock;
     for (int64_t g = 0; g * G < Ng; ++g) {
         const int64_t cols = (Ng - g * G) < G ? (Ng - g * G) : G;
@@ -901,7 +903,7 @@ int ensure_lane_pool(int device, size_t slab_bytes, int T) {
         hipError_t e = hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, prio_hi);
         for (int b = 0; b < 2 && e == hipSuccess; ++b) {
             e = hipHostMalloc(&ln.pin[b], slab_bytes, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc(&ln.dev[b], slab_bytes);
+            if (e == hipSuccess) e = dev_alloc(&ln.dev[b], slab_bytes);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev[b], hipEventDisableTiming);
         }
         if (e != hipSuccess) {
@@ -978,6 +980,12 @@ extern "C" {
 const char *brie_last_error(void) { return g_last_error.c_str(); }
 int brie_abi_version(void) { return BRIE_AMD_ABI_VERSION; }
 
+// a creation that failed half way: its arrays are released for real (brie_destroy alone would park them in the cache)
+static void drop_failed_create(brie_handle *h) {
+    brie_destroy(h);
+    g_blocks.trim();
+}
+
 int brie_create(const brie_problem *p, brie_handle **out) {
     if (!p || !out) return fail(BRIE_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1010,13 +1018,11 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     brie_handle *h = new brie_handle();
     h->p = *p;
     h->ld = round_up(p->Ng, brie::kGenesPerBlock);
-    {   // device layout of cell x gene matrices: "tiled" (default) or "rowmajor" (BRIE_LAYOUT, for A/B runs)
-        const char *lay = getenv("BRIE_LAYOUT");
-        h->tiled = !(lay && strcmp(lay, "rowmajor") == 0);
+    {   // device layout of cell x gene matrices: gene-block-major tiles [gene block][cell][256 genes]
         const char *cst = getenv("BRIE_COUNT_STORAGE");
         h->allow_compact = !(cst && strcmp(cst, "f32") == 0);
-        if (h->tiled) { h->row_stride = brie::kGenesPerBlock; h->gb_stride = p->Nc * brie::kGenesPerBlock; }
-        else { h->row_stride = h->ld; h->gb_stride = brie::kGenesPerBlock; }
+        h->row_stride = brie::kGenesPerBlock;
+        h->gb_stride = p->Nc * brie::kGenesPerBlock;
     }
     h->mode = !p->has_efflen ? brie::kLik2 : (p->n_layers == 3 ? brie::kLikEff3 : brie::kLikEff2);
     int rc = set_device(h);
@@ -1026,9 +1032,9 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     const size_t mat = static_cast<size_t>(p->Nc) * h->ld;
     const size_t vec = static_cast<size_t>(h->ld);
 #define A(ptr, n)                                            \
-    if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) { brie_destroy(h); return rc; }
+    if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) { drop_failed_create(h); return rc; }
 #define AM(ptr)                                              \
-    if ((rc = alloc_mat(&(ptr), mat, p->device, h->stream)) != BRIE_OK) { brie_destroy(h); return rc; }
+    if ((rc = alloc_mat(&(ptr), mat, p->device, h->stream)) != BRIE_OK) { drop_failed_create(h); return rc; }
     g_blocks.prepare(p->device, mat * sizeof(float));
     for (int l = 0; l < p->n_layers; ++l) AM(h->c[l]);
     AM(h->mu); AM(h->rho); AM(h->m_mu); AM(h->v_mu); AM(h->m_rho); AM(h->v_rho);
@@ -1042,14 +1048,12 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     A(h->gene_active, vec);
     A(h->ring_kl, vec * brie::kLossRing);
     A(h->ring_ll, vec * brie::kLossRing);
-    if (p->Kc > BRIE_MAX_KC && !h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout"); }
     h->cell_mode = p->intercept_mode == 1;
     h->coupled = p->Kg > 0 || h->cell_mode;
     if (h->coupled) {
         const size_t nc = static_cast<size_t>(p->Nc);
         h->gwide = p->Kg > brie::kKgMax;
         h->kgp = h->gwide ? static_cast<int>(round_up(p->Kg, 4)) : brie::kKgMax;
-        if (h->gwide && !h->tiled) { brie_destroy(h); return fail(BRIE_ERR_UNSUPPORTED, "Kg > 4 needs the tiled layout"); }
         A(h->Xg, vec * h->kgp);
         A(h->Wg, nc * h->kgp); A(h->m_Wg, nc * h->kgp); A(h->v_Wg, nc * h->kgp);
         A(h->cb, nc); A(h->m_cb, nc); A(h->v_cb, nc);
@@ -1061,25 +1065,25 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     configure_tiling(h);
     {
         const char *pk = getenv("BRIE_PACK_ACTIVE");
-        h->allow_pack = !(pk && strcmp(pk, "0") == 0) && h->tiled;
+        h->allow_pack = !(pk && strcmp(pk, "0") == 0);
         h->perm.resize(static_cast<size_t>(h->ld / 4));
         for (size_t q = 0; q < h->perm.size(); ++q) h->perm[q] = static_cast<int32_t>(q);
         e = hipMalloc(reinterpret_cast<void **>(&h->quad_ids), h->perm.size() * sizeof(int32_t));
-        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+        if (e != hipSuccess) { drop_failed_create(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
         e = hipMalloc(reinterpret_cast<void **>(&h->block_active), h->gene_blocks * sizeof(int32_t));
-        if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
-        if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { brie_destroy(h); return rc; }
+        if (e != hipSuccess) { drop_failed_create(h); return fail(BRIE_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+        if ((rc = brie_set_gene_mask(h, nullptr)) != BRIE_OK) { drop_failed_create(h); return rc; }
     }
     if (h->coupled) {
         float *rp = nullptr;
         if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * (h->kgp + 2) * p->Nc, h->stream)) != BRIE_OK) {
-            brie_destroy(h);
+            drop_failed_create(h);
             return rc;
         }
         h->row_partials = rp;
     }
     e = hipStreamSynchronize(h->stream);
-    if (e != hipSuccess) { brie_destroy(h); return fail(BRIE_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { drop_failed_create(h); return fail(BRIE_ERR_HIP, "sync: %s", hipGetErrorString(e)); }
     *out = h;
     return BRIE_OK;
 }
@@ -1095,8 +1099,6 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
     if (rc != BRIE_OK) return rc;
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
-    const bool wide = Kc > BRIE_MAX_KC;
-    if (wide && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     const size_t vec = static_cast<size_t>(h->ld);
     float **drop[] = {&h->Xc, &h->W, &h->m_W, &h->v_W, &h->Rbuf, &h->Gpart, &h->Mbuf};
     for (float **q : drop) {
@@ -1282,7 +1284,6 @@ int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t 
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
-    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "sparse upload needs the tiled layout");
     if ((rc = order_after_device_source(data ? static_cast<const void *>(data) : static_cast<const void *>(indptr))) != BRIE_OK)
         return rc;
     if (h->cs != brie::kCountF32 || h->compact_tried) {
@@ -1296,9 +1297,9 @@ int brie_upload_sparse(brie_handle *h, int which, int32_t format, const int64_t 
     int32_t *d_idx = nullptr;
     float *d_val = nullptr;
     auto cleanup = [&]() { hipFree(d_ptr); hipFree(d_idx); hipFree(d_val); };
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_ptr), (n_major + 1) * sizeof(int64_t));
-    if (e == hipSuccess && nnz > 0) e = hipMalloc(reinterpret_cast<void **>(&d_idx), nnz * sizeof(int32_t));
-    if (e == hipSuccess && nnz > 0) e = hipMalloc(reinterpret_cast<void **>(&d_val), nnz * sizeof(float));
+    hipError_t e = dev_alloc(&d_ptr, (n_major + 1) * sizeof(int64_t));
+    if (e == hipSuccess && nnz > 0) e = dev_alloc(&d_idx, nnz * sizeof(int32_t));
+    if (e == hipSuccess && nnz > 0) e = dev_alloc(&d_val, nnz * sizeof(float));
     if (e == hipSuccess) e = hipMemcpyAsync(d_ptr, indptr, (n_major + 1) * sizeof(int64_t), hipMemcpyDefault, h->stream);
     if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_idx, indices, nnz * sizeof(int32_t), hipMemcpyDefault, h->stream);
     if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(d_val, data, nnz * sizeof(float), hipMemcpyDefault, h->stream);
@@ -1541,7 +1542,7 @@ int cell_finalize_blocks(const brie_handle *h) {
 // the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
 int gwide_forward_mean(brie_handle *h, bool accumulate) {
     if (!h->Mbuf) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+        HIP_TRY(dev_alloc(&h->Mbuf, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
     }
     hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Wg,
@@ -1553,7 +1554,7 @@ int gwide_forward_mean(brie_handle *h, bool accumulate) {
 
 int wide_forward_mean(brie_handle *h) {
     if (!h->Mbuf) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->Mbuf), static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
+        HIP_TRY(dev_alloc(&h->Mbuf, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
     }
     hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Xc,
@@ -1561,6 +1562,167 @@ int wide_forward_mean(brie_handle *h) {
                        h->gb_stride, h->rows_per_chunk, 0);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
+}
+
+// ---- placement of the streamed arrays ---------------------------------------------------------------------------------
+// The step kernel of one and the same handle runs at one of two speeds that differ by 10 - 20 % depending on where
+// hipMalloc put its arrays; nothing a user-level program can see predicts it, so it is MEASURED:
+// placement_probe (the step kernel's traffic without arithmetic or effect) is timed on the handle's arrays; while the
+// rate is below `good_gbs` another set is allocated WHILE the current one is still held (other physical pages),
+// filled by device-to-device copies, probed, and the faster set is kept.  A few launches and copies per try.
+int probe_rate(brie_handle *h, int iters, double *gbs) {
+    brie::StepScalars a{};
+    a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
+    a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
+    a.rows_per_chunk = h->rows_per_chunk;
+    a.tt = h->tt;
+    const bool compact = h->cs != brie::kCountF32;
+    const void *c[3];
+    for (int l = 0; l < 3; ++l) c[l] = compact ? static_cast<const void *>(h->cu[l]) : h->c[l];
+    const bool l3 = h->p.n_layers == 3;
+    const dim3 grid(h->gene_blocks, h->n_chunks), block(brie::kBlock);
+    const int pad = 81 * 1024;                      // one workgroup per CU, as the step kernel runs (brie_inst.hip)
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int it = -1; it < iters; ++it) {
+        if (it == 0) (void)hipEventRecord(e0, h->stream);
+#define BRIE_PROBE(CS, L3)                                                                                              \
+    do {                                                                                                               \
+        auto kern = brie::placement_probe<CS, L3>;                                                                      \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pad); \
+        hipLaunchKernelGGL(kern, grid, block, pad, h->stream, c[0], c[1], c[2], h->mu, h->rho, h->m_mu, h->v_mu,       \
+                           h->m_rho, h->v_rho, a, 0u, static_cast<uint32_t *>(nullptr));                               \
+    } while (0)
+#define BRIE_PROBE_CS(CS) do { if (l3) BRIE_PROBE(CS, true); else BRIE_PROBE(CS, false); } while (0)
+        switch (h->cs) {
+            case brie::kCountU8: BRIE_PROBE_CS(brie::kCountU8); break;
+            case brie::kCountU16: BRIE_PROBE_CS(brie::kCountU16); break;
+            case brie::kCountMixed: BRIE_PROBE_CS(brie::kCountMixed); break;
+            default: BRIE_PROBE_CS(brie::kCountF32); break;
+        }
+#undef BRIE_PROBE_CS
+#undef BRIE_PROBE
+    }
+    (void)hipEventRecord(e1, h->stream);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "placement probe: %s", hipGetErrorString(e));
+    *gbs = static_cast<double>(brie_step_storage_bytes(h)) * iters / (static_cast<double>(ms) * 1e-3) / 1e9;
+    return BRIE_OK;
+}
+
+// the arrays a step streams: the six state arrays and the count layers in their current storage
+struct StreamedSet {
+    void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int n = 0;
+};
+StreamedSet streamed_set(brie_handle *h) {
+    StreamedSet s;
+    const size_t mat_bytes = static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float);
+    float *st[6] = {h->mu, h->rho, h->m_mu, h->v_mu, h->m_rho, h->v_rho};
+    for (float *q : st) { s.p[s.n] = q; s.bytes[s.n++] = mat_bytes; }
+    const bool compact = h->cs != brie::kCountF32;
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        s.p[s.n] = compact ? h->cu[l] : static_cast<void *>(h->c[l]);
+        s.bytes[s.n++] = compact ? compact_layer_bytes(h, h->cs) : mat_bytes;
+    }
+    return s;
+}
+void adopt_set(brie_handle *h, const StreamedSet &s) {
+    h->mu = static_cast<float *>(s.p[0]); h->rho = static_cast<float *>(s.p[1]);
+    h->m_mu = static_cast<float *>(s.p[2]); h->v_mu = static_cast<float *>(s.p[3]);
+    h->m_rho = static_cast<float *>(s.p[4]); h->v_rho = static_cast<float *>(s.p[5]);
+    const bool compact = h->cs != brie::kCountF32;
+    for (int l = 0; l < h->p.n_layers; ++l) {
+        if (compact) h->cu[l] = s.p[6 + l];
+        else h->c[l] = static_cast<float *>(s.p[6 + l]);
+    }
+}
+
+// rate a handle of this device has been seen to reach (GB/s of storage bytes): what "fast" means on this box
+std::mutex g_place_mu;
+double g_place_best[64] = {};
+
+int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
+    if (max_tries > 4) max_tries = 4;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    const int iters = 3;
+    double best = 0.0;
+    int rc = probe_rate(h, iters, &best);
+    if (rc != BRIE_OK) return rc;
+    h->placement_tries = 1; h->placement_kept = 0; h->placement_gbs[0] = best;
+    // every set that lost stays allocated until the search is over: a set that is freed is what the next hipMalloc
+    // hands out again (call r4a: three slow sets in a row whenever the loser was freed first)
+    std::vector<StreamedSet> losers;
+    for (int t = 1; t < max_tries && best < good_gbs; ++t) {
+        StreamedSet cur = streamed_set(h), alt;
+        size_t total = 0;
+        for (int i = 0; i < cur.n; ++i) total += cur.bytes[i];
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if (free_b < total + (size_t(2) << 30)) break;             // no room for another set: keep what there is
+        alt.n = cur.n;
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < cur.n && e == hipSuccess; ++i) {
+            alt.bytes[i] = cur.bytes[i];
+            e = hipMalloc(&alt.p[i], cur.bytes[i]);                // plain: the block cache may hold the LAST placement
+            if (e == hipSuccess) e = hipMemcpyAsync(alt.p[i], cur.p[i], cur.bytes[i], hipMemcpyDeviceToDevice, h->stream);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(h->stream);
+            for (int i = 0; i < alt.n; ++i) if (alt.p[i]) (void)hipFree(alt.p[i]);
+            break;
+        }
+        adopt_set(h, alt);
+        double r = 0.0;
+        rc = probe_rate(h, iters, &r);
+        h->placement_gbs[t] = r;
+        h->placement_tries = t + 1;
+        const bool better = rc == BRIE_OK && r > best;
+        if (better) { best = r; h->placement_kept = t; }
+        else adopt_set(h, cur);
+        losers.push_back(better ? cur : alt);
+        if (rc != BRIE_OK) break;
+    }
+    for (const StreamedSet &drop : losers)
+        for (int i = 0; i < drop.n; ++i) (void)hipFree(drop.p[i]);
+    if (rc != BRIE_OK) return rc;
+    {
+        std::lock_guard<std::mutex> l(g_place_mu);
+        const int d = h->p.device & 63;
+        if (best > g_place_best[d]) g_place_best[d] = best;
+    }
+    h->placement_done = true;
+    h->placement_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return BRIE_OK;
+}
+
+// automatic tuning before the first step of a handle whose step streams >= 256 MiB.  BRIE_PLACEMENT_TRIES = n (1 = off,
+// default 3); BRIE_PLACEMENT_GOOD_GBS = the rate at which no further set is tried.  Default 6050: over 26 handles of
+// configs[1] / configs[2] in four processes (profiles/r4a_placement_c{2,3}.jsonl) the probe -- whose rate equals the step
+// kernel's to 1 %, correlation 0.999 at configs[2] -- read 4.93 - 5.30 TB/s in the slow mode, 5.49 - 5.94 in between and
+// 6.0 - 6.24 in the fast one; or 0.97 x the best rate a handle of this process has reached on the device if higher.
+constexpr double kPlacementGoodGBs = 6050.0;
+int auto_placement(brie_handle *h) {
+    if (h->placement_done) return BRIE_OK;
+    h->placement_done = true;
+    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 3; }();
+    if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) return BRIE_OK;
+    static const double good_env = [] { const char *e = getenv("BRIE_PLACEMENT_GOOD_GBS"); return e ? atof(e) : 0.0; }();
+    double good = good_env > 0.0 ? good_env : kPlacementGoodGBs;
+    if (good_env <= 0.0) {
+        std::lock_guard<std::mutex> l(g_place_mu);
+        good = std::max(good, 0.97 * g_place_best[h->p.device & 63]);
+    }
+    return tune_placement(h, tries, good);
 }
 
 // split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell
@@ -1574,18 +1736,18 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if (split == 0 && h->coupled && h->p.sharded != 0 && !lib_reduce)
         return fail(BRIE_ERR_STATE, "this handle is one gene shard of a coupled fit: attach a communicator "
                     "(brie_attach_comm) or use brie_step_begin / all-reduce brie_rowstat_buffer / brie_step_end");
-    if (h->wide_like && !h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "wide designs need the tiled layout");
     if (n_steps == 0) return BRIE_OK;
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = io_wait(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    if ((rc = auto_placement(h)) != BRIE_OK) return rc;
     const size_t lp_need = static_cast<size_t>(n_steps) * h->fin_blocks * 2;
     if (lp_need > h->loss_parts_elems) {
         HIP_TRY(hipStreamSynchronize(h->stream));
         if (h->loss_parts) HIP_TRY(hipFree(h->loss_parts));
         h->loss_parts = nullptr;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->loss_parts), lp_need * sizeof(double)));
+        HIP_TRY(dev_alloc(&h->loss_parts, lp_need * sizeof(double)));
         h->loss_parts_elems = lp_need;
     }
     if (h->profiling) {
@@ -1918,7 +2080,6 @@ namespace {
 // layers are expanded into fp32 temporaries, the prior mean goes through Mbuf.
 int eval_elements(brie_handle *h, int32_t size, int by_draw, float *res_ll, float *res_kl) {
     int rc = BRIE_OK;
-    if (!h->tiled) return fail(BRIE_ERR_UNSUPPORTED, "the per-entry accessors need the tiled layout");
     if ((rc = ensure_identity(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
@@ -1930,7 +2091,7 @@ int eval_elements(brie_handle *h, int32_t size, int by_draw, float *res_ll, floa
     const float *layers[3] = {nullptr, nullptr, nullptr};
     for (int l = 0; l < h->p.n_layers; ++l) {
         if (h->cs == brie::kCountF32) { layers[l] = h->c[l]; continue; }
-        if (hipMalloc(reinterpret_cast<void **>(&tmp[l]), mat * sizeof(float)) != hipSuccess) {
+        if (dev_alloc(&tmp[l], mat * sizeof(float)) != hipSuccess) {
             cleanup();
             return fail(BRIE_ERR_HIP, "hipMalloc count view");
         }
@@ -1976,7 +2137,7 @@ int brie_loglik_mc(brie_handle *h, int32_t size, float *out, int64_t ld) {
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     const int64_t Nc = h->p.Nc, Ng = h->p.Ng;
     float *res = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(Nc) * Ng * sizeof(float)) != hipSuccess)
+    if (dev_alloc(&res, static_cast<size_t>(Nc) * Ng * sizeof(float)) != hipSuccess)
         return fail(BRIE_ERR_HIP, "hipMalloc result");
     rc = eval_elements(h, size, 0, res, nullptr);
     hipError_t e = hipSuccess;
@@ -2005,11 +2166,11 @@ int brie_get_loss(brie_handle *h, int32_t mc_size, int32_t axis, float *out) {
     double *part = nullptr;
     auto cleanup = [&]() { hipFree(ll); hipFree(kl); hipFree(res); hipFree(part); };
     const size_t mat = static_cast<size_t>(Nc) * Ng * sizeof(float);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&ll), mat);
-    if (e == hipSuccess && elbo) e = hipMalloc(reinterpret_cast<void **>(&kl), mat);
+    hipError_t e = dev_alloc(&ll, mat);
+    if (e == hipSuccess && elbo) e = dev_alloc(&kl, mat);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&res), static_cast<size_t>(axis == 0 ? Ng : Nc) * sizeof(float));
     if (e == hipSuccess && axis == 0)
-        e = hipMalloc(reinterpret_cast<void **>(&part), static_cast<size_t>(n_chunks) * 2 * Ng * sizeof(double));
+        e = dev_alloc(&part, static_cast<size_t>(n_chunks) * 2 * Ng * sizeof(double));
     if (e != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "get_loss buffers: %s", hipGetErrorString(e)); }
     // ELBO: KL - mean_k ll(z_k), the samples at consecutive draw ids like brie_loss_gene(mc_size) (the loss is linear in
     // them); marginLik: -log-mean-exp over the samples of ONE draw id, like a step with this MC_size
@@ -2068,7 +2229,7 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         if (h->io_slab) HIP_TRY(hipFree(h->io_slab));
         h->io_slab = nullptr;
         h->io_slab_elems = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->io_slab), need * sizeof(float)));
+        HIP_TRY(dev_alloc(&h->io_slab, need * sizeof(float)));
         h->io_slab_elems = need;
     }
     // the state is final once everything enqueued so far on the main stream has run
@@ -2254,6 +2415,36 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
     return BRIE_OK;
 }
 
+int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs) {
+    if (!h || !gbs || iters < 1) return fail(BRIE_ERR_INVALID, "bad argument");
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = io_wait(h)) != BRIE_OK) return rc;
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    return probe_rate(h, iters, gbs);
+}
+
+int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs) {
+    if (!h || max_tries < 1) return fail(BRIE_ERR_INVALID, "bad argument");
+    int rc = check_ready(h);
+    if (rc != BRIE_OK) return rc;
+    if (h->step_open) return fail(BRIE_ERR_STATE, "a step is open");
+    if ((rc = set_device(h)) != BRIE_OK) return rc;
+    if ((rc = io_wait(h)) != BRIE_OK) return rc;
+    if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
+    return tune_placement(h, max_tries, good_gbs);
+}
+
+int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (tries) *tries = h->placement_tries;
+    if (kept) *kept = h->placement_kept;
+    if (gbs) for (int i = 0; i < 4; ++i) gbs[i] = h->placement_gbs[i];
+    if (seconds) *seconds = h->placement_seconds;
+    return BRIE_OK;
+}
+
 // Measure the HBM rate of `n_read` read streams + `n_write` write streams of `bytes_per_stream`
 // each (no arithmetic) -> GB/s.  Supported mixes: (1,1) copy, (8,6) and (9,6) = elbo_adam_step with
 // 2 / 3 count layers.  `lds_bytes_per_block` > 0 reserves dynamic LDS per 256-thread block to cap the
@@ -2273,7 +2464,7 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     const char *ct = getenv("BRIE_CALIB_CONTIGUOUS");          // "1": physically contiguous buffers
     auto alloc = [&](void **q, size_t bytes) {
         if (ct && ct[0] == '1') return hipExtMallocWithFlags(q, bytes, hipDeviceMallocContiguous);
-        return hipMalloc(q, bytes);
+        return dev_alloc(q, bytes);
     };
     if (il && il[0] == '1') {
         a.n4 = (a.n4 / 64) * 64;
@@ -2344,7 +2535,7 @@ struct SlabBuffers {
     ~SlabBuffers() { for (void *q : bufs) hipFree(q); }
     float *get(size_t elems) {
         void *q = nullptr;
-        if (elems == 0 || hipMalloc(&q, elems * sizeof(float)) != hipSuccess) return nullptr;
+        if (elems == 0 || dev_alloc(&q, elems * sizeof(float)) != hipSuccess) return nullptr;
         bufs.push_back(q);
         return static_cast<float *>(q);
     }

@@ -8,8 +8,7 @@
 // a workgroup walks one contiguous piece of every array, and every per-gene statistic is a
 // private per-lane register accumulation over cells -- no cross-lane traffic in the streaming
 // loop.  The four waves of a workgroup interleave the rows of one cell chunk and fold their
-// per-gene partials through LDS once per chunk.  (BRIE_LAYOUT=rowmajor keeps the reference's
-// C-order (Nc, ld) arrays instead: same kernels, different strides; A/B experiments only.)
+// per-gene partials through LDS once per chunk.
 //
 // Reference semantics restated per kernel (paths relative to /root/reference):
 //   elbo_adam_step   brie/models/model_TFProb.py:118-127 (Z_prior), 130-191
@@ -41,10 +40,6 @@ constexpr uint32_t kInitDraw = 0xFFFFFFFFu;
 // minimum waves per SIMD requested from the register allocator for the streaming kernels
 #ifndef BRIE_MIN_WAVES
 #define BRIE_MIN_WAVES 1
-#endif
-// 1: issue the next row's loads before computing the current row (register double buffer)
-#ifndef BRIE_PREFETCH
-#define BRIE_PREFETCH 1
 #endif
 
 // ----------------------------------------------------------------------------
@@ -82,11 +77,7 @@ __device__ __forceinline__ float u01_fma(uint32_t x) {
 
 template <bool LEAN = false>
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &n0, float &n1) {
-#ifdef BRIE_LG_ROUND2
-    const float ua = u01(xa), ub = u01(xb);
-#else
     const float ua = LEAN ? u01_fma(xa) : u01(xa), ub = LEAN ? u01_fma(xb) : u01(xb);
-#endif
 #if BRIE_FAST_MATH
     const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(ua));
     n0 = r * __builtin_amdgcn_cosf(ub);      // v_cos_f32 takes revolutions: cos(2 pi ub)
@@ -156,9 +147,7 @@ __device__ __forceinline__ float f_log1p(float x) {
     // and without the two-sided branch the four elements of a lane are one basic block again, which is what lets the
     // compiler pair their arithmetic into v_pk_* instructions (the branchy form compiled to 4 x s_and_saveexec ... s_or
     // per draw and no packed math at all).
-#ifndef BRIE_LG_ROUND2      // -DBRIE_LG_ROUND2=1: the forward passes exactly as round 2 built them (A/B runs)
     if constexpr (LEAN) return f_log_sel<true>(1.0f + x);
-#endif
     return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<LEAN>(1.0f + x);
 #else
     return log1pf(x);
@@ -270,14 +259,6 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
 // Forward-only log-likelihood of TWO elements at once (2-category mode, the forward passes): the same operations as
 // loglik<kLik2, true> per element, written on 2-vectors so that every fp32 add / mul / fma is ONE v_pk_* instruction
 // for the pair (gfx950 issues packed fp32 at the scalar rate); the transcendentals stay per element.
-// BRIE_LG_PACKED=0 compiles the per-element form instead (A/B runs).
-#ifndef BRIE_LG_PACKED
-#ifdef BRIE_LG_ROUND2
-#define BRIE_LG_PACKED 0
-#else
-#define BRIE_LG_PACKED 1
-#endif
-#endif
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx2 loglik2_pair(floatx2 z, floatx2 c1, floatx2 c2) {
 #if BRIE_FAST_MATH
@@ -951,31 +932,6 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
         float xc[KCX];
         RowScalars rsc{};
         load_row(r, cur, xc, rsc);
-#if BRIE_PREFETCH == 2
-        // Two rows ahead: the loads of row r + 8 are issued before the body of row r (tuning build; meant for one
-        // workgroup per CU, where the register file has room for three rows per wave).  Branch-free body as below; a
-        // row index past the wave's last row re-reads that last row (an L2 hit) and is dropped.
-        {
-            RowRegs<CS> n1;
-            float x1[KCX];
-            RowScalars rs1{};
-            load_row(min(r + kWavesPerBlock, r_last), n1, x1, rs1);
-            while (r + kWavesPerBlock < r_last) {            // at least two rows after r
-                RowRegs<CS> n2;
-                float x2[KCX];
-                RowScalars rs2{};
-                load_row(min(r + 2 * kWavesPerBlock, r_last), n2, x2, rs2);
-                process_row(r, cur, xc, rsc);
-                cur = n1; rsc = rs1;
-                n1 = n2; rs1 = rs2;
-#pragma unroll
-                for (int k = 0; k < KC; ++k) { xc[k] = x1[k]; x1[k] = x2[k]; }
-                r += kWavesPerBlock;
-            }
-            process_row(r, cur, xc, rsc);
-            if (r < r_last) process_row(r + kWavesPerBlock, n1, x1, rs1);
-        }
-#elif BRIE_PREFETCH
         // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
         // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
         // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body
@@ -993,14 +949,6 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             r += kWavesPerBlock;
         }
         process_row(r, cur, xc, rsc);
-#else
-        for (;;) {
-            process_row(r, cur, xc, rsc);
-            if (r >= r_last) break;
-            r += kWavesPerBlock;
-            load_row(r, cur, xc, rsc);
-        }
-#endif
     }
 
     // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row
@@ -1170,7 +1118,7 @@ __global__ __launch_bounds__(kBlock) void loss_gene_eval(const LossGeneArgs a) {
                 float e[kVec];
                 normal4<true>(gquad, static_cast<uint32_t>(r), a.draw0 + static_cast<uint32_t>(rep), 0u,
                               a.seed_lo, a.seed_hi, e);
-                if constexpr (MODE == kLik2 && BRIE_LG_PACKED) {
+                if constexpr (MODE == kLik2) {
 #pragma unroll
                     for (int p = 0; p < kVec; p += 2) {
                         const floatx2 z = __builtin_elementwise_fma(floatx2{s[p], s[p + 1]}, floatx2{e[p], e[p + 1]},
@@ -1682,8 +1630,8 @@ __global__ void ingest_slab(const void *slab, int is_f32, float *dst, int r0, in
 }
 
 // flag[gene quad]: bit 0: some value is not an integer in [0, 65535]; bit 1: some value exceeds 255; bit 2: some
-// value is negative / NaN / inf.  Nc_tiled = Nc for the tiled layer, 0 (one flag word) for the row-major layout.
-__global__ void count_range_check(const float *c, int64_t n4, int Nc_tiled, int *flag) {
+// value is negative / NaN / inf.
+__global__ void count_range_check(const float *c, int64_t n4, int Nc, int *flag) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n4;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const F4 a = ld4(c + 4 * i);
@@ -1694,8 +1642,8 @@ __global__ void count_range_check(const float *c, int64_t n4, int Nc_tiled, int 
             bad |= (a.v[v] > 255.0f) ? 2 : 0;
             bad |= !(a.v[v] >= 0.0f && a.v[v] < __builtin_inff()) ? 4 : 0;      // negative, NaN or inf: not a count
         }
-        if (bad) {       // tiled: one flag word per gene quad, i == (gene block * Nc + cell) * 64 + lane
-            int *f = flag + (Nc_tiled ? i / (static_cast<int64_t>(Nc_tiled) * kWave) * kWave + i % kWave : 0);
+        if (bad) {       // one flag word per gene quad, i == (gene block * Nc + cell) * 64 + lane
+            int *f = flag + i / (static_cast<int64_t>(Nc) * kWave) * kWave + i % kWave;
             if ((__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bad) != bad) atomicOr(f, bad);
         }
     }
@@ -2232,5 +2180,68 @@ __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
         }
     }
 }
+
+#ifdef BRIE_HOST_TU
+// ----------------------------------------------------------------------------
+// placement_probe: elbo_adam_step's HBM traffic -- the same grid, the same rows per wave, the same loads one row
+// ahead, the same non-temporal 16-B stores -- with no arithmetic and NO EFFECT: every state vector is written back
+// as the bits that were read (xor with a kernel argument that is zero, so the stores cannot be folded away), the
+// counts are only read.  It can therefore run on the live arrays of a handle at any time.  How fast a set of arrays
+// streams depends on where hipMalloc placed it (the same kernel on the same data runs at 8.1 or at
+// 9.4 ms per step at configs[2] depending on the allocation); brie_placement_tune times this kernel on the handle's
+// arrays and on a second / third set and keeps the fastest.
+// ----------------------------------------------------------------------------
+typedef unsigned int uintx4 __attribute__((ext_vector_type(4)));
+template <int CS, bool L3>
+__global__ __launch_bounds__(kBlock) void placement_probe(
+    const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
+    float *__restrict__ s0, float *__restrict__ s1, float *__restrict__ s2, float *__restrict__ s3,
+    float *__restrict__ s4, float *__restrict__ s5, const StepScalars a, const uint32_t zero, uint32_t *sink) {
+    extern __shared__ float probe_pad[];            // occupancy pad only (one workgroup per CU, like the step kernel)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gb = static_cast<int>(blockIdx.x);
+    const int quad = gb * kWave + lane;
+    const int row0 = blockIdx.y * a.rows_per_chunk;
+    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
+    if (quad * kVec >= a.Ng || row0 + w >= row_end) return;
+    const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
+    const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
+    const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad] : mbase;
+    const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
+    constexpr int MODE = L3 ? kLikEff3 : kLik2;
+    float *const st[6] = {s0, s1, s2, s3, s4, s5};
+    struct Row { CountRegs<CS> cnt; uintx4 v[6]; };
+    auto load = [&](int r, Row &R) {
+        load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
+        const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) R.v[i] = __builtin_nontemporal_load(reinterpret_cast<const uintx4 *>(st[i] + off));
+    };
+    uint32_t fold = 0;
+    auto store = [&](int r, Row &R) {
+        F4 c1, c2, c3;
+        decode_counts<CS>(R.cnt, 0.0f, c1, c2, c3);
+        fold ^= __builtin_bit_cast(uint32_t, c1.v[0] + c2.v[1] + c3.v[2]);
+        const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            __builtin_nontemporal_store(R.v[i] ^ zero, reinterpret_cast<uintx4 *>(st[i] + off));
+    };
+    int r = row0 + w;
+    const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
+    Row cur;
+    load(r, cur);
+    while (r < r_last) {
+        Row nxt;
+        load(r + kWavesPerBlock, nxt);
+        store(r, cur);
+        cur = nxt;
+        r += kWavesPerBlock;
+    }
+    store(r, cur);
+    if (zero != 0u) sink[0] = fold;                 // never taken; keeps the count loads alive
+}
+#endif  // BRIE_HOST_TU
 
 }  // namespace brie

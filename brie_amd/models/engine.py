@@ -51,6 +51,7 @@ def _dense_f32(x):
     if hasattr(x, "tocsc") or hasattr(x, "data_ptr"):
         return x
     if (isinstance(x, np.ndarray) and x.ndim == 2 and x.dtype.name in _capi.TYPED_DTYPES and x.size
+            and x.dtype.isnative and x.flags.aligned
             and x.strides[1] == x.itemsize and x.strides[0] % x.itemsize == 0 and x.strides[0] >= x.shape[1] * x.itemsize):
         return x                  # integer / float64 layers (row views included) go up as they are: brie_upload_typed
     return np.ascontiguousarray(x, dtype=np.float32)
@@ -472,6 +473,8 @@ class BRIE2(object):
         if loss_gene_draw is not None:       # evaluate the final loss on a FIXED stretch of the noise stream (common
             sh.draw = int(loss_gene_draw)    # random numbers across the models of one LRT, see fit_BRIE_matrix)
         tm = self.timing = {"optimise_s": time.time() - start_time, "of_which_upload_s": upload_s, "stage_s": stage_s}
+        if hasattr(sh, "placement_info"):    # which of the probed placements of the streamed arrays the steps ran on, and
+            tm["placement"] = sh.placement_info()      # what the search cost (inside stage_s[0]; include/brie_amd.h)
         tm.update(getattr(self, "_ingest_timing", None) or {})
         self._ingest_timing = None
         t0 = time.time()

@@ -57,10 +57,27 @@ class GeneComm(object):
         if self.backend != "nccl":
             return None
         from . import _capi
-        box = [_capi.Comm.unique_id() if self.rank == 0 else None]
+        # Every rank takes the same steps whatever happens on it: the id travels, each rank tries to build its
+        # communicator, and the ranks then AGREE (an all-reduce over torch.distributed) that all of them succeeded --
+        # one rank falling back to the torch path alone would leave the others waiting in a collective for ever.
+        ok, self.native_error = 1.0, None
+        try:
+            box = [_capi.Comm.unique_id() if self.rank == 0 else None]
+        except Exception as exc:             # librccl not loadable on rank 0: the others still need the broadcast
+            box, ok, self.native_error = [None], 0.0, repr(exc)
         self.dist.broadcast_object_list(box, src=0, group=self.group)
-        dev = device if device is not None else (self.device.index if hasattr(self.device, "index") else self.device)
-        self._native = _capi.Comm(int(dev or 0), self.rank, self.world, box[0])
+        if ok and box[0] is not None:
+            try:
+                dev = device if device is not None else (self.device.index if hasattr(self.device, "index") else self.device)
+                self._native = _capi.Comm(int(dev or 0), self.rank, self.world, box[0])
+            except Exception as exc:
+                ok, self.native_error = 0.0, repr(exc)
+        else:
+            ok = 0.0
+        if float(self.allreduce_min([ok])[0]) < 1.0:
+            if self._native is not None:
+                self._native.close()
+            self._native = None
         return self._native
 
     def _tensor(self, a, dtype=None):
@@ -94,10 +111,13 @@ class GeneComm(object):
         (default: gene_shard with quad alignment).
 
         The end-of-fit gather of a gene-sharded fit (BASELINE's "RCCL weight all-gather"; replaces the `concate` of
-        model_wrap.py:260).  native=None: through the library's own communicator (`brie_comm_allgather`: librccl
-        called from libbrie_amd.so) whenever it exists, i.e. when the process group runs on RCCL; torch.distributed
-        otherwise (gloo: CPU tests, two ranks sharing a GPU).  native=False forces the torch path, True demands the
-        library's."""
+        model_wrap.py:260).  native=None: over torch.distributed -- RCCL when the process group's backend is nccl, gloo
+        in the CPU tests -- unless BRIE_NATIVE_GATHER=1 asks for the library's own communicator (`brie_comm_allgather`:
+        librccl called from libbrie_amd.so) or the group has ONE rank (the only world in which that path has run on the
+        build's 1-GPU boxes).  A fit of hours must not be lost at its last step to a collective nobody has ever seen
+        complete between two GPUs: the native path is opt-in until it has, and when asked for it is only taken if EVERY
+        rank could build its communicator (native_comm agrees across ranks).  native=False forces the torch path, True
+        demands the library's."""
         import torch
         local = np.asarray(local, np.float32)
         if local.ndim == 1:
@@ -106,7 +126,9 @@ class GeneComm(object):
         per = max(b - a for a, b in ranges)
         buf = np.zeros((local.shape[0], per), np.float32)
         buf[:, :local.shape[1]] = local
-        nat = self.native_comm() if native in (None, True) else None
+        import os
+        want = native is True or (native is None and (self.world == 1 or os.environ.get("BRIE_NATIVE_GATHER") == "1"))
+        nat = self.native_comm() if want else None
         if native is True and nat is None:
             raise RuntimeError("no native communicator: the process group runs on %s, not on RCCL" % self.backend)
         self.last_gather_path = "brie_comm_allgather" if nat is not None else "torch.distributed"

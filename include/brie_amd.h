@@ -299,6 +299,25 @@ int brie_get_count_storage(const brie_handle *h);
 int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64_t bytes_per_stream,
                           int32_t iters, int32_t lds_bytes_per_block, double *gbps);
 
+/* Placement of the streamed arrays (no reference counterpart; the reference leaves memory to TensorFlow).  How fast a
+ * handle's step kernel streams depends on where the allocator put its arrays: byte-identical code on identical data runs
+ * at one of two speeds 10 - 20 % apart.  The library therefore measures: a probe kernel with the
+ * step kernel's traffic and no effect on the data is timed on the handle's arrays; while its rate (GB/s of
+ * brie_step_storage_bytes) is below `good_gbs` and HBM has room, a further set of arrays is allocated while the current
+ * one is still held, filled by device-to-device copies, probed, and the faster set is kept (results are bit-identical:
+ * only addresses change; sets that lost are freed when the search is over).  brie_step does this by itself before the
+ * first step of a handle that streams >= 256 MiB per step: up to BRIE_PLACEMENT_TRIES sets (default 3; 1 = off), good_gbs
+ * = BRIE_PLACEMENT_GOOD_GBS (default 6050, or 0.97 x the best rate a handle of this process has reached on the device
+ * when that is higher).  Typical cost at configs[2]: 0.13 s per extra set (26 GB allocated and copied), 3 s when the
+ * allocator has a slow moment.
+ *  brie_placement_probe: rate of the probe on the arrays as they are (iters timed launches after one warm-up).
+ *  brie_placement_tune : the procedure above on demand, at most max_tries <= 4 sets.
+ *  brie_placement_info : sets probed so far, which one is in use (0 = the original), their rates (gbs[4]) and the
+ *                        seconds spent probing, allocating and copying; any pointer may be NULL. */
+int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs);
+int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs);
+int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds);
+
 /* Free / total HBM of a device in bytes (hipMemGetInfo).  fitBRIE uses it to split a gene range that does not
  * fit into sequential super-batches -- the role of the reference's batch_size (model_wrap.py:241-260), sized for
  * 288 GB instead of for 500k elements. */
@@ -306,9 +325,12 @@ int brie_device_memory(int32_t device, int64_t *free_bytes, int64_t *total_bytes
 
 /* brie_destroy keeps the cell x gene arrays of the handle (>= 256 MB each) for the next handle of the SAME size on the
  * same device -- sequential fits of one size (the super-batches above, one fit after another in a service) otherwise
- * pay hipFree + hipMalloc of tens of GB again, which is milliseconds on a good day and seconds on a bad one.  One
- * generation only: a handle of another size, brie_device_memory, an allocation failure inside the library and this
- * call release them.  BRIE_DEVICE_CACHE=0 switches the cache off. */
+ * pay hipFree + hipMalloc of tens of GB again, which is milliseconds on a good day and seconds on a bad one -- and a
+ * placement that brie_placement_tune found fast stays in use.  One generation only: a handle of another size,
+ * brie_device_memory, a failed brie_create and this call release them, and every large allocation of the library that
+ * fails is tried once more after releasing them.  (The fp32 count layers a LIVE handle gives up when it compacts its
+ * counts are freed, not cached.)  The cache belongs to the process: another process on the same GPU cannot reclaim it.
+ * BRIE_DEVICE_CACHE=0 switches the cache off. */
 int brie_trim_memory(void);
 
 /* Count simulator -- brie/models/simulator.py:7-75.  Stateless; every array is C-order (Nc, Ng) fp32 in host or

@@ -11,6 +11,14 @@
  * Build: gcc -O3 -fopenmp -shared -fPIC oracle/brie_oracle.c -o oracle/_build/libbrie_oracle.so -lm
  *        (+ -DBRIE_ORACLE_F64 -o .../libbrie_oracle_f64.so: the same code with every fp32 quantity held in
  *         double -- the precision-independent answer the fp32 results are measured against)
+ *        (+ -DBRIE_ORACLE_B -ffp-contract=fast [-mfma] -o .../libbrie_oracle_b.so: "o32b", a SECOND fp32 evaluation of the
+ *         same algorithm that differs from the first the way any other fp32 implementation legitimately may -- the
+ *         noise stream's Box-Muller evaluated in float (logf / sqrtf / cosf / sinf of the float-rounded angle: within
+ *         2e-6 of the fp64-rounded value, the tolerance tests/test_gpu_parity.py grants the device), the cells of a
+ *         thread walked in REVERSE order with the per-gene sums formed in fp32 over 64 cells at a time before they
+ *         enter the fp64 totals (the HIP kernels form fp32 partial sums per lane and chunk), and the compiler free to
+ *         contract a * b + c into fused multiply-adds.  o32b-vs-o32 is the null distribution the HIP-vs-o32
+ *         differences are held against: tests/util.py::psi_null_rule, profiles/psi_null.py)
  * Nothing in brie_amd/ may link or load this file.
  */
 #include <math.h>
@@ -62,9 +70,16 @@ static void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uin
     uint32_t c[4] = {quad, cell, draw, k};
     philox4x32_10(c, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
     for (int p = 0; p < 2; ++p) {
+#ifdef BRIE_ORACLE_B     /* Box-Muller in float: the uniforms are exact in fp32, everything after them rounds in fp32 */
+        const float ua = ((float)(c[2 * p] >> 9) + 0.5f) * 0x1p-23f, ub = ((float)(c[2 * p + 1] >> 9) + 0.5f) * 0x1p-23f;
+        const float r = sqrtf(-2.0f * logf(ua)), th = 6.283185307179586f * ub;
+        e[2 * p] = (real)(r * cosf(th));
+        e[2 * p + 1] = (real)(r * sinf(th));
+#else
         const double r = sqrt(-2.0 * log(u01(c[2 * p]))), th = 6.283185307179586476925 * u01(c[2 * p + 1]);
         e[2 * p] = (real)(float)(r * cos(th));
         e[2 * p + 1] = (real)(float)(r * sin(th));
+#endif
     }
 }
 
@@ -102,6 +117,10 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
 #endif
     double *acc = (double *)malloc(sizeof(double) * (size_t)nthreads * S * Ng);
     real *lL = (real *)malloc(sizeof(real) * 3 * (size_t)Ng);
+#ifdef BRIE_ORACLE_B
+    float *accf = (float *)malloc(sizeof(float) * (size_t)nthreads * S * Ng);     /* fp32 sums of <= 64 cells */
+    if (!accf) return -1;
+#endif
     if (!acc || !lL) return -1;
     if (p->has_efflen)
         for (int j = 0; j < Ng; ++j) {
@@ -118,9 +137,21 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
 #ifdef _OPENMP
             tid = omp_get_thread_num();
 #endif
+#ifdef BRIE_ORACLE_B
+            double *a64 = acc + (size_t)tid * S * Ng;
+            float *a = accf + (size_t)tid * S * Ng;
+            memset(a, 0, sizeof(float) * (size_t)S * Ng);
+            int in_chunk = 0;
+#else
             double *a = acc + (size_t)tid * S * Ng;
+#endif
 #pragma omp for schedule(static)
-            for (int i = 0; i < Nc; ++i) {
+            for (int ii = 0; ii < Nc; ++ii) {
+#ifdef BRIE_ORACLE_B
+                const int i = Nc - 1 - ii;                 /* the thread's cells in reverse order */
+#else
+                const int i = ii;
+#endif
                 const real *x = Xc + (size_t)i * Kc;
                 for (int j0 = 0; j0 < Ng; j0 += 4) {
                     real eps[8][4];                        /* up to 8 MC samples */
@@ -153,7 +184,7 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                             ll += l; gbar += g; gse += g * s * eps[k][v];
                         }
                         ll /= (real)p->mc; gbar /= (real)p->mc; gse /= (real)p->mc;
-                        for (int k = 0; k < Kc; ++k) a[(size_t)k * Ng + j] += (double)(x[k] * rr);
+                        for (int k = 0; k < Kc; ++k) a[(size_t)k * Ng + j] += x[k] * rr;
                         a[(size_t)(Kc + 0) * Ng + j] += rr;
                         a[(size_t)(Kc + 1) * Ng + j] += RC(1) - d * d * isig2 - s2r;
                         a[(size_t)(Kc + 2) * Ng + j] += kl;
@@ -162,7 +193,16 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                         adam(&Z_std_log[o], &m_rho[o], &v_rho[o], s2r - RC(1) - gse, alpha, 0);
                     }
                 }
+#ifdef BRIE_ORACLE_B
+                if (++in_chunk == 64) {
+                    for (size_t q = 0; q < (size_t)S * Ng; ++q) { a64[q] += (double)a[q]; a[q] = 0.0f; }
+                    in_chunk = 0;
+                }
+#endif
             }
+#ifdef BRIE_ORACLE_B
+            for (size_t q = 0; q < (size_t)S * Ng; ++q) a64[q] += (double)a[q];
+#endif
         }
         double loss_kl = 0.0, loss_ll = 0.0;
         for (int j = 0; j < Ng; ++j) {
@@ -179,7 +219,17 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
         if (trace) trace[step] = (real)(loss_kl - loss_ll);
     }
     free(acc); free(lL);
+#ifdef BRIE_ORACLE_B
+    free(accf);
+#endif
     return 0;
+}
+
+/* the noise stream of this build, for tests: out[4] = eps of gene quad `quad`, cell `cell` at (draw, k) as float */
+void brie_oracle_normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uint64_t seed, float *out) {
+    real e[4];
+    normal4(quad, cell, draw, k, seed, e);
+    for (int v = 0; v < 4; ++v) out[v] = (float)e[v];
 }
 
 int brie_oracle_real_bytes(void) { return (int)sizeof(real); }

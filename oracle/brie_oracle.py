@@ -51,8 +51,17 @@ class OracleBRIE2(object):
     """Restatement of `BRIE2` (ref:35-273): gene or cell intercept mode, cell and gene features."""
 
     def __init__(self, Nc, Ng, Kc=0, effLen=None, intercept=None, sigma=None,
-                 seed=0, gene_offset=0, dtype=np.float32, init=None, Kg=0, intercept_mode='gene'):
+                 seed=0, gene_offset=0, dtype=np.float32, init=None, Kg=0, intercept_mode='gene', variant_b=False):
         self.Nc, self.Ng, self.Kc, self.Kg = int(Nc), int(Ng), int(Kc), int(Kg)
+        # variant_b: a SECOND evaluation of the same algorithm in the same precision that differs the way another
+        # implementation legitimately may -- Box-Muller evaluated in float32 (within 2e-6 of the fp64-rounded stream) and
+        # every reduction over cells / genes taken over the REVERSED axis (other association of the fp32 sums).  The
+        # null the HIP path's differences to the fp32 oracle are held against for the model variants the C restatement
+        # does not cover (tests/test_gpu_parity.py::test_psi_after_full_default_schedule_model_variants).
+        # variant_b = True / 1: both differences; 2: the float32 Box-Muller only; 3: the reversed reductions only (three
+        # members of the family "another fp32 evaluation", for a spread instead of a single draw)
+        self.variant_b = int(variant_b)
+        self._b_noise, self._b_sums = self.variant_b in (1, 2), self.variant_b in (1, 3)
         self.cell_mode = str(intercept_mode).upper() == 'CELL'          # ref:53-60
         self.par_shape = (self.Nc, 1) if self.cell_mode else (1, self.Ng)
         self.Xg = None
@@ -141,10 +150,24 @@ class OracleBRIE2(object):
     # ------------------------------------------------------------- noise
     def noise(self, MC_size):
         """eps (MC, Nc, Ng) for the current draw id; advances the draw counter."""
-        e = np.stack([philox.normal(self.seed, self.draw, k, self.Nc, self.Ng, self.gene_offset)
+        e = np.stack([philox.normal(self.seed, self.draw, k, self.Nc, self.Ng, self.gene_offset,
+                                    float_box_muller=self._b_noise)
                       for k in range(MC_size)], axis=0)
         self.draw += 1
         return e.astype(self.dtype)
+
+    # ------------------------------------------------------------- reductions
+    def _sum(self, x, axis):
+        """x.sum(axis, keepdims=True); variant_b sums the reversed axis."""
+        if self._b_sums:
+            x = np.ascontiguousarray(np.flip(x, axis=axis))
+        return x.sum(axis=axis, keepdims=True)
+
+    def _mm(self, a, b):
+        """a @ b; variant_b contracts in reversed order."""
+        if self._b_sums:
+            return np.matmul(np.ascontiguousarray(a[:, ::-1]), np.ascontiguousarray(b[::-1]))
+        return np.matmul(a, b)
 
     # ------------------------------------------------------------- loss
     def loglik_terms(self, counts, z):
@@ -204,12 +227,12 @@ class OracleBRIE2(object):
         q = (w * g_k).sum(axis=0)                                  # dL/dm = -q
         qe = (w * g_k * eps).sum(axis=0) * sig                     # dL/dlog(sigma) = -qe
         if self.Kc > 0:
-            out['Wc_loc'] = -np.matmul(np.asarray(Xc, dt).T, q)
+            out['Wc_loc'] = -self._mm(np.asarray(Xc, dt).T, q)
         if self.Kg > 0:
-            out['Wg_loc'] = -np.matmul(q, np.asarray(self.Xg, dt))
+            out['Wg_loc'] = -self._mm(q, np.asarray(self.Xg, dt))
         ax = 1 if self.cell_mode else 0
-        out['intercept'] = -q.sum(axis=ax, keepdims=True)
-        out['sigma_log'] = -qe.sum(axis=ax, keepdims=True)
+        out['intercept'] = -self._sum(q, ax)
+        out['sigma_log'] = -self._sum(qe, ax)
         return out
 
     def loss_and_grads(self, counts, Xc, MC_size=1, eps=None, need_grads=True):
@@ -253,12 +276,12 @@ class OracleBRIE2(object):
         out['Z_loc'] = r - gbar
         out['Z_std_log'] = s2 - 1 - gse
         if self.Kc > 0:
-            out['Wc_loc'] = -np.matmul(np.asarray(Xc, dt).T, r)
+            out['Wc_loc'] = -self._mm(np.asarray(Xc, dt).T, r)
         if self.Kg > 0:
-            out['Wg_loc'] = -np.matmul(r, np.asarray(self.Xg, dt))
+            out['Wg_loc'] = -self._mm(r, np.asarray(self.Xg, dt))
         ax = 1 if self.cell_mode else 0                     # (Nc,1) parameters sum over genes, (1,Ng) over cells
-        out['intercept'] = -r.sum(axis=ax, keepdims=True)
-        out['sigma_log'] = (1 - d * d * inv_sig2 - s2).sum(axis=ax, keepdims=True)
+        out['intercept'] = -self._sum(r, ax)
+        out['sigma_log'] = self._sum(1 - d * d * inv_sig2 - s2, ax)
         return out
 
     # ------------------------------------------------------------- Adam

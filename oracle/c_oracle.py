@@ -9,17 +9,33 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "brie_oracle.c")
 LIB = os.path.join(HERE, "_build", "libbrie_oracle.so")
 LIB_F64 = os.path.join(HERE, "_build", "libbrie_oracle_f64.so")
+LIB_B = os.path.join(HERE, "_build", "libbrie_oracle_b.so")
 
 
-def build(force=False, f64=False):
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            return " fma " in fh.read().replace("\n", " ")
+    except OSError:
+        return False
+
+
+def build(force=False, f64=False, variant_b=False):
     """gcc -O3 -fopenmp -> oracle/_build/libbrie_oracle.so (fp32, the reference's precision) or, with f64=True,
     libbrie_oracle_f64.so (the same code with every quantity in double).  -ffp-contract=off: no fused
-    multiply-adds, so the fp32 build rounds after every operation like the eager reference does."""
-    lib = LIB_F64 if f64 else LIB
+    multiply-adds, so the fp32 build rounds after every operation like the eager reference does.
+    variant_b=True: libbrie_oracle_b.so, "o32b" -- a second fp32 evaluation (float Box-Muller, reversed cell order with
+    fp32 partial sums, -ffp-contract=fast and FMA instructions where the host has them; see the header of brie_oracle.c)."""
+    assert not (f64 and variant_b)
+    lib = LIB_B if variant_b else (LIB_F64 if f64 else LIB)
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(SRC):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
-        subprocess.run(["gcc", "-O3", "-ffp-contract=off", "-fopenmp", "-shared", "-fPIC"] +
-                       (["-DBRIE_ORACLE_F64"] if f64 else []) + [SRC, "-o", lib, "-lm"], check=True)
+        flags = ["-DBRIE_ORACLE_F64"] if f64 else []
+        if variant_b:
+            flags = ["-DBRIE_ORACLE_B", "-ffp-contract=fast"] + (["-mfma"] if _cpu_has_fma() else [])
+        else:
+            flags = ["-ffp-contract=off"] + flags
+        subprocess.run(["gcc", "-O3"] + flags + ["-fopenmp", "-shared", "-fPIC", SRC, "-o", lib, "-lm"], check=True)
     return lib
 
 
@@ -33,10 +49,10 @@ class COracle(object):
     """State + optimiser slots as float32 arrays, stepped by the C kernel; mirrors OracleBRIE2's fields."""
 
     def __init__(self, counts, Xc, effLen=None, seed=0, gene_offset=0, intercept=None, sigma=None, init=None,
-                 dtype=np.float32):
+                 dtype=np.float32, variant_b=False):
         from .brie_oracle import OracleBRIE2
         self.dtype = np.dtype(dtype)
-        self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64))
+        self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64, variant_b=variant_b))
         assert self.lib.brie_oracle_real_bytes() == self.dtype.itemsize
         dt = self.dtype
         self.counts = [np.ascontiguousarray(c, dt) for c in counts]

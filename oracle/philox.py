@@ -64,8 +64,10 @@ def _u01(x):
     return ((x >> np.uint32(9)).astype(np.float64) + 0.5) * (2.0 ** -23)
 
 
-def normal_quads(seed, draw, k, cells, quads):
-    """eps for all `cells` x gene quads `quads` -> float32 (len(cells), len(quads), 4)."""
+def normal_quads(seed, draw, k, cells, quads, float_box_muller=False):
+    """eps for all `cells` x gene quads `quads` -> float32 (len(cells), len(quads), 4).
+    float_box_muller: log / sqrt / cos / sin evaluated in float32 on the (exact) float32 uniforms instead of in float64
+    and rounded once -- what another fp32 implementation of the stream does (within 2e-6 of the defined values)."""
     cells = np.asarray(cells, dtype=np.uint64).reshape(-1, 1)
     quads = np.asarray(quads, dtype=np.uint64).reshape(1, -1)
     seed = int(seed)
@@ -73,6 +75,13 @@ def normal_quads(seed, draw, k, cells, quads):
                                    seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     out = np.empty(x0.shape + (4,), dtype=np.float32)
     for p, (xa, xb) in enumerate(((x0, x1), (x2, x3))):
+        if float_box_muller:
+            ua, ub = _u01(xa).astype(np.float32), _u01(xb).astype(np.float32)
+            r = np.sqrt(np.float32(-2.0) * np.log(ua))
+            th = np.float32(6.283185307179586) * ub
+            out[..., 2 * p] = r * np.cos(th)
+            out[..., 2 * p + 1] = r * np.sin(th)
+            continue
         r = np.sqrt(-2.0 * np.log(_u01(xa)))
         th = 2.0 * np.pi * _u01(xb)
         out[..., 2 * p] = (r * np.cos(th)).astype(np.float32)
@@ -80,12 +89,12 @@ def normal_quads(seed, draw, k, cells, quads):
     return out
 
 
-def normal(seed, draw, k, n_cells, n_genes, gene_offset=0, cell_offset=0):
+def normal(seed, draw, k, n_cells, n_genes, gene_offset=0, cell_offset=0, float_box_muller=False):
     """eps[(cell_offset..+n_cells), (gene_offset..+n_genes)] as float32 (n_cells, n_genes)."""
     g0 = int(gene_offset)
     g1 = g0 + int(n_genes)
     q0, q1 = g0 // 4, (g1 + 3) // 4
     cells = np.arange(cell_offset, cell_offset + n_cells)
-    e = normal_quads(seed, draw, k, cells, np.arange(q0, q1))
+    e = normal_quads(seed, draw, k, cells, np.arange(q0, q1), float_box_muller=float_box_muller)
     e = e.reshape(len(cells), (q1 - q0) * 4)
     return np.ascontiguousarray(e[:, g0 - 4 * q0: g0 - 4 * q0 + n_genes])

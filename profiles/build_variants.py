@@ -9,7 +9,6 @@ VARIANTS = {
     "nt0_fast1": ["BRIE_NT=0", "BRIE_FAST_MATH=1"],
     "nt1_fast0": ["BRIE_NT=1", "BRIE_FAST_MATH=0"],
     "nt0_fast0": ["BRIE_NT=0", "BRIE_FAST_MATH=0"],
-    "lg_round2": ["BRIE_LG_ROUND2=1"],          # loss_gene_eval / margin_step as round 2 built them
 }
 names = sys.argv[1:] or sorted(VARIANTS)
 for n in names:

@@ -30,7 +30,10 @@ VARIANTS = {
 Nc, Ng = 200, 520
 
 
-def run_variant(name, min_iter=1000, seed=41, data_seed=37):
+def run_variant(name, min_iter=1000, seed=41, data_seed=37, null=False):
+    """null=False (round 3): HIP and the fp32 NumPy oracle, each against the fp64 one.  null=True (round 4): HIP against
+    the fp32 oracle, next to three further fp32 NumPy evaluations of the same algorithm (OracleBRIE2 variant_b = 1, 2, 3:
+    float Box-Muller and / or reversed reductions) against that same oracle -- the direct fp32-vs-fp32 null."""
     from brie_amd import _capi
     from tests import util
     mode, Kg, Kc, L, MC, target = VARIANTS[name]
@@ -39,8 +42,12 @@ def run_variant(name, min_iter=1000, seed=41, data_seed=37):
         P["Xc"] = (P["Xc"] * 0.3).astype(np.float32)       # many N(0,1) features: keep the prior mean inside the clip range
     P["Xg"] = np.random.default_rng(5 + data_seed).standard_normal((Ng, Kg)).astype(np.float32) if data_seed != 37 else \
         np.random.default_rng(5).standard_normal((Ng, Kg)).astype(np.float32)
-    runs = {"o32": util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode),
-            "o64": util.oracle_model(P, Nc, Ng, Kc, seed, np.float64, Kg=Kg, mode=mode)}
+    runs = {"o32": util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode)}
+    if null:
+        for v in (1, 2, 3):
+            runs["o32b%d" % v] = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode, variant_b=v)
+    else:
+        runs["o64"] = util.oracle_model(P, Nc, Ng, Kc, seed, np.float64, Kg=Kg, mode=mode)
     sh = util.device_shard(P, Nc, Ng, Kc, seed, Kg=Kg, mode=mode)
     sh.set_target(target)
     t0 = time.time()
@@ -65,8 +72,10 @@ def run_variant(name, min_iter=1000, seed=41, data_seed=37):
     out = {"variant": name, "mode": mode, "Kg": Kg, "Kc": Kc, "count_layers": L, "MC_size": MC, "target": target,
            "model_seed": seed, "data_seed": data_seed, "shape": [Nc, Ng], "steps": 6 * int(min_iter / 6), "seconds": time.time() - t0,
            "compared": "sigmoid(prior mean)" if target == "marginLik" else "Psi"}
-    for key, a in (("hip_vs_o64", "hip"), ("o32_vs_o64", "o32")):
-        d = np.abs(psi[a] - psi["o64"])
+    pairs = [("hip_vs_o32", "hip", "o32")] + [("o32b%d_vs_o32" % v, "o32b%d" % v, "o32") for v in (1, 2, 3)] if null else \
+        [("hip_vs_o64", "hip", "o64"), ("o32_vs_o64", "o32", "o64")]
+    for key, a, b in pairs:
+        d = np.abs(psi[a] - psi[b])
         ex = d > 1e-4
         out[key] = {"max": float(d.max()), "p99": float(np.percentile(d, 99)), "p99.9": float(np.percentile(d, 99.9)),
                     "n_gt_1e-4": int(ex.sum()), "frac_gt_1e-4": float(ex.mean()),

@@ -7,11 +7,11 @@ Tolerances (floating point path; north star: PSI within 1e-4 of the CPU path):
     (Adam's first update of a fresh optimiser is +-lr whatever |g| is, so an
     element with g ~ 0 moves on the sign of a rounding error), itself bounded by
     2.2 lr per fresh optimiser; sized by 1 000 soak cases (profiles/r3c_soak_record.json).
-  * PSI after a staged fit: tests/util.py::psi_parity_rule (revision 2) -- genes that moved
-    as a whole (displaced / clustered) and, in the quiet genes, entries beyond 1e-4 of the
-    fp64 oracle are counted and bounded by what the fp32 oracle (the reference's own
-    precision) produces on the same trajectory (evidence and the held-out checks:
-    DESIGN.md section 2, profiles/r3s_psi_delta_rev2_part*.json).
+  * PSI after a staged fit: tests/util.py::psi_null_rule -- HIP against the fp32 CPU oracle; genes
+    that moved as a whole (displaced / clustered) and, in the quiet genes, entries beyond 1e-4
+    are counted and bounded by what a SECOND fp32 CPU evaluation of the same algorithm (o32b:
+    float Box-Muller, reversed sums, fused multiply-adds) does against that same oracle run --
+    a direct fp32-vs-fp32 null (profiles/psi_null_r04.json).
 """
 import numpy as np
 import pytest
@@ -125,50 +125,51 @@ def test_psi_after_staged_fit(lib, Nc, Ng, Kc, L, MC, min_iter):
     from brie_amd import _capi
     P = util.problem(Nc, Ng, Kc, L, theta=3.0)
     seed = 11
-    o64 = util.oracle_model(P, Nc, Ng, Kc, seed, np.float64)
     o32 = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32)
+    o32b = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, variant_b=True)     # the null: a second fp32 evaluation
     sh = util.device_shard(P, Nc, Ng, Kc, seed)
     for n, lr in util.staged_schedule(min_iter):
-        for o in (o64, o32):
+        for o in (o32, o32b):
             o.reset_optimizer()
             o.minimize(P["counts_pc"], P["Xc"], n, lr, MC)
         sh.reset_optimizer()
         sh.step(n, lr, MC)
     psi_d = sh.read(_capi.PSI)
-    d_dev = np.abs(psi_d - o64.Psi)
-    d_o32 = np.abs(o32.Psi - o64.Psi)
-    print("PSI delta vs fp64 oracle: HIP max %.3g p99 %.3g | fp32 oracle max %.3g p99 %.3g"
-          % (d_dev.max(), np.percentile(d_dev, 99), d_o32.max(), np.percentile(d_o32, 99)))
-    print(util.psi_parity_of(sh, o32, o64, what="Psi"))     # the parity rule, stated once (tests/util.py)
-    # same rule for the interval width and the prior width: bulk tight, worst element bounded by
-    # what the reference's own precision (fp32 oracle) does on the same trajectory
-    for name, dev, ref64, ref32 in (("Psi95CI", sh.read(_capi.PSI95CI), o64.Psi95CI, o32.Psi95CI),
-                                    ("sigma", sh.read(_capi.SIGMA), o64.sigma, o32.sigma)):
-        d = np.abs(dev - ref64)
-        d32 = np.abs(ref32 - ref64)
-        assert np.percentile(d, 99) <= max(2e-4, 3 * np.percentile(d32, 99)), (name, float(np.percentile(d, 99)))
-        assert d.max() <= max(2e-3, 3 * d32.max()), (name, float(d.max()), float(d32.max()))
+    d_dev = np.abs(psi_d - o32.Psi)
+    d_nul = np.abs(o32b.Psi - o32.Psi)
+    print("PSI delta vs fp32 oracle: HIP max %.3g p99 %.3g | second fp32 CPU evaluation max %.3g p99 %.3g"
+          % (d_dev.max(), np.percentile(d_dev, 99), d_nul.max(), np.percentile(d_nul, 99)))
+    print(util.psi_null_of(sh, o32, o32b, what="Psi"))       # the parity rule, stated once (tests/util.py)
+    # same yardstick for the interval width and the prior width: bulk tight, worst element bounded by what the second
+    # fp32 evaluation does against the same oracle run
+    for name, dev, ref, nul in (("Psi95CI", sh.read(_capi.PSI95CI), o32.Psi95CI, o32b.Psi95CI),
+                                ("sigma", sh.read(_capi.SIGMA), o32.sigma, o32b.sigma)):
+        d = np.abs(dev - ref)
+        dn = np.abs(nul - ref)
+        assert np.percentile(d, 99) <= max(2e-4, 3 * np.percentile(dn, 99)), (name, float(np.percentile(d, 99)))
+        assert d.max() <= max(2e-3, 3 * dn.max()), (name, float(d.max()), float(dn.max()))
 
 
 @pytest.mark.parametrize("Kc", [0, 1])
 def test_psi_after_full_default_schedule(lib, Kc):
     """configs[0] (200 x 500) through the WHOLE BRIE2.fit default schedule (6 x 166 steps, fresh Adam per stage,
-    model_TFProb.py:234-241), HIP vs the C restatement in fp64 and fp32 (oracle/brie_oracle.c)."""
+    model_TFProb.py:234-241), HIP vs the C restatement in fp32 (oracle/brie_oracle.c), judged by the second fp32 build
+    of that restatement (-DBRIE_ORACLE_B) against the first."""
     from brie_amd import _capi
     from oracle.c_oracle import COracle
     Nc, Ng = 200, 500
     P = util.problem(Nc, Ng, Kc, 2, theta=3.0)
     seed = 11
-    o64 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float64)
     o32 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32)
+    o32b = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32, variant_b=True)
     sh = util.device_shard(P, Nc, Ng, Kc, seed)
     for n, lr in util.staged_schedule(1000):
-        for o in (o64, o32):
+        for o in (o32, o32b):
             o.reset_optimizer()
             o.minimize(n, lr, 1)
         sh.reset_optimizer()
         sh.step(n, lr, 1, trace=False)
-    print("996 steps, Kc=%d:" % Kc, util.psi_parity_of(sh, o32, o64, what="Psi after 996 steps"))
+    print("996 steps, Kc=%d:" % Kc, util.psi_null_of(sh, o32, o32b, what="Psi after 996 steps"))
     sh.close()
 
 
@@ -969,23 +970,23 @@ def test_distinct_handles_are_independent_across_threads(lib):
 def test_psi_after_full_default_schedule_model_variants(lib, variant):
     """The model variants beyond the plain per-gene model (gene features with per-cell weights, per-cell intercept /
     sigma, a wide cell design on the MFMA tile kernel, target="marginLik") through the WHOLE default schedule (6 x 166
-    steps, fresh Adam per stage): HIP against the NumPy restatement in fp64, next to the same restatement in fp32.
+    steps, fresh Adam per stage): HIP against the NumPy restatement in fp32, judged by the same comparison as everywhere
+    else since round 4 -- what further fp32 CPU evaluations of the same algorithm do against that same oracle run.
     In the coupled models one sign event in a parameter shared by a row (a cell's Wg_loc entry, its intercept) reaches every
-    gene of that cell, so fp32 and fp64 part widely -- 21 % of the entries beyond 1e-4 with two gene features, for the
-    fp32 oracle and for the HIP path alike.  Which run draws the larger events is a coin toss at this size (200 x 520):
-    over two sets of seeds and six variants the entry counts HIP / fp32 oracle range from 0.27 to 2.05 (1.03, 0.57, 0.96,
-    1.08, 1.00 with the seeds used here; 0.27, 2.05, 1.17, 0.94, 1.02 with others), p99 from 0.48 to 2.0
-    (profiles/psi_delta_variants_r03.json, ..._seed59.json).  The gene-level rule of tests/util.py has no meaning here;
-    what is asserted is that the HIP path is no further from the fp64 answer than the reference's own precision is, as a
-    distribution and within the factor 3 that two fp32 runs differ by among themselves: count, bulk and worst entry."""
+    gene of that cell, so two fp32 runs part across the whole matrix (21 % of the entries beyond 1e-4 with two gene
+    features, round 3) and the gene-level partition of tests/util.py::psi_null_rule has no meaning; its ENTRY-level
+    statistics and constants are applied to the whole matrix.  Which run draws the larger row / column events is a coin
+    toss at 200 x 520, so the null is a spread, not a draw: three members of the family (float Box-Muller + reversed
+    sums, either alone) and the HIP figures are held against the largest of them."""
     import os
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from profiles.psi_delta_variants import run_variant
-    r = run_variant(variant)
-    h, o = r["hip_vs_o64"], r["o32_vs_o64"]
-    print(variant, "HIP vs fp64:", h, "| fp32 oracle vs fp64:", o)
+    r = run_variant(variant, null=True)
+    h, nulls = r["hip_vs_o32"], [r["o32b%d_vs_o32" % v] for v in (1, 2, 3)]
+    print(variant, "HIP vs fp32 oracle:", h, "| three further fp32 evaluations vs the same oracle:", nulls)
     n = r["shape"][0] * r["shape"][1]
-    assert h["n_gt_1e-4"] <= 3.0 * o["n_gt_1e-4"] + max(1e-3 * n, 50), (variant, h["n_gt_1e-4"], o["n_gt_1e-4"])
-    assert h["p99"] <= 3.0 * o["p99"] + 1e-5, (variant, h["p99"], o["p99"])
-    assert h["max"] <= max(2e-3, 3.0 * o["max"]), (variant, h["max"], o["max"])
+    top = {k: max(o[k] for o in nulls) for k in ("n_gt_1e-4", "p99", "max")}
+    assert h["n_gt_1e-4"] <= 1.5 * top["n_gt_1e-4"] + max(1e-5 * n, 50), (variant, h["n_gt_1e-4"], [o["n_gt_1e-4"] for o in nulls])
+    assert h["p99"] <= 1.5 * top["p99"] + 1e-5, (variant, h["p99"], [o["p99"] for o in nulls])
+    assert h["max"] <= max(2e-3, 3.0 * top["max"]), (variant, h["max"], [o["max"] for o in nulls])

@@ -1,0 +1,84 @@
+"""-m gpu: the placement search of the streamed arrays (brie_placement_probe / _tune / _info, include/brie_amd.h).
+
+How fast a handle's step kernel streams depends on where the allocator put its arrays (the same
+code on the same data at 8.1 or 9.5 ms per step at configs[2]).  The library times an effect-free probe kernel with
+the step kernel's traffic on the handle's arrays and on up to two further sets and keeps the fastest.  What has to hold
+whatever the rates are: the probe changes NOTHING, moving to another set changes nothing but addresses, and a fit that
+searched is bit-identical to one that did not."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(sh):
+    from brie_amd import _capi
+    from tests import util
+    st = util.device_state(sh)
+    st["c1"] = sh.read(_capi.COUNT1)
+    st["c2"] = sh.read(_capi.COUNT2)
+    return st
+
+
+def _same(a, b):
+    for k in a:
+        assert a[k].shape == b[k].shape and np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("L,storage,big", [(2, None, False), (2, None, True), (3, None, False), (2, "f32", False)])
+def test_probe_and_forced_search_change_nothing_but_addresses(lib, L, storage, big):
+    from brie_amd import _capi
+    from tests import util
+    Nc, Ng, Kc = 700, 1100, 2
+    P = util.problem(Nc, Ng, Kc, L, seed=77)
+    if big:                                   # some quads beyond 255: u8 / u16 tiers per gene quad
+        P["counts"][0][5, 3] = 300.0
+        P["counts"][1][9, 700] = 5000.0
+    a = util.device_shard(P, Nc, Ng, Kc, 5, storage=storage)
+    b = util.device_shard(P, Nc, Ng, Kc, 5, storage=storage)
+    b.placement_tune(1, 0.0)                  # one "set" = the arrays as they are: b never moves
+    ta = [a.step(4, 0.01, 1)]
+    tb = [b.step(4, 0.01, 1)]
+    before = _state(a)
+    addr = [a.debug_address(w) for w in (_capi.Z_LOC, _capi.Z_STD_LOG, 20, 21, 22, 23)]
+    rate = a.placement_probe(2)
+    assert rate > 0.0
+    _same(before, _state(a))                  # the probe has no effect
+    info = a.placement_tune(3, 1e30)          # unreachable target: all three sets are tried, the fastest is kept
+    assert info["tries"] == 3 and 0 <= info["kept"] < 3 and len(info["GBs"]) == 3 and min(info["GBs"]) > 0.0
+    assert info["GBs"][info["kept"]] == max(info["GBs"]) and info["seconds"] > 0.0
+    after = [a.debug_address(w) for w in (_capi.Z_LOC, _capi.Z_STD_LOG, 20, 21, 22, 23)]
+    assert (after != addr) == (info["kept"] != 0)
+    _same(before, _state(a))                  # ... and neither has the move
+    ta.append(a.step(5, 0.005, 3))
+    tb.append(b.step(5, 0.005, 3))
+    assert np.array_equal(np.concatenate(ta), np.concatenate(tb))
+    _same(_state(a), _state(b))
+    lg_a, lg_b = a.loss_gene(3), b.loss_gene(3)
+    assert np.array_equal(lg_a, lg_b)
+    assert b.placement_info()["tries"] == 1
+    a.close()
+    b.close()
+
+
+def test_the_first_step_of_a_large_handle_searches_by_itself(lib):
+    """>= 256 MiB per step: brie_step probes before its first launch (and tries further sets while the rate is below
+    the library's idea of fast).  The result is the one of a handle that was told not to search."""
+    from brie_amd import _capi
+    from tests import util
+    Nc, Ng, Kc = 24000, 260, 1                # 6.2 M elements x 50 B = 312 MB per step
+    P = util.problem(Nc, Ng, Kc, 2, seed=78)
+    a = util.device_shard(P, Nc, Ng, Kc, 6)
+    b = util.device_shard(P, Nc, Ng, Kc, 6)
+    assert a.placement_info()["tries"] == 0
+    b.placement_tune(1, 0.0)
+    ta, tb = a.step(3, 0.01, 1), b.step(3, 0.01, 1)
+    info = a.placement_info()
+    assert 1 <= info["tries"] <= 3 and info["GBs"][info["kept"]] == max(info["GBs"])
+    assert np.array_equal(ta, tb)
+    assert np.array_equal(a.read(_capi.PSI), b.read(_capi.PSI))
+    n = a.placement_info()["tries"]
+    a.step(2, 0.01, 1)
+    assert a.placement_info()["tries"] == n   # once per handle
+    a.close()
+    b.close()

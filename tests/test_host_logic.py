@@ -297,6 +297,19 @@ def test_typed_ingest_conversion_equals_the_reference_cast(built_lib, dtype):
         assert np.array_equal(out, want, equal_nan=True) and np.array_equal(np.signbit(out), np.signbit(want)), val
 
 
+def test_non_native_byte_order_layers_take_the_numpy_cast():
+    """np.dtype('>i4').name is 'int32' as well: a big-endian layer (HDF5, FITS) handed raw to brie_upload_typed would be
+    read as garbage.  Such a layer -- and an unaligned one -- goes through the float32 cast instead."""
+    from brie_amd.models import engine
+    a = np.arange(24, dtype=">i4").reshape(4, 6)
+    out = engine._dense_f32(a)
+    assert out.dtype == np.float32 and out.dtype.isnative and np.array_equal(out, np.arange(24).reshape(4, 6))
+    native = np.arange(24, dtype=np.int32).reshape(4, 6)
+    assert engine._dense_f32(native) is native                  # native integers still go up as they are
+    raw = np.zeros(4 * 6 * 4 + 1, np.uint8)[1:].view(np.int32).reshape(4, 6)       # misaligned view
+    assert not raw.flags.aligned and engine._dense_f32(raw).dtype == np.float32
+
+
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):
@@ -413,6 +426,53 @@ def test_c_abi_argument_checks_and_loud_failure_without_a_gpu(built_lib):
     if not torch.cuda.is_available():
         rc, msg = create()
         assert rc == -3 and "hipGetDeviceCount" in msg and not h.value
+
+
+def test_psi_null_rule_holds_hip_against_a_second_fp32_evaluation():
+    """The rule since round 4 (tests/util.py::psi_null_rule) on synthetic runs: `h` = HIP vs the fp32 oracle, `n` = a second
+    fp32 CPU evaluation vs the same oracle, both reduced to per-gene summaries first (so that they can be computed where
+    the matrices are and judged elsewhere).  What it lets pass and what it refuses; and that slicing the summaries to a
+    gene subset equals summarising the sliced matrices."""
+    from tests import util
+    rng = np.random.default_rng(5)
+    Nc, Ng, Kc = 4000, 200, 2
+    psi32 = rng.uniform(0.05, 0.95, size=(Nc, Ng)).astype(np.float32)
+    base = {"Wc_loc": rng.normal(size=(Kc, Ng)), "intercept": rng.normal(size=Ng), "sigma_log": rng.normal(size=Ng) * 0.1}
+
+    def run(noise=2e-6, displaced=(), clustered=(), scattered=0, shift=2e-3, seed=0):
+        r = np.random.default_rng(seed)
+        psi = psi32.astype(np.float64) + r.normal(size=psi32.shape) * noise
+        par = {k: v.copy() for k, v in base.items()}
+        for j in displaced:
+            par["intercept"][j] += shift
+            psi[:, j] += 0.25 * shift
+        for j in clustered:
+            psi[r.choice(Nc, Nc // 50, replace=False), j] += 3e-4
+        for k in r.choice(Nc * 80, scattered, replace=False):
+            psi[k // 80, 120 + k % 80] += 2e-4
+        return util.gene_summaries(psi, psi32, par, base)
+
+    rep = util.psi_null_rule(run(seed=1), run(seed=2), "synthetic")
+    assert rep["holds"] and rep["displaced_genes"] == {"hip_vs_o32": 0, "o32b_vs_o32": 0} and rep["quiet_genes"]["genes"] == Ng
+    assert 5e-6 < rep["quiet_genes"]["p99_upper_bin_edge"]["hip_vs_o32"] < 6e-6        # 2.576 x 2e-6, to one 4.7 % bin
+    rep = util.psi_null_rule(run(displaced=(3, 50), clustered=(7,), scattered=20, seed=1),
+                             run(displaced=(10,), clustered=(8, 9), scattered=25, seed=2), "synthetic")
+    assert rep["displaced_genes"] == {"hip_vs_o32": 2, "o32b_vs_o32": 1}
+    assert rep["clustered_genes"]["hip_vs_o32"] == 1 and rep["clustered_genes"]["o32b_vs_o32"] == 2
+    assert rep["quiet_genes"]["genes"] == Ng - 6 and rep["quiet_genes"]["gt_1e-4"] == {"hip_vs_o32": 20, "o32b_vs_o32": 25}
+    for bad, what in ((dict(displaced=tuple(range(12))), "moved genes"), (dict(clustered=tuple(range(20, 28))), "moved genes"),
+                      (dict(scattered=150), "entries beyond 1e-4"), (dict(noise=2.2e-5), "p99"),
+                      (dict(displaced=(3,), shift=0.2), "gene shift")):
+        with pytest.raises(AssertionError, match=what):
+            util.psi_null_rule(run(seed=1, **bad), run(seed=2, scattered=40 if "scattered" in bad else 0), "synthetic")
+    rep = util.psi_null_rule(run(seed=1, scattered=150), run(seed=2, scattered=40), "synthetic", check=False)
+    assert not rep["holds"] and rep["violated"][0][0].startswith("entries beyond 1e-4")
+    # a gene subset of the summaries == the summaries of the gene subset
+    full = run(displaced=(3,), clustered=(7,), scattered=30, seed=4)
+    cols = np.arange(64)
+    sub = util.slice_summaries(full, cols)
+    assert sub["hist"].shape == (64, util.NULL_BINS.size) and int(sub["hist"].sum()) == 64 * Nc
+    assert np.array_equal(sub["n_gt"], full["n_gt"][:64]) and sub["Nc"] == Nc
 
 
 def test_psi_parity_rule_counts_moved_genes_as_genes_and_scattered_entries_as_entries():

@@ -31,14 +31,51 @@ def test_c_oracle_matches_numpy_oracle(L, Kc, MC):
     assert c.draw == o.draw == 12
 
 
+def test_second_fp32_build_is_the_same_algorithm_within_the_tolerances_the_device_is_granted():
+    """o32b (oracle/brie_oracle.c -DBRIE_ORACLE_B; the NumPy oracle's variant_b): the null of tests/util.py::psi_null_rule.
+    It must be the SAME algorithm evaluated another way: its noise within 2e-6 of the defined stream (the tolerance
+    tests/test_gpu_parity.py::test_noise_stream_matches_oracle grants the device), a few steps within the short-horizon
+    bounds the device is held to -- and NOT bit-identical, or it would be no null at all."""
+    import ctypes
+    from oracle import philox
+    from oracle.c_oracle import build
+    libs = {v: ctypes.CDLL(build(variant_b=v)) for v in (False, True)}
+    out = {v: np.zeros((40, 25, 4), np.float32) for v in libs}
+    for v, lib in libs.items():
+        lib.brie_oracle_normal4.argtypes = [ctypes.c_uint32] * 4 + [ctypes.c_uint64, ctypes.c_void_p]
+        for cell in range(40):
+            for quad in range(25):
+                lib.brie_oracle_normal4(quad, cell, 7, 2, 123456789012, out[v][cell, quad].ctypes.data_as(ctypes.c_void_p))
+    ref = philox.normal(123456789012, 7, 2, 40, 100).reshape(40, 25, 4)
+    np.testing.assert_array_equal(out[False], ref)                       # the first build IS the defined stream
+    d = np.abs(out[True].astype(np.float64) - ref)
+    assert 0 < d.max() <= 2e-6 and (out[True] != ref).mean() > 0.2
+    dn = np.abs(philox.normal(5, 3, 1, 64, 64, float_box_muller=True).astype(np.float64) - philox.normal(5, 3, 1, 64, 64))
+    assert 0 < dn.max() <= 2e-6
+    Nc, Ng, Kc = 90, 60, 2
+    P = make_problem(Nc, Ng, Kc=Kc, L=3, seed=92)
+    cnt = add_pseudo_count(P["counts"])
+    a = COracle(cnt, P["Xc"], effLen=P["effLen"], seed=19)
+    b = COracle(cnt, P["Xc"], effLen=P["effLen"], seed=19, variant_b=True)
+    na = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=19, dtype=np.float32)
+    nb = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=19, dtype=np.float32, variant_b=True)
+    np.testing.assert_allclose(b.minimize(5, 0.01, 2), a.minimize(5, 0.01, 2), rtol=3e-5)
+    np.testing.assert_allclose(nb.minimize(cnt, P["Xc"], 5, 0.01, 2), na.minimize(cnt, P["Xc"], 5, 0.01, 2), rtol=3e-5)
+    for x, y in ((a, b), (na, nb)):
+        for name in ("Z_loc", "Z_std_log", "Wc_loc", "intercept", "sigma_log"):
+            dd = np.abs(np.asarray(getattr(x, name), np.float64) - np.asarray(getattr(y, name), np.float64))
+            assert np.percentile(dd, 99.9) < 2e-5 and dd.max() < 1e-3, name
+        assert not np.array_equal(np.asarray(x.Z_loc), np.asarray(y.Z_loc))
+
+
 def test_c_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
     """The checker itself under ASan + UBSan on the CPU (GPU sanitizers are unavailable on this pool): both
     precisions, 2- and 3-layer likelihood, ragged shapes; any finding aborts with a non-zero exit code."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ([], ["-DBRIE_ORACLE_F64"]):
-        exe = str(tmp_path / ("oracle_san" + ("64" if extra else "32")))
+    for extra in ([], ["-DBRIE_ORACLE_F64"], ["-DBRIE_ORACLE_B", "-ffp-contract=fast"]):
+        exe = str(tmp_path / ("oracle_san" + "_".join(extra).replace("-", "").replace("=", "")))
         subprocess.run(["gcc", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                         "-fno-omit-frame-pointer"] + extra +
                        [os.path.join(root, "tests", "c_abi", "oracle_sanitize.c"), os.path.join(root, "oracle", "brie_oracle.c"),

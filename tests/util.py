@@ -15,9 +15,10 @@ def problem(Nc, Ng, Kc, L, seed=20240617, theta=1.5):
 
 
 def oracle_model(P, Nc, Ng, Kc, seed, dtype=np.float32, gene_offset=0, intercept=None, sigma=None, Kg=0,
-                 mode='gene'):
+                 mode='gene', variant_b=False):
     o = OracleBRIE2(Nc, Ng, Kc, effLen=P["effLen"], seed=seed, dtype=dtype,
-                    gene_offset=gene_offset, intercept=intercept, sigma=sigma, Kg=Kg, intercept_mode=mode)
+                    gene_offset=gene_offset, intercept=intercept, sigma=sigma, Kg=Kg, intercept_mode=mode,
+                    variant_b=variant_b)
     o.Xg = P.get("Xg")
     return o
 
@@ -174,3 +175,107 @@ def psi_parity_of(sh, o32, o64, cols=None, what=""):
         psi_h = psi_h[:, cols]
     return psi_parity_rule({"hip": psi_h, "o32": o32.Psi, "o64": o64.Psi},
                            {"hip": run_params(sh, cols), "o32": run_params(o32), "o64": run_params(o64)}, what)
+
+
+# ---- the direct fp32-vs-fp32 null (round 4) ----------------------------------------------------------
+NULL_BINS = 10.0 ** (-8.0 + 0.02 * np.arange(401))       # log-spaced edges 1e-8 .. 1, 4.7 % wide
+
+
+def gene_summaries(psi_a, psi_b, par_a, par_b):
+    """Everything the null rule consumes about the difference of two runs, PER GENE (so that it can be computed where
+    the matrices are and judged elsewhere): own-parameter shift, entries beyond PSI_TOL, largest entry, and a
+    log-binned histogram of |dPsi| (NULL_BINS; bin 0 also takes everything below 1e-8)."""
+    d = np.abs(np.asarray(psi_a, np.float64) - np.asarray(psi_b, np.float64))
+    Nc, Ng = d.shape
+    B = NULL_BINS.size
+    hist = np.zeros((Ng, B), np.int32)
+    for j0 in range(0, Ng, 64):                            # gene slabs keep the temporaries small
+        dj = d[:, j0:j0 + 64]
+        idx = np.clip(np.searchsorted(NULL_BINS, dj.ravel(), side="right") - 1, 0, B - 1)
+        key = np.tile(np.arange(dj.shape[1]), dj.shape[0]) * B + idx
+        hist[j0:j0 + dj.shape[1]] = np.bincount(key, minlength=dj.shape[1] * B).reshape(dj.shape[1], B)
+    return {"shift": gene_shift(par_a, par_b), "n_gt": (d > PSI_TOL).sum(0).astype(np.int64), "max": d.max(0),
+            "hist": hist, "Nc": int(Nc)}
+
+
+def slice_summaries(s, cols):
+    return {"shift": s["shift"][cols], "n_gt": s["n_gt"][cols], "max": s["max"][cols], "hist": s["hist"][cols], "Nc": s["Nc"]}
+
+
+def _p99_from_hist(hist):
+    tot = hist.sum(0).astype(np.int64)
+    n = int(tot.sum())
+    if n == 0:
+        return 0.0
+    k = int(np.searchsorted(np.cumsum(tot), 0.99 * n))
+    k = min(k, NULL_BINS.size - 1)
+    return float(NULL_BINS[min(k + 1, NULL_BINS.size - 1)])         # upper edge of the bin holding the 99th percentile
+
+
+def psi_null_rule(h, n, what="", check=True):
+    """THE parity rule since round 4: the HIP path against the fp32 CPU restatement (o32), judged by what a SECOND fp32
+    CPU evaluation of the same algorithm (o32b: oracle/brie_oracle.c built with -DBRIE_ORACLE_B -- float Box-Muller,
+    reversed cell order with fp32 partial sums, fused multiply-adds) does against that same o32 run.  No fp64 run is
+    involved.  `h` = gene_summaries(HIP, o32), `n` = gene_summaries(o32b, o32): same problem, init and noise stream.
+
+    The statistics and the constants are those of revision 2 (round 3, psi_parity_rule above), unchanged; only the
+    yardstick changed from "o32 vs o64" to "o32b vs o32" -- a direct fp32-vs-fp32 null:
+      displaced gene: own-parameter shift vs o32 > GENE_SHIFT;  clustered gene: not displaced, more than
+      max(5, 0.1 % of its cells) beyond PSI_TOL;  moved = either;  quiet = moved in NEITHER comparison.
+      1. #moved(h) <= 1.5 #moved(n) + max(3, 1 % of the genes);
+      2. entries of quiet genes beyond 1e-4:  N(h) <= 1.5 N(n) + max(1e-5 entries, 50);
+      3. their 99th percentile (from the per-gene histograms, upper bin edge): p99(h) <= 1.5 p99(n) + 1e-5;
+      4. worst entry of every gene displaced in neither: max(h) <= max(2e-3, 3 max(n));
+      5. largest own-parameter shift <= 0.15.
+    Returns the report; with check=True a violated rule raises AssertionError naming the case (`what`)."""
+    Ng, Nc = h["shift"].shape[0], h["Nc"]
+    cluster = max(5, int(1e-3 * Nc))
+    disp_h, disp_n = h["shift"] > GENE_SHIFT, n["shift"] > GENE_SHIFT
+    clus_h, clus_n = ~disp_h & (h["n_gt"] > cluster), ~disp_n & (n["n_gt"] > cluster)
+    moved_h, moved_n = disp_h | clus_h, disp_n | clus_n
+    undisp, quiet = ~(disp_h | disp_n), ~(moved_h | moved_n)
+    rep = {"genes": int(Ng), "cells": int(Nc),
+           "displaced_genes": {"hip_vs_o32": int(disp_h.sum()), "o32b_vs_o32": int(disp_n.sum())},
+           "clustered_genes": {"hip_vs_o32": int(clus_h.sum()), "o32b_vs_o32": int(clus_n.sum()),
+                               "more_cells_beyond_1e-4_than": cluster},
+           "largest_gene_shift": {"hip_vs_o32": float(h["shift"].max()), "o32b_vs_o32": float(n["shift"].max())},
+           "all_entries_gt_1e-4": {"hip_vs_o32": int(h["n_gt"].sum()), "o32b_vs_o32": int(n["n_gt"].sum())},
+           "all_entries_max": {"hip_vs_o32": float(h["max"].max()), "o32b_vs_o32": float(n["max"].max())}}
+    viol = []
+    if not moved_h.sum() <= 1.5 * moved_n.sum() + max(3, 0.01 * Ng):
+        viol.append(("moved genes", int(moved_h.sum()), int(moved_n.sum())))
+    if not h["shift"].max() <= 0.15:
+        viol.append(("gene shift", float(h["shift"].max())))
+    if undisp.any():
+        mh, mn = float(h["max"][undisp].max()), float(n["max"][undisp].max())
+        rep["undisplaced_genes"] = {"genes": int(undisp.sum()), "max": {"hip_vs_o32": mh, "o32b_vs_o32": mn}}
+        if not mh <= max(2e-3, 3 * mn):
+            viol.append(("max over undisplaced genes", mh, mn))
+    if quiet.any():
+        entries = int(quiet.sum()) * Nc
+        nh, nn = int(h["n_gt"][quiet].sum()), int(n["n_gt"][quiet].sum())
+        ph, pn = _p99_from_hist(h["hist"][quiet]), _p99_from_hist(n["hist"][quiet])
+        rep["quiet_genes"] = {"genes": int(quiet.sum()), "entries": entries, "gt_1e-4": {"hip_vs_o32": nh, "o32b_vs_o32": nn},
+                              "p99_upper_bin_edge": {"hip_vs_o32": ph, "o32b_vs_o32": pn}}
+        if not nh <= 1.5 * nn + max(1e-5 * entries, 50):
+            viol.append(("entries beyond 1e-4 in quiet genes", nh, nn, entries))
+        if not ph <= 1.5 * pn + 1e-5:
+            viol.append(("p99 of quiet genes", ph, pn))
+    rep["holds"] = not viol
+    if viol:
+        rep["violated"] = [list(v) for v in viol]
+    if check:
+        assert not viol, (what, viol, rep)
+    return rep
+
+
+def psi_null_of(sh, o32, o32b, cols=None, what=""):
+    """psi_null_rule for a device shard: HIP vs the fp32 oracle, judged by a second fp32 CPU evaluation vs that oracle
+    (`cols`: the oracles hold only this gene slice of the shard)."""
+    from brie_amd import _capi
+    psi_h = sh.read(_capi.PSI)
+    if cols is not None:
+        psi_h = psi_h[:, cols]
+    h = gene_summaries(psi_h, o32.Psi, run_params(sh, cols), run_params(o32))
+    n = gene_summaries(o32b.Psi, o32.Psi, run_params(o32b), run_params(o32))
+    return psi_null_rule(h, n, what)

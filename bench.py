@@ -30,6 +30,10 @@ import time
 
 import numpy as np
 
+# the C oracle legs (OpenMP) run between device calls: idle OpenMP workers must sleep, not spin against the HIP runtime's
+# threads on the few host cores a GPU box grants (set before libgomp is loaded; tests/conftest.py does the same)
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -105,6 +109,16 @@ def make_inputs(torch, dev, cfg, g0, g1, seed):
         c0 = c1
     torch.cuda.synchronize()
     return Xc, size, layers, eff_all
+
+
+_T0 = time.time()
+
+
+def note(msg):
+    """Progress on stderr (stdout carries the one JSON line): which leg is running, seconds since start."""
+    if os.environ.get("RANK", "0") == "0":
+        sys.stderr.write("[bench %6.1f s] %s\n" % (time.time() - _T0, msg))
+        sys.stderr.flush()
 
 
 def config_seed(name):
@@ -187,7 +201,7 @@ def hbm_traffic(args, world, storage):
                 cmd += ["--rows-per-chunk", str(args.rows_per_chunk)]
             if shard_of:
                 cmd += ["--emulate-shard-of", str(shard_of)]
-            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(standalone_env(), TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+            subprocess.run(cmd, check=True, cwd="/tmp", env=dict(standalone_env(), TMPDIR="/tmp", BRIE_PLACEMENT_TRIES="1"), stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, timeout=600)
             total = 0.0
             for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -207,9 +221,28 @@ def hbm_traffic(args, world, storage):
         return dict(fallback, traffic_error=repr(exc))
 
 
+def usable_cores():
+    """Host cores this process can really use: its affinity mask, capped by the CPU quota of its cgroup (a GPU box may
+    show 256 CPUs in the mask and grant a handful)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                                   # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(math.ceil(float(q) / float(per)))))
+    except (OSError, ValueError):
+        try:                                               # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def per_gene_vectors(sh, Kc, n_rep):
     from brie_amd import _capi
-    return np.concatenate([sh.read(_capi.WC_LOC).reshape(Kc, -1), sh.read(_capi.INTERCEPT).reshape(1, -1),
+    return np.concatenate([sh.read(_capi.WC_LOC).reshape(Kc, sh.Ng), sh.read(_capi.INTERCEPT).reshape(1, -1),
                            sh.read(_capi.SIGMA).reshape(1, -1), sh.loss_gene(n_rep).reshape(1, -1)], axis=0)
 
 
@@ -445,6 +478,7 @@ def main(argv=None):
     seed = config_seed(args.config)
 
     # ---- synthetic inputs, generated on the device, resident before the timed region
+    note("generating inputs: %s" % cfg["desc"])
     t_gen = time.time()
     Xc, size, layers, eff_all = make_inputs(torch, dev, cfg, g0, g1, seed)
 
@@ -479,8 +513,10 @@ def main(argv=None):
     t_gen = time.time() - t_gen
 
     lr = 0.005
+    note("warm-up (the first step also compacts the counts and searches the placement)")
     sh.step(args.warmup, lr, args.mc, trace=False)
     sh.synchronize()
+    note("placement: %r" % (sh.placement_info(),))
     sh.profile_enable(True)
 
     def fence():
@@ -494,6 +530,7 @@ def main(argv=None):
     sh.synchronize()
     fence()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.3f ms per step" % (elapsed / args.steps * 1e3))
     if args.pmc_child:                       # run under rocprofv3 --pmc by the parent bench: the launches are all it needs
         sh.close()
         return
@@ -621,6 +658,7 @@ def main(argv=None):
     #  like a fresh process, and the counter runs further down are other processes on this GPU)
     _capi.trim_memory()
     if e2e_inputs is not None:
+        note("whole BRIE2.fit + BRIE_RV from host arrays (pcie_inclusive)")
         # Secondary, PCIe-inclusive figure (never `value`): the reference's unit of work through the public API --
         # host count layers in, BRIE2.fit with the default schedule (996 staged steps + 500-draw loss_gene), host
         # Psi / Z_std / Psi95CI / Z_loc out (model_wrap.py:138-146) -- upload, compaction and read-back included.
@@ -647,7 +685,9 @@ def main(argv=None):
 
     _capi.trim_memory()
     if rank == 0:
+        note("HBM traffic: two rocprofv3 --pmc child runs")
         out["roofline"].update(hbm_traffic(args, world, storage_main))
+        note("traffic: %r (%s)" % (out["roofline"].get("traffic"), out["roofline"].get("traffic_source") or out["roofline"].get("traffic_error")))
     if rank == 0 and psi_quad is not None:
         # PSI delta ON THE TIMED WORKLOAD: genes are independent and the noise stream is keyed by the global gene
         # index, so the CPU oracle run on one gene quad over all Nc cells is an exact reference for those genes
@@ -662,6 +702,7 @@ def main(argv=None):
             "max": float(d.max()), "p99": float(np.percentile(d, 99))}
     if rank == 0:
         if not args.no_psi_check:
+            note("PSI delta check on configs[0] (HIP, fp32 oracle, second fp32 evaluation)")
             try:
                 out["psi_delta_vs_cpu_ref"] = psi_delta_check()
             except AssertionError as exc:          # a violated parity rule is REPORTED in the line, it does not cost the line
@@ -670,8 +711,9 @@ def main(argv=None):
                     raise
         if not args.no_cpu_baseline:
             from oracle.brie_oracle_torch import time_reference_shape
-            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            usable = usable_cores()
             cores = min(6, usable)                        # reference default --nproc 6 (bin/quant.py:183)
+            note("CPU baselines (%d usable cores)" % usable)
             n_gene = min(int(math.ceil(500000 / float(Nc))), sample_layers[0].shape[1])
             nb = max(1, min(3, sample_layers[0].shape[1] // n_gene))
 
@@ -691,10 +733,16 @@ def main(argv=None):
             }
             # the same eager baseline on ALL usable host cores (SURVEY 8d asks for both; bin/quant.py:183 defaults to 6)
             if usable > cores:
-                eps_all, el_all = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, nb, n_steps, args.mc, threads=usable)
+                # calibrated on its own: eager per-op dispatch over many threads can be SLOWER than over six (call r4b: a
+                # box with 256 cores in the mask never finished the six-thread step count)
+                note("eager CPU baseline on all %d usable cores" % usable)
+                eps_c, _ = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, 1, 3, args.mc, threads=usable,
+                                                warmup_steps=1)
+                n_all = int(max(3, min(n_steps, args.cpu_seconds * eps_c / (Nc * n_gene * nb))))
+                eps_all, el_all = time_reference_shape(Nc, n_gene * nb, counts_fn, Xc_host, nb, n_all, args.mc, threads=usable)
                 out["cpu_baseline_all_cores"] = {
                     "value": eps_all, "unit": "cell*gene*iterations/s", "cores": usable, "kind": "port",
-                    "sample": "the cpu_baseline sample on all %d usable cores, %.1f s" % (usable, el_all),
+                    "sample": "the cpu_baseline batches x %d Adam steps on all %d usable cores, %.1f s" % (n_all, usable, el_all),
                     "gpu_over_cpu": value / eps_all}
             else:
                 out["cpu_baseline_all_cores"] = dict(out["cpu_baseline"], sample="this process may run on %d cores: all "
@@ -707,7 +755,8 @@ def main(argv=None):
                 co = COracle(add_pseudo_count(sample_layers), Xc_host, effLen=None if L == 2 else eff_host, seed=seed)
                 # all cores THIS PROCESS may run on (a box reports 256 CPUs and grants 6 of them); set explicitly because
                 # torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks
-                co.set_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+                note("fused C/OpenMP CPU baseline")
+                co.set_threads(usable)
                 co.minimize(2, 0.005, args.mc)
                 t0 = time.perf_counter()
                 co.minimize(3, 0.005, args.mc)
@@ -728,6 +777,7 @@ def main(argv=None):
 
     # ---- LAST: the C-ABI communicator's gather (never run between two GPUs by the build).  Nothing measured comes
     # after it; if it does not come back, rank 0 prints its line and every rank leaves without another collective.
+    note("host legs done")
     wait_for_rank0()
     came_back = True
     if gather_state is not None:

@@ -16,7 +16,7 @@ COUNT1, COUNT2, COUNT3, XC, EFFLEN, XG = 0, 1, 2, 3, 4, 5
 Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
 ABI_VERSION = 2
-MAX_KC = 64          # 0..8 in registers, 9..64 with the W tile in LDS + an MFMA kernel for Xc^T.r
+MAX_KC = 1024        # 0..8 in registers, 9..64 on the matrix cores inside the streaming pass, beyond in 64-feature panels
 MAX_KG = 64
 
 EXPORTS = [

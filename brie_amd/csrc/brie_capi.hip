@@ -104,6 +104,7 @@ struct brie_handle {
     int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
     // wide cell designs (Kc > BRIE_MAX_KC): W tile in LDS for Xc.W, MFMA kernel for Xc^T.r
     bool wide = false;
+    bool vwide = false;             // Kc > BRIE_MAX_KC_WIDE: 64-feature panels (see setup_paths)
     int kernel_kc = 0;              // KC of the kernel instantiation (0 for wide designs)
     // Wide designs on the matrix cores (brie_tile.hip.h): Kc > 8 and / or Kg > 4 with forward and backward products
     // fused into the streaming pass.  wide_like = the per-gene statistics carry no Xc rows (S = 4), Wc_loc is updated
@@ -193,7 +194,7 @@ int io_wait(brie_handle *h) {
 
 // ---- the cell x gene arrays of the last destroyed handle, kept for the next one of the same size ----------------------
 // hipMalloc / hipFree of the 4 - 12 GB arrays of a shard are usually milliseconds and sometimes seconds (1.5 - 5.4 s in 3
-// of ~40 creations of round 3, 3.0 s for the 96 GB of configs[4]: profiles/r3a_ingest_ab_c3.json, r3k_bench_c5_whole_n1.json).
+// of ~40 creations of round 3, 3.0 s for the 96 GB of configs[4]: profiles/history/r3a_ingest_ab_c3.json, r3k_bench_c5_whole_n1.json).
 // Sequential fits of one size -- fitBRIE's super-batches, a fit after a bench, the models of an LRT that cannot share a
 // handle -- give the arrays back and ask for the same sizes a moment later.  ONE generation is kept: the blocks of the
 // last destroyed handle, all of one size on one device; a handle of another size, brie_device_memory and
@@ -301,7 +302,10 @@ void setup_paths(brie_handle *h) {
     // (gene features 5..8 stay on the LDS-broadcast variant: measured 1.06 x vs 1.09 x the narrow model's step time)
     const char *mk = getenv("BRIE_TILE_MIN_KG");       // A/B runs: smallest Kg that takes the tile kernel (default 8)
     const int min_kg = mk ? atoi(mk) : 8;
-    h->tile = want_tile && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
+    // Kc > 64 ("very wide"): no single kernel holds the W tile; Xc . Wc_loc and Xc^T . r are formed in 64-feature panels
+    // around the LDS-free WIDE variant of the streaming kernel (run_steps, wide_forward_mean, wide_backward)
+    h->vwide = Kc > BRIE_MAX_KC_WIDE;
+    h->tile = want_tile && !h->vwide && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
     h->tile_kcr = kcr ? 4 : 0;
     h->tile_nacc = kcm == 0 ? 0 : (Kc <= 32 ? 1 : 2);
@@ -329,7 +333,7 @@ void configure_tiling(brie_handle *h) {
         // A function of Nc ONLY (never of the shard's gene count): the per-gene fp32 partial sums are
         // then formed in the same order however the genes are sharded, so a gene's trajectory is
         // bit-identical in a 1-GPU fit and in any gene shard.  Aim for >= 128 cell chunks (measured best:
-        // 256 rows at Nc = 50k, 64 rows at Nc = 10k; profiles/r01_rows_per_chunk.log).
+        // 256 rows at Nc = 50k, 64 rows at Nc = 10k; profiles/history/r01_rows_per_chunk.log).
         rpc = 256;
         while (rpc > 16 && (Nc + rpc - 1) / rpc < 128) rpc /= 2;
     }
@@ -993,8 +997,8 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_INVALID, "abi_version %d != %d", p->abi_version, BRIE_AMD_ABI_VERSION);
     if (p->Nc <= 0 || p->Ng <= 0 || p->Nc > INT32_MAX || p->Ng > INT32_MAX - 1024)
         return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
-    if (p->Kc < 0 || p->Kc > BRIE_MAX_KC_WIDE)
-        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_WIDE);
+    if (p->Kc < 0 || p->Kc > BRIE_MAX_KC_PANELS)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_PANELS);
     if (p->Kg > BRIE_MAX_KG_WIDE)
         return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG_WIDE);
     if (p->Kg < 0) return fail(BRIE_ERR_INVALID, "Kg=%d", p->Kg);
@@ -1093,7 +1097,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
 // compacted once), replace everything that depends on the design width and the seed.
 int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_intercept, int32_t train_sigma) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
-    if (Kc < 0 || Kc > BRIE_MAX_KC_WIDE) return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", Kc, BRIE_MAX_KC_WIDE);
+    if (Kc < 0 || Kc > BRIE_MAX_KC_PANELS) return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", Kc, BRIE_MAX_KC_PANELS);
     if (h->step_open) return fail(BRIE_ERR_STATE, "a step is open");
     int rc = set_device(h);
     if (rc != BRIE_OK) return rc;
@@ -1497,7 +1501,11 @@ int brie_get_count_storage(const brie_handle *h) { return h ? h->cs : -1; }
 int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
     // LDS-broadcast wide variants: residual r written by the step, read back by wide_design_grad (the tile kernel keeps it on chip)
-    const int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
+    int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
+    if (h->vwide) {              // P panels: Xc.Wc_loc written once and re-read / re-written P - 1 times, the step's round trip,
+        const int64_t P = (h->p.Kc + BRIE_MAX_KC_WIDE - 1) / BRIE_MAX_KC_WIDE;     // the residual read by P gradient launches
+        gemm_streams = 4 * (2 * P - 1) + 8 + 4 * P;
+    }
     if (h->cs == brie::kCountMixed) {                    // genes of u8 quads move 1 byte per count, of u16 quads 2
         int64_t genes16 = 0;
         for (int64_t q = 0; q * brie::kVec < h->p.Ng; ++q)
@@ -1520,17 +1528,35 @@ namespace {
 // Wide designs (Kc = 9..64): G = Xc^T . r on the matrix cores, then Adam for Wc_loc.
 int wide_backward(brie_handle *h, float alpha) {
     const dim3 grid(h->gene_blocks, h->n_gchunks), block(512);
-    if (h->p.Kc <= 32)
-        hipLaunchKernelGGL((brie::wide_design_grad<1>), grid, block, 0, h->stream, h->Xc, h->Rbuf, h->Gpart,
-                           static_cast<int>(h->p.Nc), h->p.Kc, h->ld, h->gb_stride, h->gchunk_rows);
-    else
-        hipLaunchKernelGGL((brie::wide_design_grad<2>), grid, block, 0, h->stream, h->Xc, h->Rbuf, h->Gpart,
-                           static_cast<int>(h->p.Nc), h->p.Kc, h->ld, h->gb_stride, h->gchunk_rows);
+    const int Kc = h->p.Kc;
+    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE) {            // one launch per 64-feature panel (one for Kc <= 64)
+        const int kp = std::min(Kc - k0, BRIE_MAX_KC_WIDE);
+        const float *xp = h->Xc + k0;
+        float *gp = h->Gpart + static_cast<size_t>(k0) * h->ld;
+        if (kp <= 32)
+            hipLaunchKernelGGL((brie::wide_design_grad<1>), grid, block, 0, h->stream, xp, h->Rbuf, gp,
+                               static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc);
+        else
+            hipLaunchKernelGGL((brie::wide_design_grad<2>), grid, block, 0, h->stream, xp, h->Rbuf, gp,
+                               static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc);
+    }
     const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
     hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
                        h->n_gchunks, alpha, h->gene_active, h->ld);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
+}
+
+// dst (Nc, ld) tiled = Xc . Wc_loc, in panels of at most 64 features (the W tile of a panel sits in LDS)
+void launch_xw_panels(brie_handle *h, float *dst) {
+    const int Kc = h->p.Kc;
+    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE) {
+        const int kp = std::min(Kc - k0, BRIE_MAX_KC_WIDE);
+        hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream,
+                           h->Xc + k0, h->W + static_cast<size_t>(k0) * h->ld, dst, static_cast<int>(h->p.Nc),
+                           static_cast<int>(h->p.Ng), kp, h->ld, h->row_stride, h->gb_stride, h->rows_per_chunk,
+                           k0 > 0 ? 1 : 0, Kc);
+    }
 }
 
 // Mbuf = Xc . Wc_loc for the forward-only loss_gene pass of a wide design
@@ -1547,7 +1573,7 @@ int gwide_forward_mean(brie_handle *h, bool accumulate) {
     }
     hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Wg,
                        h->Xg, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->kgp, h->ld, h->row_stride,
-                       h->gb_stride, h->rows_per_chunk, accumulate ? 1 : 0);
+                       h->gb_stride, h->rows_per_chunk, accumulate ? 1 : 0, h->kgp);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
 }
@@ -1557,9 +1583,7 @@ int wide_forward_mean(brie_handle *h) {
         HIP_TRY(dev_alloc(&h->Mbuf, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
     }
-    hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Xc,
-                       h->W, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->p.Kc, h->ld, h->row_stride,
-                       h->gb_stride, h->rows_per_chunk, 0);
+    launch_xw_panels(h, h->Mbuf);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
 }
@@ -1771,7 +1795,8 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     a.rows_per_chunk = h->rows_per_chunk; a.mc = mc_size; a.inv_mc = 1.0f / static_cast<float>(mc_size);
     a.seed_lo = static_cast<uint32_t>(h->p.seed & 0xFFFFFFFFull); a.seed_hi = static_cast<uint32_t>(h->p.seed >> 32);
     a.quad_offset = static_cast<uint32_t>(h->p.gene_offset / 4);
-    a.kc_wide = h->wide_like ? h->p.Kc : 0;
+    a.kc_wide = (h->wide_like && !h->vwide) ? h->p.Kc : 0;
+    a.mean_in_rbuf = h->vwide ? 1 : 0;
     a.pc = h->pc;
     a.gene_active = h->gene_active; a.block_active = h->block_active; a.quad_ids = h->quad_ids;
     a.tt = h->tt;                    // tiers per gene quad (kCountMixed), one launch
@@ -1834,6 +1859,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         f.ring_prev = static_cast<int32_t>((h->ring_pos + brie::kLossRing - 1) % brie::kLossRing);
         h->ring_pos += 1;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
+        if (h->vwide) launch_xw_panels(h, h->Rbuf);   // Kc > 64: the prior mean's Xc . Wc_loc, panel by panel (timed with the step)
         if (use_tile) launch_tile(h, cfg, q, a, ta);
         else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
@@ -2251,7 +2277,7 @@ int brie_read_results_async(brie_handle *h, float *psi, float *z_std, float *psi
         // Slab k lives in buffer k & 1 and on stream k & 1.  The export kernel of slab k + 1 is enqueued BEFORE the copies
         // of slab k start: a copy into pageable memory blocks this thread, and next to the 500-draw loss_gene pass the
         // short export kernel waits milliseconds for compute units -- with kernel and copies of all slabs on ONE stream the
-        // copy engine idled through every one of those waits (tail behind loss_gene 0.22 s; profiles/r3g_*).  Stream order
+        // copy engine idled through every one of those waits (tail behind loss_gene 0.22 s; profiles/history/r3g_*).  Stream order
         // still protects the buffers: kernel k + 2 follows the copies of slab k on their common stream.
         const bool one_stream = getenv("BRIE_IO_ONE_STREAM") != nullptr;             // A/B runs: round 2's order
         const int64_t n_slabs = (Nc + slab_rows - 1) / slab_rows;

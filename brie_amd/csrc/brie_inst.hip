@@ -19,7 +19,7 @@ namespace {
 // every ten steps at the C3 shape (profiles/occ_pad_sweep.py): 3 per CU (what 166 VGPRs allow) 8.26 ms, 2 per CU 8.17 -
 // 8.21 ms, 1 per CU 8.07 - 8.11 ms on a fast box; 9.37 -> 9.12 ms on a box in its slow mode (r04j / r04k logs).  Capping
 // through the register allocator (amdgpu_waves_per_eu) re-schedules every instantiation (MC_size 3 with effLen: 13 %
-// slower, profiles/r03n_ab_max_waves.log), so the launch simply carries enough unused dynamic LDS that a second
+// slower, profiles/history/r03n_ab_max_waves.log), so the launch simply carries enough unused dynamic LDS that a second
 // workgroup no longer fits the CU's 160 KB.  BRIE_STEP_OCCUPANCY_CAP=0: hardware occupancy, =1 / =2: one / two per CU (A/B runs;
 // read once, or at every launch when BRIE_STEP_OCCUPANCY_CAP_DYNAMIC is set).
 struct OccupancyPads { int one = 0, two = 0; };
@@ -46,7 +46,7 @@ void step_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a
     static const OccupancyPads pads = occupancy_pads(kern);
     // automatic: one per CU for one Monte-Carlo sample per step; with more samples the row body keeps the SIMD's VALU
     // busy most of the time and a second wave per SIMD is what hides the memory latency (MC_size 3: one per CU is 4 - 15 %
-    // SLOWER than two for Kc = 1, 3, 8; profiles/r04o_occ_matrix.log)
+    // SLOWER than two for Kc = 1, 3, 8; profiles/history/r04o_occ_matrix.log)
     int cap = occupancy_cap();
     if (cap < 0) cap = MC == 1 ? 1 : 2;
     const int pad = cap == 1 ? pads.one : (cap == 2 ? pads.two : 0);

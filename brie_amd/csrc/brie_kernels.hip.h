@@ -316,6 +316,9 @@ struct StepScalars {
                                             //   g*gb_stride + r*row_stride + 4*l + v
     int32_t Nc, Ng, rows_per_chunk, mc;
     int32_t kc_wide;                        // wide designs: run-time number of cell features (9..64)
+    int32_t mean_in_rbuf;                   // very wide designs (Kc > 64): Xc.Wc_loc was formed panel by panel into `rbuf`
+                                            // by wide_prior_mean; the kernel takes it from there (kc_wide = 0) and writes
+                                            // the residual back to the same place
     uint32_t seed_lo, seed_hi, draw, quad_offset;
     float alpha;                            // lr*sqrt(1-b2^t)/(1-b1^t)
     float inv_mc;
@@ -706,8 +709,11 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
                 rs.clam = cp.clam[r];
             }
             load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
-            if constexpr (WIDE)          // the cell's design row: lane k holds feature k (one coalesced load)
-                R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
+            if constexpr (WIDE) {
+                if (a.mean_in_rbuf) R.mp = ld4s(rbuf + off);      // Xc . Wc_loc of this element, formed beforehand
+                else                     // the cell's design row: lane k holds feature k (one coalesced load)
+                    R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
+            }
             if constexpr (!MARGIN) {
                 R.mu = ld4s(mu_p + off);
                 R.rho = ld4s(rho_p + off);
@@ -740,6 +746,10 @@ __global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
             if constexpr (WIDE) {        // Xc . Wc_loc: broadcast x_k with v_readlane, W_k from LDS
                 const int xbits = __builtin_bit_cast(int, R.mp.v[0]);
                 float mp[kVec] = {0.f, 0.f, 0.f, 0.f};
+                if (a.mean_in_rbuf) {
+#pragma unroll
+                    for (int v = 0; v < kVec; ++v) mp[v] = R.mp.v[v];
+                }
                 for (int k = 0; k < a.kc_wide; ++k) {
                     const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xbits, k));
                     const F4 wk = ld4(wlds + k * kGenesPerBlock + lane * kVec);
@@ -1356,9 +1366,11 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
 }
 
 // wide designs, forward only (loss_gene_eval reads it): Mbuf = Xc . Wc_loc, tiled like the state arrays
+// (Kc = the features of THIS launch, at most kWideKcMax: a panel of a wider design starts at Xc + k0 with row pitch x_ld
+//  and at W + k0 * ld, and accumulates)
 __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const float *W, float *Mbuf, int Nc, int Ng,
                                                           int Kc, int64_t ld, int64_t row_stride, int64_t gb_stride,
-                                                          int rows_per_chunk, int accumulate) {
+                                                          int rows_per_chunk, int accumulate, int x_ld) {
     __shared__ float wlds[kWideKcMax * kGenesPerBlock];
     for (int i = threadIdx.x; i < Kc * kGenesPerBlock; i += kBlock)
         wlds[i] = W[static_cast<int64_t>(i / kGenesPerBlock) * ld + blockIdx.x * kGenesPerBlock + (i % kGenesPerBlock)];
@@ -1369,7 +1381,7 @@ __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const
     const int row_end = min(row0 + rows_per_chunk, Nc);
     const int64_t mbase = static_cast<int64_t>(blockIdx.x) * gb_stride + lane * kVec;
     for (int r = row0 + w; r < row_end; r += kWavesPerBlock) {
-        const int xbits = __builtin_bit_cast(int, lane < Kc ? Xc[static_cast<int64_t>(r) * Kc + lane] : 0.0f);
+        const int xbits = __builtin_bit_cast(int, lane < Kc ? Xc[static_cast<int64_t>(r) * x_ld + lane] : 0.0f);
         F4 m = {{0.f, 0.f, 0.f, 0.f}};
         if (accumulate) m = ld4(Mbuf + mbase + static_cast<int64_t>(r) * row_stride);
         for (int k = 0; k < Kc; ++k) {
@@ -1390,9 +1402,11 @@ __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const
 // Gpart: (n_chunks, Kc, ld) partial sums, reduced in fp64 by wide_w_adam.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NACC>      // 1: Kc <= 32, 2: Kc <= 64
+// (Kc = the features of THIS launch; a panel of a wider design passes Xc + k0 with row pitch x_ld, Gpart + k0 * ld and
+//  the chunk stride kc_total of the whole design)
 __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict__ Xc, const float *__restrict__ R,
                                                         float *__restrict__ Gpart, int Nc, int Kc, int64_t ld,
-                                                        int64_t gb_stride, int rows_per_chunk) {
+                                                        int64_t gb_stride, int rows_per_chunk, int x_ld, int kc_total) {
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x >> 6;                        // gene slice 0..7
     const int half = lane >> 5, l31 = lane & 31;
@@ -1415,7 +1429,7 @@ __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict_
 #pragma unroll
             for (int a = 0; a < NACC; ++a) {
                 const int feat = l31 + 32 * a;
-                aval[u][a] = (ok && feat < Kc) ? Xc[static_cast<int64_t>(rr) * Kc + feat] : 0.0f;
+                aval[u][a] = (ok && feat < Kc) ? Xc[static_cast<int64_t>(rr) * x_ld + feat] : 0.0f;
             }
         }
 #pragma unroll
@@ -1430,7 +1444,7 @@ __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict_
         for (int q = 0; q < 16; ++q) {
             const int feat = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * a;
             if (feat < Kc)
-                Gpart[(static_cast<int64_t>(blockIdx.y) * Kc + feat) * ld + blockIdx.x * kGenesPerBlock + w * 32 + l31] =
+                Gpart[(static_cast<int64_t>(blockIdx.y) * kc_total + feat) * ld + blockIdx.x * kGenesPerBlock + w * 32 + l31] =
                     acc[a][q];
         }
 }

@@ -77,7 +77,7 @@ __device__ __forceinline__ void tile_sync(int *ctr, int &arrived) {
 }
 
 // KCR  = 4: gene-feature models with at most 4 cell features (the usual kind: a few covariates next to Xg).  A 32-feature
-//        MFMA tile would contract 3 real rows of 32 -- 8 % of a tile's cycles in X^T.R alone (profiles/r03q_tile_phases.log)
+//        MFMA tile would contract 3 real rows of 32 -- 8 % of a tile's cycles in X^T.R alone (profiles/history/r03q_tile_phases.log)
 //        -- so the cell design is handled the way elbo_adam_step does it: weights and X^T.R accumulators in registers,
 //        the cell's design row through scalar loads, 2 x 4 FMAs per feature and row.  NACC must be 0.
 template <int MODE, int CS, int NACC, int NJT, int NH, int KCR = 0>
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
     // them with coalesced loads into registers while the previous tile finishes, and drops them into At once that tile's
     // readers are through.  (Each lane fetching its own A operand inside the MFMA loop -- one 4-byte load per lane, row
     // and k-step -- cost 64 cache lines per instruction and one L2 round trip per k-step: 17 000 cycles for a forward
-    // product whose MFMAs take 4 400, profiles/r03j_tile_phases.log.)
+    // product whose MFMAs take 4 400, profiles/history/r03j_tile_phases.log.)
     constexpr int NXL = 4 * NACC, NGL = 4 * NJT;            // loads per thread: 32 x 32 NACC (NJT) floats over 256 threads
     float pre_x[NXL > 0 ? NXL : 1], pre_g[NGL > 0 ? NGL : 1];
     const float inv_kc = t.Kc > 0 ? 1.0f / static_cast<float>(t.Kc) : 0.0f;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(NH * kBlock, 2) void elbo_adam_step_tile(   // 2 wa
             // Operands are read from LDS four k-steps at a time, one batch ahead of the MFMAs that use them (a
             // read-wait-MFMA sequence per step would expose one LDS latency per 64 MFMA cycles); k beyond K reads row
             // K - 1 and contributes a zero A operand -- no branch in the loop.  (Pinning "reads of the next batch, then
-            // the MFMAs" with sched_group_barrier was measured and is slower: profiles/r03r_tile_phases.log.)
+            // the MFMAs" with sched_group_barrier was measured and is slower: profiles/history/r03r_tile_phases.log.)
             const int l31 = fresh(lane) & 31, half = fresh(lane) >> 5;
             const float *arow_l = At + l31 * AS;            // the lane's A row (cell); rows past the chunk hold zeros
             auto forward = [&](const float *arow, const float *btile, int bstride, int K) {

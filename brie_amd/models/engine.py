@@ -218,7 +218,7 @@ class BRIE2(object):
         16 GB of fresh host memory (configs[2]) leave the critical path.  The buffers stay PAGEABLE: page-locking
         them (brie_host_register) would let the copy engine write at PCIe speed, but registering GBs of user memory
         while kernels run stalls the device queues (measured: +1.0 s on the 996 steps of configs[2],
-        profiles/r02d_e2e_fit_c3_pinned_while_running.json)."""
+        profiles/history/r02d_e2e_fit_c3_pinned_while_running.json)."""
         import threading
         bufs = {w: np.empty((self.Nc, self.Ng), np.float32) for w in (_capi.PSI, _capi.Z_STD, _capi.PSI95CI, _capi.Z_LOC)}
 

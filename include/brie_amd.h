@@ -76,7 +76,7 @@ typedef struct brie_problem {
     int64_t Ng;               /* genes in this shard */
     int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
                                  keys the noise stream so results do not depend on sharding */
-    int32_t Kc;               /* cell features (0..BRIE_MAX_KC_WIDE) */
+    int32_t Kc;               /* cell features (0..BRIE_MAX_KC_PANELS) */
     int32_t Kg;               /* gene features (0..BRIE_MAX_KG_WIDE); > 0 couples the genes of a shard */
     int32_t n_layers;         /* 2 or 3 count layers */
     int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
@@ -91,6 +91,9 @@ typedef struct brie_problem {
 
 #define BRIE_MAX_KC 8         /* cell features fused into the streaming kernel (Xc row in SGPRs) */
 #define BRIE_MAX_KC_WIDE 64   /* wider designs: W tile in LDS for Xc.W, hand-written fp32 MFMA kernel for Xc^T.r */
+#define BRIE_MAX_KC_PANELS 1024   /* beyond 64: Xc.W and Xc^T.r in panels of 64 features around the streaming kernel, which
+                                     exchanges them through one extra array (the reference has no limit,
+                                     model_TFProb.py:84,122-123; no BASELINE config has more than 5) */
 #define BRIE_MAX_KG 4          /* gene features kept in registers; above: Xg tile in LDS */
 #define BRIE_MAX_KG_WIDE 64
 

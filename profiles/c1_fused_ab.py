@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""REJECTED EXPERIMENT (round 3; the library no longer has this path, the log is profiles/r3a_c1_fused_finalize_ab_rejected.log).
+"""REJECTED EXPERIMENT (round 3; the library no longer has this path, the log is profiles/history/r3a_c1_fused_finalize_ab_rejected.log).
 configs[0] (200 x 500) is launch-bound: two dependent ~6 us kernels per step.  A/B of the fused finalize (the
 per-gene finalize in the tail of the step kernel, one launch per step) against the two-kernel step, alternating in ONE
 process: wall time per step of brie_step(trace=False) batches, with and without per-launch profiling events.

@@ -7,7 +7,7 @@ and underneath the 500-draw loss_gene pass -- the last phase of every fit (what 
 two_streams (default of the library): slab k on stream k & 1, export kernel of slab k + 1 enqueued before the copies of
 slab k; one_stream: BRIE_IO_ONE_STREAM=1, round 2's order.  (Call r3g measured a third variant -- staged lanes with
 page-locked slabs and host memcpy threads, the mirror of the ingest -- at 0.27-0.30 s tail against 0.22 s and removed it:
-profiles/r3g_staged_egress_ab_rejected.json.)
+profiles/history/r3g_staged_egress_ab_rejected.json.)
 """
 import argparse
 import json

@@ -2,7 +2,7 @@
 """PSI-delta evidence: how far is the HIP path from the CPU reference, and how far is the reference's own
 fp32 precision from the precision-independent answer, after the FULL default schedules?
 
-    python profiles/psi_delta.py --out profiles/psi_delta_r02.json            (GPU box)
+    python profiles/psi_delta.py --out profiles/history/psi_delta_r02.json            (GPU box)
     python profiles/psi_delta.py --oracles-only                               (no GPU: fills the oracle cache)
 
 For every case the same seeded problem (same init, same Philox noise stream) is run through
@@ -231,7 +231,7 @@ def util_params(p):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "psi_delta.json"),
-                    help="(the committed profiles/psi_delta_r03.json is the evidence revision 1 of the rule was frozen on: not a default target)")
+                    help="(the committed profiles/history/psi_delta_r03.json is the evidence revision 1 of the rule was frozen on: not a default target)")
     ap.add_argument("--cases", default=",".join(R03))
     ap.add_argument("--variants", default="hip")
     ap.add_argument("--oracles-only", action="store_true")

@@ -4,7 +4,7 @@ gene features Xg with per-cell weights, per-cell intercept / sigma, wide cell de
 HIP vs the NumPy restatement (oracle/brie_oracle.py) in fp64, next to the same restatement in fp32 -- the reference's own
 precision on the same trajectory.  In these models a sign event can hit a parameter shared by a whole ROW (a cell's Wg_loc
 entry, its intercept) as well as a gene's own: exceedances are reported per column and per row.
-    python profiles/psi_delta_variants.py [--out profiles/psi_delta_variants_r03.json]      (GPU box)
+    python profiles/psi_delta_variants.py [--out profiles/history/psi_delta_variants_r03.json]      (GPU box)
 The oracle is the checker here, never the thing measured."""
 import argparse
 import json

@@ -15,6 +15,7 @@ rm -rf $RAW; mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-psi-check --no-pmc --no-f32-leg --no-e2e $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/trace -o trace -- python3 $R/bench.py $ARGS > $OUT/bench_trace.log 2>&1
+export BRIE_PLACEMENT_TRIES=1     # counter passes: traffic does not depend on the placement; no 26-GB copies under --pmc
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $RAW/pmc_fetch -o fetch -- python3 $R/bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $RAW/pmc_write -o write -- python3 $R/bench.py $ARGS > $OUT/bench_write.log 2>&1
 python3 $R/profiles/summarize.py $RAW > $OUT/summary.txt 2>&1

@@ -1,6 +1,6 @@
 """Wide designs at the C3 shape: MFMA tile kernel (default) vs the round-1 LDS-broadcast variants (BRIE_WIDE_PATH=lds)
 vs the narrow reference model (Kc = 3, Kg = 0), INTERLEAVED in one process because the step time of one and the same
-kernel drifts by up to +-10 % over seconds on these boxes (profiles/r02h_alloc_cycles.log: identical addresses, 8.0 .. 9.8 ms).
+kernel drifts by up to +-10 % over seconds on these boxes (profiles/history/r02h_alloc_cycles.log: identical addresses, 8.0 .. 9.8 ms).
 
     python profiles/wide_ab.py [--rounds 4] [--steps 6]
 """

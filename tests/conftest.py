@@ -5,7 +5,7 @@ import pytest
 
 # The C oracle (oracle/brie_oracle.c) is OpenMP code that the GPU tests call between device calls: its idle worker threads
 # must sleep, not spin, or they compete with the HIP runtime's own threads for the few host cores a GPU box grants
-# (profiles/run_r3u.sh: 900 s against 50 s for the same work).  Set before libgomp is loaded.
+# (profiles/history/run_r3u.sh: 900 s against 50 s for the same work).  Set before libgomp is loaded.
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

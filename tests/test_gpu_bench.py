@@ -23,7 +23,9 @@ def _env(**extra):
 
 
 def _line(p):
-    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    if p.returncode != 0:              # the whole story, not pytest's abbreviated repr of it
+        pytest.fail("bench.py exited with %d\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s"
+                    % (p.returncode, p.stdout[-1500:], p.stderr[-6000:]), pytrace=False)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     return json.loads(lines[0])

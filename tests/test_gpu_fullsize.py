@@ -20,7 +20,7 @@ PER_GENE = 5e-6          # Wc_loc / intercept / sigma_log of a quad after 12 ste
 
 def _quad_states_close(tag, dev, ref, psi=None):
     """Short-horizon parity of one gene quad over ALL cells against the fp32 oracle (6 - 12 Adam steps of ONE fresh
-    optimiser), sized by what the 18 quads of this file need (profiles/r3q_fullsize_needs.log: per-gene vectors within
+    optimiser), sized by what the 18 quads of this file need (profiles/history/r3q_fullsize_needs.log: per-gene vectors within
     1.43e-6; 99.9 % quantile of Z_loc / Z_std_log 1.67e-6; at most 3 of 400 000 elements beyond 1e-4, the largest 2.4e-4;
     Psi 99.9 % 2.98e-7, one element at 2.5e-5):
       * the per-gene vectors Wc_loc / intercept / sigma_log (a handful of numbers): every one within PER_GENE = 5e-6;

@@ -6,7 +6,7 @@ Tolerances (floating point path; north star: PSI within 1e-4 of the CPU path):
     every element within 1e-3 except at most one sign-flipped element per array
     (Adam's first update of a fresh optimiser is +-lr whatever |g| is, so an
     element with g ~ 0 moves on the sign of a rounding error), itself bounded by
-    2.2 lr per fresh optimiser; sized by 1 000 soak cases (profiles/r3c_soak_record.json).
+    2.2 lr per fresh optimiser; sized by 1 000 soak cases (profiles/history/r3c_soak_record.json).
   * PSI after a staged fit: tests/util.py::psi_null_rule -- HIP against the fp32 CPU oracle; genes
     that moved as a whole (displaced / clustered) and, in the quiet genes, entries beyond 1e-4
     are counted and bounded by what a SECOND fp32 CPU evaluation of the same algorithm (o32b:
@@ -27,9 +27,9 @@ _RECORD = None            # tests/tools/soak_randomised.py sets a list: (array, 
 
 def assert_states_close(so, sd, bulk=1e-5, worst=1e-3, lr=0.01, fresh=1):
     """State arrays of the oracle and of the device after a few Adam steps (the short-horizon parity rule), sized by
-    what 1 000 soak cases of the two random families need (profiles/r3c_soak_record.json: 6 545 comparisons; the
+    what 1 000 soak cases of the two random families need (profiles/history/r3c_soak_record.json: 6 545 comparisons; the
     99.9 % quantile of an array of >= 1000 elements never above 1.9e-6; 6 comparisons with ONE element beyond 1e-3,
-    the largest 2.3e-3) and 2 400 more in assert mode (profiles/r3f_soak_assert_mode.log, r3n_soak_wide.log: the
+    the largest 2.3e-3) and 2 400 more in assert mode (profiles/history/r3f_soak_assert_mode.log, r3n_soak_wide.log: the
     largest 99.9 % quantile 7.6e-6, the Wc_loc of a ONE-cell problem).
 
       bulk    99.9 % of every array of >= 1000 elements within `bulk` (1e-5; smaller arrays fall under `worst` alone);
@@ -640,6 +640,37 @@ def test_wide_cell_design_matches_oracle(lib, Kc, L, MC):
     assert sh.step_storage_bytes() <= sh.step_algorithmic_bytes()
 
 
+@pytest.mark.parametrize("Kc,L,MC,mode,Kg", [(96, 2, 1, "gene", 0), (130, 3, 2, "gene", 0), (70, 2, 1, "cell", 2)])
+def test_very_wide_cell_design_runs_in_panels(lib, Kc, L, MC, mode, Kg):
+    """Kc > 64 (the reference has no limit, model_TFProb.py:84,122-123): Xc.Wc_loc and Xc^T.r are
+    formed in panels of 64 features around the streaming kernel (a ragged last panel at Kc = 130; with gene features and
+    per-cell intercepts next to it).  Same oracle, same bounds as the one-pass wide designs."""
+    from brie_amd import _capi
+    Nc, Ng = 300, 520
+    P = util.problem(Nc, Ng, Kc, L, seed=157)
+    P["Xc"] = (P["Xc"] * 0.2).astype(np.float32)           # many N(0,1) features: keep the prior mean inside the clip range
+    if Kg:
+        P["Xg"] = np.random.default_rng(9).standard_normal((Ng, Kg)).astype(np.float32)
+    o = util.oracle_model(P, Nc, Ng, Kc, 59, np.float32, Kg=Kg, mode=mode)
+    sh = util.device_shard(P, Nc, Ng, Kc, 59, Kg=Kg, mode=mode)
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 5, 0.01, MC)
+    tr_d = sh.step(5, 0.01, MC)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
+    assert_states_close(util.oracle_state(o), util.device_state(sh), bulk=5e-5)
+    np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
+    assert sh.step_storage_bytes() > sh.step_algorithmic_bytes()          # the panels exchange through HBM, and say so
+    if not Kg and mode == "gene":                          # the other target on the same design
+        sh.set_target("marginLik")
+        o.reset_optimizer()
+        sh.reset_optimizer()
+        tr_o = o.minimize(P["counts_pc"], P["Xc"], 3, 0.01, 3, target="marginLik")
+        np.testing.assert_allclose(sh.step(3, 0.01, 3), tr_o, rtol=1e-4)
+        np.testing.assert_allclose(sh.read(_capi.WC_LOC), o.Wc_loc, atol=2e-4)
+    with pytest.raises(NotImplementedError):
+        _capi.Shard(Nc, Ng, 1025)
+    sh.close()
+
+
 def test_sparse_layers_densified_on_device(lib):
     """CSC / CSR / COO count layers (model_wrap.py:108-111 densifies on the host) incl. duplicate entries."""
     import scipy.sparse as sp
@@ -744,7 +775,7 @@ def test_packing_active_quads_is_bit_identical(lib, monkeypatch):
 def test_packing_with_a_ragged_last_quad_keeps_every_frozen_loss(lib, monkeypatch, Ng):
     """Ng % 4 != 0: packing the active quads to the front moves a FULL quad into the last position, whose genes 1..3 then
     sit at positions >= Ng.  The per-gene finalize used to stop at position Ng and dropped the carried losses of those
-    (frozen) genes from the trace and the loss ring -- found by soak sequence 61 of call r3c (profiles/r3d_soak_seq61_failure.log).
+    (frozen) genes from the trace and the loss ring -- found by soak sequence 61 of call r3c (profiles/history/r3d_soak_seq61_failure.log).
     Trace, loss window and state against the oracle, and bit-identical to the unpacked run."""
     Nc, Kc = 130, 3
     P = util.problem(Nc, Ng, Kc, 3, seed=361)

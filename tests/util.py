@@ -95,9 +95,9 @@ def gene_shift(pa, pb):
 
 def psi_parity_rule(psi, par, what=""):
     """THE parity rule of the floating-point path (north star: PSI within 1e-4 of the CPU path).
-    Revision 2 (round 3).  Revision 1 was frozen on seven cases (profiles/psi_delta_r03.json) and then put to six
+    Revision 2 (round 3).  Revision 1 was frozen on seven cases (profiles/history/psi_delta_r03.json) and then put to six
     held-out cases with other seeds and another shape: it held on five and failed on one
-    (profiles/r3r_psi_delta_heldout.json, mid_cli_96_s3) -- which showed what it had lumped together, see "clustered".
+    (profiles/history/r3r_psi_delta_heldout.json, mid_cli_96_s3) -- which showed what it had lumped together, see "clustered".
     Revision 2 was in turn checked on a second held-out set generated after it (profiles/psi_delta.py::HELD_OUT_2).
 
     psi[k], par[k] for k in 'hip' (the HIP path), 'o32' (the CPU restatement in fp32 = the reference's precision),
@@ -119,7 +119,7 @@ def psi_parity_rule(psi, par, what=""):
                       moved TOGETHER -- mostly own parameters just under the threshold (2.4e-4 .. 4e-4) acting through
                       the covariates, sometimes no end-of-fit shift at all: under noisy MC gradients the fp32 and the
                       fp64 trajectory of a gene part and re-converge again and again, and the last step is a snapshot
-                      of that process (profiles/r3u_cluster_trajectory_*.json: 10 682 of 20 000 cells at step 1715,
+                      of that process (profiles/history/r3u_cluster_trajectory_*.json: 10 682 of 20 000 cells at step 1715,
                       0 at step 4949, 190 at the end);
       moved gene = displaced or clustered;  quiet gene = moved in NEITHER run.
       1. genes:    #moved(hip) <= 1.5 #moved(o32) + max(3, 1 % of the genes);

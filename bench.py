@@ -405,7 +405,7 @@ def main(argv=None):
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-psi-check", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args(argv)
     # RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this driver (exported on the pool already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

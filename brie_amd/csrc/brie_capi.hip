@@ -1682,6 +1682,15 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     int rc = probe_rate(h, iters, &best);
     if (rc != BRIE_OK) return rc;
     h->placement_tries = 1; h->placement_kept = 0; h->placement_gbs[0] = best;
+    static const bool log_sets = getenv("BRIE_PLACEMENT_LOG") != nullptr;      // experiments: where every set lives
+    auto log_set = [&](int t, double rate) {
+        if (!log_sets) return;
+        const StreamedSet s = streamed_set(h);
+        fprintf(stderr, "[brie placement] set %d  %.1f GB/s ", t, rate);
+        for (int i = 0; i < s.n; ++i) fprintf(stderr, " %p(+%zu)", s.p[i], s.bytes[i]);
+        fprintf(stderr, "\n");
+    };
+    log_set(0, best);
     // every set that lost stays allocated until the search is over: a set that is freed is what the next hipMalloc
     // hands out again (call r4a: three slow sets in a row whenever the loser was freed first)
     std::vector<StreamedSet> losers;
@@ -1710,6 +1719,7 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
         rc = probe_rate(h, iters, &r);
         h->placement_gbs[t] = r;
         h->placement_tries = t + 1;
+        log_set(t, r);
         const bool better = rc == BRIE_OK && r > best;
         if (better) { best = r; h->placement_kept = t; }
         else adopt_set(h, cur);
@@ -2486,26 +2496,9 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     a.n4 = bytes_per_stream / 16;
     std::vector<void *> bufs;
     auto cleanup = [&]() { for (void *q : bufs) hipFree(q); };
-    const char *il = getenv("BRIE_CALIB_INTERLEAVE");          // "1": all streams interleaved in one buffer (StreamArgs)
-    const char *ct = getenv("BRIE_CALIB_CONTIGUOUS");          // "1": physically contiguous buffers
-    auto alloc = [&](void **q, size_t bytes) {
-        if (ct && ct[0] == '1') return hipExtMallocWithFlags(q, bytes, hipDeviceMallocContiguous);
-        return dev_alloc(q, bytes);
-    };
-    if (il && il[0] == '1') {
-        a.n4 = (a.n4 / 64) * 64;
-        void *q = nullptr;
-        const size_t bytes = static_cast<size_t>(n_read + n_write) * a.n4 * 16;
-        if (alloc(&q, bytes) != hipSuccess) return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer");
-        hipMemset(q, 0, bytes);
-        bufs.push_back(q);
-        for (int i = 0; i < n_read; ++i) a.in[i] = static_cast<const float *>(q);
-        for (int i = 0; i < n_write; ++i) a.out[i] = static_cast<float *>(q);
-        a.ns_interleave = n_read + n_write;
-    } else
     for (int i = 0; i < n_read + n_write; ++i) {
         void *q = nullptr;
-        if (alloc(&q, a.n4 * 16) != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer"); }
+        if (dev_alloc(&q, a.n4 * 16) != hipSuccess) { cleanup(); return fail(BRIE_ERR_HIP, "hipMalloc calibration buffer"); }
         hipMemset(q, 0, a.n4 * 16);
         bufs.push_back(q);
         if (i < n_read) a.in[i] = static_cast<const float *>(q); else a.out[i - n_read] = static_cast<float *>(q);
@@ -2518,10 +2511,7 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
     // three depths of loads in flight per thread (1, 2, 4 vectors x n_read streams); the best one is reported
     float ms = 0.f;
     hipError_t e = hipSuccess;
-    const char *only_env = getenv("BRIE_CALIB_VARIANT");      // experiments: time one variant (1, 2 or 4) only
-    const int only = only_env ? atoi(only_env) : 0;
     for (int unroll = 1; unroll <= 4 && e == hipSuccess; unroll *= 2) {
-        if (only && unroll != only) continue;
         for (int it = -2; it < iters; ++it) {
             if (it == 0) hipEventRecord(e0, nullptr);
 #define BRIE_SM2(NR, NW, U)                                                                               \

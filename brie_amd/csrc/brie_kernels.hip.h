@@ -2117,13 +2117,8 @@ struct StreamArgs {
     const float *in[12];
     float *out[12];
     int64_t n4;          // float4 elements per stream
-    // > 0: all streams live in ONE buffer, interleaved in 1-KiB pieces (piece p of stream s at ((p * ns + s) * 64) float4) --
-    // the layout question of DESIGN 4.3a: are 14 separate arrays slower than one array of 14-KiB rows?
-    int32_t ns_interleave;
 };
-__device__ __forceinline__ int64_t sm_at(const StreamArgs &a, int s, int64_t i) {
-    return a.ns_interleave ? ((((i >> 6) * a.ns_interleave + s) << 6) | (i & 63)) : i;
-}
+__device__ __forceinline__ int64_t sm_at(const StreamArgs &, int, int64_t i) { return i; }
 template <int NR, int NW, bool NT, int U = 1>
 __global__ __launch_bounds__(kBlock) void stream_mix(const StreamArgs a) {
     // U independent 16-B vectors per thread and iteration, all NR*U loads issued before the first store

@@ -8,7 +8,8 @@ Three runs of every case of profiles/psi_delta.py::CASES on the same problem, in
   hip   libbrie_amd.so
 and two comparisons, each reduced to PER-GENE summaries (tests/util.py::gene_summaries):
   null = o32b vs o32   (CPU only:  python profiles/psi_null.py --null --cases ...   -> profiles/psi_null/<case>_null.npz)
-  hip  = hip  vs o32   (GPU box:   python profiles/psi_null.py --hip  --cases ...   -> gpurun_out/psi_null/<case>_hip.npz)
+  hip  = hip  vs o32   (GPU box:   python profiles/psi_null.py --hip  --cases ...   -> gpurun_out/psi_null/<case>_hip.npz,
+                        committed as profiles/psi_null_hip/<case>_hip.npz)
 --evaluate applies tests/util.py::psi_null_rule to every case that has both and writes profiles/psi_null_r04.json.
 --fixture CASE:N writes tests/golden/psi_null_<case>_first<N>.npz: the o32 Psi and parameters of the first N genes
 (genes are independent and the noise is keyed by the global gene index, so the slice is exact for those genes) plus
@@ -31,14 +32,16 @@ sys.path.insert(0, os.path.join(ROOT, "profiles"))
 import psi_delta as pd                                      # noqa: E402  (CASES, problem(), schedule(), the o32 cache)
 
 NULL_DIR = os.path.join(ROOT, "profiles", "psi_null")
-HIP_DIR = os.path.join(ROOT, "gpurun_out", "psi_null")
+HIP_DIR = os.path.join(ROOT, "gpurun_out", "psi_null")        # written on the GPU box, merged back by gpurun
+HIP_KEPT = os.path.join(ROOT, "profiles", "psi_null_hip")      # ... and committed from there
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 SUMMARY_KEYS = ("shift", "n_gt", "max", "hist", "Nc")
 
 
-def run_o32b(case):
-    """Psi and per-gene parameters of the o32b build after the case's full schedule (cached next to the o32 cache)."""
-    path = os.path.join(pd.CACHE, "%s_float32b.npz" % case)
+def run_o32b(case, tag=""):
+    """Psi and per-gene parameters of the o32b build after the case's full schedule (cached next to the o32 cache).
+    `tag`: a further draw of the null (e.g. another OpenMP thread count = another association of the per-thread sums)."""
+    path = os.path.join(pd.CACHE, "%s_float32b%s.npz" % (case, tag))
     if os.path.exists(path):
         z = np.load(path)
         return {k: z[k] for k in pd.PARAMS + ("psi",)}
@@ -69,12 +72,12 @@ def load_summary(path):
     return s
 
 
-def null_case(case):
+def null_case(case, tag=""):
     from tests import util
     o32 = pd.run_oracle(case, np.float32, want_params=True)
-    b = run_o32b(case)
+    b = run_o32b(case, tag)
     s = util.gene_summaries(b["psi"], o32["psi"], pd.util_params(b), pd.util_params(o32))
-    save_summary(os.path.join(NULL_DIR, "%s_null.npz" % case), s)
+    save_summary(os.path.join(NULL_DIR, "%s_null%s.npz" % (case, tag)), s)
     print("null %-16s moved-by-shift %d  entries > 1e-4: %d  max %.3g" % (
         case, int((s["shift"] > util.GENE_SHIFT).sum()), int(s["n_gt"].sum()), float(s["max"].max())), flush=True)
 
@@ -138,11 +141,22 @@ def evaluate(cases, out):
     tot = {"displaced": [0, 0], "clustered": [0, 0], "quiet_entries_gt_1e-4": [0, 0]}
     for case in cases:
         fn, fh = os.path.join(NULL_DIR, "%s_null.npz" % case), os.path.join(HIP_DIR, "%s_hip.npz" % case)
+        if not os.path.exists(fh):                      # the committed copy of an earlier GPU call
+            fh = os.path.join(HIP_KEPT, "%s_hip.npz" % case)
         if not (os.path.exists(fn) and os.path.exists(fh)):
             continue
         c = pd.CASES[case]
         rep = util.psi_null_rule(load_summary(fh), load_summary(fn), case, check=False)
         rep["desc"] = c["desc"]
+        extra = sorted(f for f in os.listdir(NULL_DIR) if f.startswith(case + "_null_") and f.endswith(".npz"))
+        if extra:                   # further draws of the null: the spread of the yardstick itself (reported, not used by the rule)
+            rep["further_null_draws"] = {}
+            for f in extra:
+                r2 = util.psi_null_rule(load_summary(fh), load_summary(os.path.join(NULL_DIR, f)), case, check=False)
+                rep["further_null_draws"][f[len(case) + 6:-4]] = {
+                    "holds_against_this_draw": r2["holds"], "displaced_genes": r2["displaced_genes"]["o32b_vs_o32"],
+                    "clustered_genes": r2["clustered_genes"]["o32b_vs_o32"],
+                    "quiet_gt_1e-4": r2.get("quiet_genes", {}).get("gt_1e-4")}
         rep["steps"], rep["MC_size"] = 6 * int(c["min_iter"] / 6), c["MC"]
         result["cases"][case] = rep
         for k, key in (("displaced", "displaced_genes"), ("clustered", "clustered_genes")):
@@ -168,6 +182,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", default=",".join(pd.R03 + pd.HELD_OUT + pd.HELD_OUT_2))
     ap.add_argument("--null", action="store_true")
+    ap.add_argument("--null-tag", default="", help="suffix of a further null draw (run with another OMP_NUM_THREADS)")
     ap.add_argument("--hip", action="store_true")
     ap.add_argument("--evaluate", action="store_true")
     ap.add_argument("--fixture", default=None, metavar="CASE:N")
@@ -176,7 +191,7 @@ def main():
     cases = [c for c in args.cases.split(",") if c]
     if args.null:
         for case in cases:
-            null_case(case)
+            null_case(case, args.null_tag)
     if args.hip:
         for case in cases:
             hip_case(case)

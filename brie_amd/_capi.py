@@ -31,7 +31,7 @@ EXPORTS = [
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
-    "brie_placement_probe", "brie_placement_tune", "brie_placement_info",
+    "brie_placement_probe", "brie_placement_tune", "brie_placement_info", "brie_probe_layouts",
 ]
 COMM_ID_BYTES = 128
 #: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
@@ -128,6 +128,7 @@ def load_library(path=None):
     lib.brie_reconfigure.argtypes = [vp, i32, ctypes.c_uint64, i32, i32]
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
+    lib.brie_probe_layouts.argtypes = [i32, i64, i64, i64, i32, vp, i32, vp]
     lib.brie_placement_probe.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_placement_tune.argtypes = [vp, i32, ctypes.c_double]
     lib.brie_placement_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double),
@@ -259,6 +260,16 @@ def host_convert_u16(a):
     _check(lib, lib.brie_host_convert_u16(a.ctypes.data_as(ctypes.c_void_p), a.shape[0], a.shape[1], a.strides[0] // 4,
                                           out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(flag)))
     return out, bool(flag.value)
+
+
+def probe_layouts(Nc, Ng, slab_bytes, offsets, iters=3, device=0):
+    """GB/s of the placement probe for every row of `offsets` (n_layouts, 8) inside ONE slab (brie_probe_layouts)."""
+    lib = load_library()
+    off = np.ascontiguousarray(offsets, np.int64).reshape(-1, 8)
+    out = np.zeros(off.shape[0], np.float64)
+    _check(lib, lib.brie_probe_layouts(int(device), int(Nc), int(Ng), int(slab_bytes), off.shape[0], off.ctypes.data, int(iters),
+                                       out.ctypes.data))
+    return out
 
 
 def host_convert_slab(a):

@@ -1675,6 +1675,8 @@ double g_place_best[64] = {};
 
 int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     if (max_tries > 4) max_tries = 4;
+    // BRIE_PLACEMENT_INTERLEAVE=0: candidate sets one after the other, each allocated as a block (A/B runs; the first version)
+    static const bool interleave = [] { const char *e = getenv("BRIE_PLACEMENT_INTERLEAVE"); return !(e && e[0] == '0'); }();
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(h->stream));
     const int iters = 3;
@@ -1691,43 +1693,57 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
         fprintf(stderr, "\n");
     };
     log_set(0, best);
-    // every set that lost stays allocated until the search is over: a set that is freed is what the next hipMalloc
-    // hands out again (call r4a: three slow sets in a row whenever the loser was freed first)
-    std::vector<StreamedSet> losers;
-    for (int t = 1; t < max_tries && best < good_gbs; ++t) {
-        StreamedSet cur = streamed_set(h), alt;
-        size_t total = 0;
-        for (int i = 0; i < cur.n; ++i) total += cur.bytes[i];
+    const StreamedSet first = streamed_set(h);
+    size_t total = 0;
+    for (int i = 0; i < first.n; ++i) total += first.bytes[i];
+    // Candidate sets.  Arrays that lie next to each other in physical memory stream slower than arrays that lie far apart
+    // (one slab, the same memory, calls r4k / r4l: packed 5.2 TB/s, the same arrays 18 GB apart 6.3 TB/s in every process),
+    // and a block of fresh allocations is handed out back to back.  So the candidates are allocated INTERLEAVED -- array 0
+    // of every candidate, then array 1 of every candidate, ... -- which puts the arrays of one set a few arrays apart at no
+    // cost; every candidate is probed and all but the fastest set are freed when the search is over (a set that is freed
+    // early is what the next hipMalloc hands out again, call r4a).
+    int n_cand = 0;
+    if (best < good_gbs && max_tries > 1) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if (free_b < total + (size_t(2) << 30)) break;             // no room for another set: keep what there is
-        alt.n = cur.n;
-        hipError_t e = hipSuccess;
-        for (int i = 0; i < cur.n && e == hipSuccess; ++i) {
-            alt.bytes[i] = cur.bytes[i];
-            e = hipMalloc(&alt.p[i], cur.bytes[i]);                // plain: the block cache may hold the LAST placement
-            if (e == hipSuccess) e = hipMemcpyAsync(alt.p[i], cur.p[i], cur.bytes[i], hipMemcpyDeviceToDevice, h->stream);
-        }
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipStreamSynchronize(h->stream);
-            for (int i = 0; i < alt.n; ++i) if (alt.p[i]) (void)hipFree(alt.p[i]);
-            break;
-        }
-        adopt_set(h, alt);
+        n_cand = max_tries - 1;
+        while (n_cand > 0 && free_b < static_cast<size_t>(n_cand) * total + (size_t(2) << 30)) --n_cand;   // what fits
+    }
+    std::vector<StreamedSet> cand(static_cast<size_t>(n_cand));
+    auto drop = [](StreamedSet &s) { for (int i = 0; i < s.n; ++i) if (s.p[i]) { (void)hipFree(s.p[i]); s.p[i] = nullptr; } };
+    hipError_t e = hipSuccess;
+    for (StreamedSet &c : cand) { c.n = first.n; for (int i = 0; i < first.n; ++i) c.bytes[i] = first.bytes[i]; }
+    if (interleave) {
+        for (int i = 0; i < first.n && e == hipSuccess; ++i)
+            for (int k = 0; k < n_cand && e == hipSuccess; ++k) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
+    } else {
+        for (int k = 0; k < n_cand && e == hipSuccess; ++k)
+            for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
+    }
+    if (e != hipSuccess) {                       // out of memory half way: search among what is complete (nothing, usually)
+        (void)hipGetLastError();
+        for (StreamedSet &c : cand) drop(c);
+        n_cand = 0;
+    }
+    int kept = -1;                               // index into cand, -1 = the first set
+    for (int k = 0; k < n_cand && rc == BRIE_OK; ++k) {
+        if (best >= good_gbs) break;                                // good enough: the remaining candidates are not needed
+        for (int i = 0; i < first.n && e == hipSuccess; ++i)
+            e = hipMemcpyAsync(cand[k].p[i], first.p[i], first.bytes[i], hipMemcpyDeviceToDevice, h->stream);
+        if (e != hipSuccess) { rc = fail(BRIE_ERR_HIP, "placement copy: %s", hipGetErrorString(e)); break; }
+        adopt_set(h, cand[k]);
         double r = 0.0;
         rc = probe_rate(h, iters, &r);
-        h->placement_gbs[t] = r;
-        h->placement_tries = t + 1;
-        log_set(t, r);
-        const bool better = rc == BRIE_OK && r > best;
-        if (better) { best = r; h->placement_kept = t; }
-        else adopt_set(h, cur);
-        losers.push_back(better ? cur : alt);
-        if (rc != BRIE_OK) break;
+        h->placement_gbs[k + 1] = r;
+        h->placement_tries = k + 2;
+        log_set(k + 1, r);
+        if (rc == BRIE_OK && r > best) { best = r; kept = k; h->placement_kept = k + 1; }
     }
-    for (const StreamedSet &drop : losers)
-        for (int i = 0; i < drop.n; ++i) (void)hipFree(drop.p[i]);
+    adopt_set(h, kept < 0 ? first : cand[kept]);
+    (void)hipStreamSynchronize(h->stream);
+    for (int k = 0; k < n_cand; ++k)
+        if (k != kept) drop(cand[k]);
+    if (kept >= 0) { StreamedSet f = first; drop(f); }
     if (rc != BRIE_OK) return rc;
     {
         std::lock_guard<std::mutex> l(g_place_mu);
@@ -1740,7 +1756,8 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
 }
 
 // automatic tuning before the first step of a handle whose step streams >= 256 MiB.  BRIE_PLACEMENT_TRIES = n (1 = off,
-// default 3); BRIE_PLACEMENT_GOOD_GBS = the rate at which no further set is tried.  Default 6050: over 26 handles of
+// default 4: the first set + three interleaved candidates); BRIE_PLACEMENT_GOOD_GBS = the rate at which no further set
+// is tried.  Default 6050: over 26 handles of
 // configs[1] / configs[2] in four processes (profiles/r4a_placement_c{2,3}.jsonl) the probe -- whose rate equals the step
 // kernel's to 1 %, correlation 0.999 at configs[2] -- read 4.93 - 5.30 TB/s in the slow mode, 5.49 - 5.94 in between and
 // 6.0 - 6.24 in the fast one; or 0.97 x the best rate a handle of this process has reached on the device if higher.
@@ -1748,7 +1765,7 @@ constexpr double kPlacementGoodGBs = 6050.0;
 int auto_placement(brie_handle *h) {
     if (h->placement_done) return BRIE_OK;
     h->placement_done = true;
-    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 3; }();
+    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 4; }();
     if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) return BRIE_OK;
     static const double good_env = [] { const char *e = getenv("BRIE_PLACEMENT_GOOD_GBS"); return e ? atof(e) : 0.0; }();
     double good = good_env > 0.0 ? good_env : kPlacementGoodGBs;
@@ -2478,6 +2495,56 @@ int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, dou
     if (kept) *kept = h->placement_kept;
     if (gbs) for (int i = 0; i < 4; ++i) gbs[i] = h->placement_gbs[i];
     if (seconds) *seconds = h->placement_seconds;
+    return BRIE_OK;
+}
+
+// Experiment aid (no reference counterpart): ONE slab, the eight streamed arrays of a 2-layer u8 problem carved out of it at
+// caller-given byte offsets, the placement probe timed for each of `n_layouts` offset sets -- does the RELATIVE spacing of the
+// arrays decide the streaming rate, the physical memory being the same?  offsets: n_layouts x 8 (six state arrays, two u8
+// count layers), each + its array inside slab_bytes.  gbs: n_layouts rates (storage bytes of a step / probe time).
+int brie_probe_layouts(int32_t device, int64_t Nc, int64_t Ng, int64_t slab_bytes, int32_t n_layouts, const int64_t *offsets,
+                       int32_t iters, double *gbs) {
+    if (!offsets || !gbs || n_layouts < 1 || iters < 1 || Nc <= 0 || Ng <= 0) return fail(BRIE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t ld = round_up(Ng, brie::kGenesPerBlock);
+    const int64_t mat = Nc * ld * 4, cnt = Nc * ld;
+    for (int i = 0; i < n_layouts * 8; ++i) {
+        const int64_t need = offsets[i] + ((i % 8) < 6 ? mat : cnt);
+        if (offsets[i] < 0 || offsets[i] % 16 != 0 || need > slab_bytes) return fail(BRIE_ERR_INVALID, "offset %d outside the slab", i);
+    }
+    char *slab = nullptr;
+    HIP_TRY(dev_alloc(&slab, static_cast<size_t>(slab_bytes)));
+    hipError_t e = hipMemset(slab, 0, static_cast<size_t>(slab_bytes));
+    brie::StepScalars a{};
+    a.ld = ld; a.row_stride = brie::kGenesPerBlock; a.gb_stride = Nc * brie::kGenesPerBlock;
+    a.Nc = static_cast<int32_t>(Nc); a.Ng = static_cast<int32_t>(Ng);
+    int rpc = 256;
+    while (rpc > 16 && (Nc + rpc - 1) / rpc < 128) rpc /= 2;
+    a.rows_per_chunk = rpc;
+    const dim3 grid(static_cast<unsigned>(ld / brie::kGenesPerBlock), static_cast<unsigned>((Nc + rpc - 1) / rpc)), block(brie::kBlock);
+    const int pad = 81 * 1024;
+    auto kern = brie::placement_probe<brie::kCountU8, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int l = 0; l < n_layouts && e == hipSuccess; ++l) {
+        const int64_t *o = offsets + 8 * l;
+        float *st[6];
+        for (int i = 0; i < 6; ++i) st[i] = reinterpret_cast<float *>(slab + o[i]);
+        for (int it = -1; it < iters; ++it) {
+            if (it == 0) hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(kern, grid, block, pad, nullptr, slab + o[6], slab + o[7], static_cast<const void *>(nullptr), st[0],
+                               st[1], st[2], st[3], st[4], st[5], a, 0u, static_cast<uint32_t *>(nullptr));
+        }
+        hipEventRecord(e1, nullptr);
+        e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        gbs[l] = static_cast<double>(Nc) * Ng * 50.0 * iters / (ms * 1e-3) / 1e9;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(slab);
+    if (e != hipSuccess) return fail(BRIE_ERR_HIP, "layout probe: %s", hipGetErrorString(e));
     return BRIE_OK;
 }
 

@@ -304,15 +304,17 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
 
 /* Placement of the streamed arrays (no reference counterpart; the reference leaves memory to TensorFlow).  How fast a
  * handle's step kernel streams depends on where the allocator put its arrays: byte-identical code on identical data runs
- * at one of two speeds 10 - 20 % apart.  The library therefore measures: a probe kernel with the
- * step kernel's traffic and no effect on the data is timed on the handle's arrays; while its rate (GB/s of
- * brie_step_storage_bytes) is below `good_gbs` and HBM has room, a further set of arrays is allocated while the current
- * one is still held, filled by device-to-device copies, probed, and the faster set is kept (results are bit-identical:
- * only addresses change; sets that lost are freed when the search is over).  brie_step does this by itself before the
- * first step of a handle that streams >= 256 MiB per step: up to BRIE_PLACEMENT_TRIES sets (default 3; 1 = off), good_gbs
- * = BRIE_PLACEMENT_GOOD_GBS (default 6050, or 0.97 x the best rate a handle of this process has reached on the device
- * when that is higher).  Typical cost at configs[2]: 0.13 s per extra set (26 GB allocated and copied), 3 s when the
- * allocator has a slow moment.
+ * at 8.1 or at 9.5 ms per step at configs[2] -- arrays that lie next to each other in physical
+ * memory stream slower than arrays that lie far apart.  The library therefore measures: a probe kernel with the step
+ * kernel's traffic and no effect on the data is timed on the handle's arrays; if its rate (GB/s of
+ * brie_step_storage_bytes) is below `good_gbs` and HBM has room, up to max_tries - 1 candidate sets are allocated
+ * INTERLEAVED (array 0 of every candidate, then array 1 of every candidate, ...: the arrays of one set end up a few arrays
+ * apart), filled by device-to-device copies and probed until one is good; the fastest set is kept, the others are freed when
+ * the search is over (results are bit-identical: only addresses change).  brie_step does this by itself before the first
+ * step of a handle that streams >= 256 MiB per step: BRIE_PLACEMENT_TRIES sets in all (default 4; 1 = off), good_gbs =
+ * BRIE_PLACEMENT_GOOD_GBS (default 6050, or 0.97 x the best rate a handle of this process has reached on the device when
+ * that is higher).  Typical cost at configs[2]: 0.17 s (three candidates of 26 GB allocated, one or two copied and probed);
+ * 0.8 - 3 s when the allocator has a slow moment.
  *  brie_placement_probe: rate of the probe on the arrays as they are (iters timed launches after one warm-up).
  *  brie_placement_tune : the procedure above on demand, at most max_tries <= 4 sets.
  *  brie_placement_info : sets probed so far, which one is in use (0 = the original), their rates (gbs[4]) and the
@@ -320,6 +322,13 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
 int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs);
 int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs);
 int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds);
+
+/* Experiment aid: one slab of slab_bytes, the eight streamed arrays of a 2-layer u8-count problem of (Nc, Ng) placed at the
+ * caller's byte offsets (offsets[n_layouts][8]: six state arrays, two count layers; multiples of 16), the placement probe
+ * timed for every layout on the SAME physical memory -> gbs[n_layouts].  Separates "where the memory is" from "how the
+ * arrays are spaced" (profiles/layout_probe.py). */
+int brie_probe_layouts(int32_t device, int64_t Nc, int64_t Ng, int64_t slab_bytes, int32_t n_layouts, const int64_t *offsets,
+                       int32_t iters, double *gbs);
 
 /* Free / total HBM of a device in bytes (hipMemGetInfo).  fitBRIE uses it to split a gene range that does not
  * fit into sequential super-batches -- the role of the reference's batch_size (model_wrap.py:241-260), sized for

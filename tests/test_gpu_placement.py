@@ -74,7 +74,7 @@ def test_the_first_step_of_a_large_handle_searches_by_itself(lib):
     b.placement_tune(1, 0.0)
     ta, tb = a.step(3, 0.01, 1), b.step(3, 0.01, 1)
     info = a.placement_info()
-    assert 1 <= info["tries"] <= 3 and info["GBs"][info["kept"]] == max(info["GBs"])
+    assert 1 <= info["tries"] <= 4 and info["GBs"][info["kept"]] == max(info["GBs"])
     assert np.array_equal(ta, tb)
     assert np.array_equal(a.read(_capi.PSI), b.read(_capi.PSI))
     n = a.placement_info()["tries"]

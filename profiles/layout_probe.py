@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--nc", type=int, default=50000)
     ap.add_argument("--ng", type=int, default=20000)
+    ap.add_argument("--scan", type=int, default=0, help="GB: the third experiment, one packed set moved through a slab of this size")
+    ap.add_argument("--scan-step", type=int, default=8)
     ap.add_argument("--spread", type=int, default=0, help="GB: the second experiment, arrays spread over a slab of this size")
     args = ap.parse_args()
     from brie_amd import _capi
@@ -85,11 +87,22 @@ def main():
         layouts["only_counts_far"][7] += 100 * GB
         layouts["only_mu_far"] = pack(S)
         layouts["only_mu_far"][0] += 100 * GB
+    if args.scan:
+        # third experiment: ONE packed set moved through the slab -- which regions are slow?
+        GB = 1 << 30
+        layouts = {}
+        span = 6 * S + 2 * up(cnt, 2 * MB)
+        x = 0
+        while x * GB + span + 64 * MB < args.scan * GB:
+            layouts["packed_at_%03dGB" % x] = pack(S, start=x * GB)
+            x += args.scan_step
     names = list(layouts)
     off = np.array([layouts[n] for n in names], np.int64)
     slab = int(off.max() + mat + 64 * MB)
     if args.spread:
         slab = max(slab, args.spread << 30)
+    if args.scan:
+        slab = max(slab, args.scan << 30)
     for r in range(args.rounds):
         g = _capi.probe_layouts(Nc, Ng, slab, off, iters=3)
         print(json.dumps({"pid": os.getpid(), "round": r, "slab_GB": round(slab / 1e9, 1),

@@ -82,3 +82,21 @@ def test_the_first_step_of_a_large_handle_searches_by_itself(lib):
     assert a.placement_info()["tries"] == n   # once per handle
     a.close()
     b.close()
+
+
+def test_layout_probe_times_given_layouts_inside_one_slab(lib):
+    """brie_probe_layouts (the experiment aid behind DESIGN 4.3: the same memory, the arrays carved out at given offsets):
+    one rate per layout, offsets checked against the slab."""
+    from brie_amd import _capi
+    Nc, Ng = 4000, 1024
+    ld = 1024
+    mat, cnt = Nc * ld * 4, Nc * ld
+    packed = [i * mat for i in range(6)] + [6 * mat, 6 * mat + cnt]
+    apart = [i * (mat + (8 << 20)) for i in range(6)] + [6 * (mat + (8 << 20)), 7 * (mat + (8 << 20))]
+    slab = 8 * (mat + (8 << 20))
+    g = _capi.probe_layouts(Nc, Ng, slab, [packed, apart], iters=2)
+    assert g.shape == (2,) and (g > 0).all()
+    with pytest.raises((ValueError, _capi.BrieError)):
+        _capi.probe_layouts(Nc, Ng, slab, [[slab] * 8])                 # outside the slab
+    with pytest.raises((ValueError, _capi.BrieError)):
+        _capi.probe_layouts(Nc, Ng, slab, [[8] * 8])                    # not 16-byte aligned

@@ -26,6 +26,8 @@ def wide_shapes(n, seed):
         kind = ["plain", "plain", "wide", "cell", "xg", "fixed", "margin", "wide_cell", "wide_xg"][i % 9]
         L = int(rng.choice([2, 3]))
         Kc = int(rng.integers(9, 65)) if kind.startswith("wide") else int(rng.integers(0, 9))
+        if kind.startswith("wide") and rng.random() < 0.25:
+            Kc = int(rng.integers(65, 161))                  # very wide designs: 64-feature panels (round 4)
         Kg = int(rng.integers(1, 65)) if kind.endswith("xg") else 0
         out.append((5000 + i, kind, int(rng.integers(1, 521)), int(rng.integers(1, 1101)), Kc, Kg, L,
                     int(rng.choice([1, 2, 3, 5])), bool(L == 3 or rng.random() < 0.3)))

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--nc", type=int, default=50000)
     ap.add_argument("--ng", type=int, default=20000)
+    ap.add_argument("--small", type=int, default=0, help="GB: the fourth experiment, a small set inside a slab of this size")
     ap.add_argument("--scan", type=int, default=0, help="GB: the third experiment, one packed set moved through a slab of this size")
     ap.add_argument("--scan-step", type=int, default=8)
     ap.add_argument("--spread", type=int, default=0, help="GB: the second experiment, arrays spread over a slab of this size")
@@ -96,6 +97,20 @@ def main():
         while x * GB + span + 64 * MB < args.scan * GB:
             layouts["packed_at_%03dGB" % x] = pack(S, start=x * GB)
             x += args.scan_step
+    if args.small:
+        # fourth experiment: a SMALL set (configs[1]: 0.2-GB arrays) inside a slab of args.small GB: how far apart must its arrays lie?
+        GB = 1 << 30
+        c2 = up(cnt, 2 * MB)
+        layouts = {}
+        for start in (0, 20, 40):
+            layouts["packed_at_%dGB" % start] = pack(S, start=start * GB)
+        for pitch_gb in (0.5, 1, 2, 3, 4, 5, 6, 7, 8):
+            pitch = int(pitch_gb * GB)
+            layouts["pitch_%sGB" % pitch_gb] = [i * pitch for i in range(8)]
+        layouts["two_groups_16GB"] = [0, S, 2 * S, 16 * GB, 16 * GB + S, 16 * GB + 2 * S, 3 * S, 16 * GB + 3 * S]
+        layouts["two_groups_32GB"] = [0, S, 2 * S, 32 * GB, 32 * GB + S, 32 * GB + 2 * S, 3 * S, 32 * GB + 3 * S]
+        layouts["two_groups_48GB"] = [0, S, 2 * S, 48 * GB, 48 * GB + S, 48 * GB + 2 * S, 3 * S, 48 * GB + 3 * S]
+        layouts["three_groups_20GB"] = [0, S, 20 * GB, 20 * GB + S, 40 * GB, 40 * GB + S, 2 * S, 20 * GB + 2 * S]
     names = list(layouts)
     off = np.array([layouts[n] for n in names], np.int64)
     slab = int(off.max() + mat + 64 * MB)
@@ -103,6 +118,8 @@ def main():
         slab = max(slab, args.spread << 30)
     if args.scan:
         slab = max(slab, args.scan << 30)
+    if args.small:
+        slab = max(slab, args.small << 30)
     for r in range(args.rounds):
         g = _capi.probe_layouts(Nc, Ng, slab, off, iters=3)
         print(json.dumps({"pid": os.getpid(), "round": r, "slab_GB": round(slab / 1e9, 1),

@@ -241,6 +241,10 @@ def psi_null_rule(h, n, what="", check=True):
            "largest_gene_shift": {"hip_vs_o32": float(h["shift"].max()), "o32b_vs_o32": float(n["shift"].max())},
            "all_entries_gt_1e-4": {"hip_vs_o32": int(h["n_gt"].sum()), "o32b_vs_o32": int(n["n_gt"].sum())},
            "all_entries_max": {"hip_vs_o32": float(h["max"].max()), "o32b_vs_o32": float(n["max"].max())}}
+    # reported, not judged: how far the entries of the DISPLACED genes go in either comparison -- a displaced
+    # gene moves all its cells by about sigmoid'(z) x its parameter shift, which rule 5 bounds
+    rep["displaced_genes_worst_entry"] = {"hip_vs_o32": float(h["max"][disp_h].max()) if disp_h.any() else 0.0,
+                                          "o32b_vs_o32": float(n["max"][disp_n].max()) if disp_n.any() else 0.0}
     viol = []
     if not moved_h.sum() <= 1.5 * moved_n.sum() + max(3, 0.01 * Ng):
         viol.append(("moved genes", int(moved_h.sum()), int(moved_n.sum())))

@@ -7,6 +7,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -22,6 +23,7 @@ def main():
     ap.add_argument("--scan", type=int, default=0, help="GB: the third experiment, one packed set moved through a slab of this size")
     ap.add_argument("--scan-step", type=int, default=8)
     ap.add_argument("--spread", type=int, default=0, help="GB: the second experiment, arrays spread over a slab of this size")
+    ap.add_argument("--only", default="", help="comma-separated layout names: time series of a few layouts over many rounds")
     args = ap.parse_args()
     from brie_amd import _capi
     Nc, Ng = args.nc, args.ng
@@ -111,6 +113,15 @@ def main():
         layouts["two_groups_32GB"] = [0, S, 2 * S, 32 * GB, 32 * GB + S, 32 * GB + 2 * S, 3 * S, 32 * GB + 3 * S]
         layouts["two_groups_48GB"] = [0, S, 2 * S, 48 * GB, 48 * GB + S, 48 * GB + 2 * S, 3 * S, 48 * GB + 3 * S]
         layouts["three_groups_20GB"] = [0, S, 20 * GB, 20 * GB + S, 40 * GB, 40 * GB + S, 2 * S, 20 * GB + 2 * S]
+        # what a slab candidate of the product looked like in call r4ac (pieces not 2-MiB aligned, the second group 40 GiB
+        # after the end of the first, both count layers next to the second group), and its variants
+        B = 3 * mat + 40 * GB
+        layouts["product_like_unaligned_40GB"] = [0, mat, 2 * mat, B, B + mat, B + 2 * mat, B + 3 * mat + 2 * MB, B + 3 * mat + 2 * MB + c2]
+        layouts["aligned_40GB_counts_at_B"] = [0, S, 2 * S, 40 * GB, 40 * GB + S, 40 * GB + 2 * S, 40 * GB + 3 * S, 40 * GB + 3 * S + c2]
+        layouts["aligned_32GB_counts_at_B"] = [0, S, 2 * S, 32 * GB, 32 * GB + S, 32 * GB + 2 * S, 32 * GB + 3 * S, 32 * GB + 3 * S + c2]
+        layouts["unaligned_32GB_counts_split"] = [0, mat, 2 * mat, 32 * GB, 32 * GB + mat, 32 * GB + 2 * mat, 3 * mat, 32 * GB + 3 * mat]
+    if args.only:
+        layouts = {n: layouts[n] for n in args.only.split(",")}
     names = list(layouts)
     off = np.array([layouts[n] for n in names], np.int64)
     slab = int(off.max() + mat + 64 * MB)
@@ -122,7 +133,7 @@ def main():
         slab = max(slab, args.small << 30)
     for r in range(args.rounds):
         g = _capi.probe_layouts(Nc, Ng, slab, off, iters=3)
-        print(json.dumps({"pid": os.getpid(), "round": r, "slab_GB": round(slab / 1e9, 1),
+        print(json.dumps({"pid": os.getpid(), "t": round(time.time(), 3), "round": r, "slab_GB": round(slab / 1e9, 1),
                           "GBs": {n: round(float(x), 1) for n, x in zip(names, g)}}), flush=True)
 
 

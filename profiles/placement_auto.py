@@ -44,7 +44,7 @@ def main():
     ms, n = sh.profile_read()
     info = sh.placement_info()
     alg = sh.step_algorithmic_bytes()
-    print(json.dumps({"config": args.config, "pid": os.getpid(), "placement": info, "kernel_ms": round(ms / n, 4),
+    print(json.dumps({"config": args.config, "pid": os.getpid(), "t": round(time.time(), 3), "placement": info, "kernel_ms": round(ms / n, 4),
                       "frac": round(alg / (ms / n * 1e-3) / 8e12, 4), "first_three_steps_s": round(first, 3)}), flush=True)
     sh.close()
 

@@ -54,6 +54,19 @@ def test_probe_and_forced_search_change_nothing_but_addresses(lib, L, storage, b
     tb.append(b.step(5, 0.005, 3))
     assert np.array_equal(np.concatenate(ta), np.concatenate(tb))
     _same(_state(a), _state(b))
+    # per-batch convergence on the moved arrays: freezing packs the active gene quads to the front (the arrays of a state
+    # slab keep their place, the others swap roles with a scratch buffer), un-freezing restores the order
+    mask = np.random.default_rng(3).random(Ng) < 0.4
+    for sh in (a, b):
+        sh.set_gene_mask(mask)
+    ta.append(a.step(3, 0.01, 1))
+    tb.append(b.step(3, 0.01, 1))
+    for sh in (a, b):
+        sh.set_gene_mask(None)
+    ta.append(a.step(2, 0.01, 1))
+    tb.append(b.step(2, 0.01, 1))
+    assert np.array_equal(np.concatenate(ta), np.concatenate(tb))
+    _same(_state(a), _state(b))
     lg_a, lg_b = a.loss_gene(3), b.loss_gene(3)
     assert np.array_equal(lg_a, lg_b)
     assert b.placement_info()["tries"] == 1

@@ -17,7 +17,7 @@ Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
 ABI_VERSION = 2
 MAX_KC = 1024        # 0..8 in registers, 9..64 on the matrix cores inside the streaming pass, beyond in 64-feature panels
-MAX_KG = 64
+MAX_KG = 1024        # 0..4 in registers, 5..64 as a tile in LDS / on the matrix cores, beyond in 64-feature panels
 
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_upload_typed", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",

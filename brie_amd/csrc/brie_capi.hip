@@ -104,7 +104,11 @@ struct brie_handle {
     int target = 0;                 // 0 = "ELBO", 1 = "marginLik" (model_TFProb.py:194-211)
     // wide cell designs (Kc > BRIE_MAX_KC): W tile in LDS for Xc.W, MFMA kernel for Xc^T.r
     bool wide = false;
-    bool vwide = false;             // Kc > BRIE_MAX_KC_WIDE: 64-feature panels (see setup_paths)
+    bool vwide = false;             // Kc > BRIE_MAX_KC_WIDE or Kg > BRIE_MAX_KG_WIDE: 64-feature panels (see setup_paths)
+    bool vgwide = false;            // Kg > BRIE_MAX_KG_WIDE: Wg_loc . Xg^T and r . Xg in panels as well
+    float *Xg_zero = nullptr;       // (4, ld) / (Nc, 4) zeros: what the register slots of the coupled step variant read
+    float *Wg_zero = nullptr;       //   when the gene design goes through the panels
+    int part_kgp = brie::kKgMax;    // pitch of the Wg part of a row chunk (= kgp unless vgwide)
     int kernel_kc = 0;              // KC of the kernel instantiation (0 for wide designs)
     // Wide designs on the matrix cores (brie_tile.hip.h): Kc > 8 and / or Kg > 4 with forward and backward products
     // fused into the streaming pass.  wide_like = the per-gene statistics carry no Xc rows (S = 4), Wc_loc is updated
@@ -282,7 +286,8 @@ int alloc_f32(float **p, size_t elems, hipStream_t s) {
 // decide the kernel family of this handle from (Kc, Kg, layout); called at create and at brie_reconfigure
 void setup_paths(brie_handle *h) {
     const int Kc = h->p.Kc;
-    h->wide = Kc > BRIE_MAX_KC;
+    h->vgwide = h->coupled && h->p.Kg > BRIE_MAX_KG_WIDE;
+    h->wide = Kc > BRIE_MAX_KC || h->vgwide;
     const char *wp = getenv("BRIE_WIDE_PATH");         // "lds": the round-1 LDS-broadcast variants (A/B runs)
     const bool want_tile = !(wp && strcmp(wp, "lds") == 0);
     const int kgp = h->coupled ? h->kgp : 0;
@@ -304,7 +309,9 @@ void setup_paths(brie_handle *h) {
     const int min_kg = mk ? atoi(mk) : 8;
     // Kc > 64 ("very wide"): no single kernel holds the W tile; Xc . Wc_loc and Xc^T . r are formed in 64-feature panels
     // around the LDS-free WIDE variant of the streaming kernel (run_steps, wide_forward_mean, wide_backward)
-    h->vwide = Kc > BRIE_MAX_KC_WIDE;
+    // Kg > 64: the same for the gene design (Wg_loc . Xg^T into the same buffer, r . Xg by gene_design_grad); whatever
+    // cell design stands next to it then goes through the panels too, one family of kernels
+    h->vwide = Kc > BRIE_MAX_KC_WIDE || h->vgwide;
     h->tile = want_tile && !h->vwide && (h->wide || (h->gwide && h->p.Kg >= min_kg)) && h->tile_lds <= 160 * 1024 - 64;
     h->wide_like = h->wide || h->tile;
     h->tile_kcr = kcr ? 4 : 0;
@@ -999,8 +1006,8 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         return fail(BRIE_ERR_INVALID, "bad shape Nc=%lld Ng=%lld", (long long)p->Nc, (long long)p->Ng);
     if (p->Kc < 0 || p->Kc > BRIE_MAX_KC_PANELS)
         return fail(BRIE_ERR_UNSUPPORTED, "Kc=%d outside 0..%d", p->Kc, BRIE_MAX_KC_PANELS);
-    if (p->Kg > BRIE_MAX_KG_WIDE)
-        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG_WIDE);
+    if (p->Kg > BRIE_MAX_KG_PANELS)
+        return fail(BRIE_ERR_UNSUPPORTED, "Kg=%d outside 0..%d", p->Kg, BRIE_MAX_KG_PANELS);
     if (p->Kg < 0) return fail(BRIE_ERR_INVALID, "Kg=%d", p->Kg);
     if (p->intercept_mode != 0 && p->intercept_mode != 1)
         return fail(BRIE_ERR_INVALID, "intercept_mode=%d (0 = gene, 1 = cell)", p->intercept_mode);
@@ -1063,6 +1070,8 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         A(h->cb, nc); A(h->m_cb, nc); A(h->v_cb, nc);
         A(h->clam, nc); A(h->m_clam, nc); A(h->v_clam, nc);
         A(h->rowstat, nc * (h->kgp + 2));
+        h->part_kgp = p->Kg > BRIE_MAX_KG_WIDE ? brie::kKgMax : h->kgp;
+        if (p->Kg > BRIE_MAX_KG_WIDE) { A(h->Xg_zero, vec * brie::kKgMax); A(h->Wg_zero, nc * brie::kKgMax); }
     }
 #undef A
     setup_paths(h);                 // kernel family: register path, LDS-broadcast wide variants, or the MFMA tile kernel
@@ -1080,7 +1089,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     }
     if (h->coupled) {
         float *rp = nullptr;
-        if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * (h->kgp + 2) * p->Nc, h->stream)) != BRIE_OK) {
+        if ((rc = alloc_f32(&rp, static_cast<size_t>(h->gene_blocks) * (h->part_kgp + 2) * p->Nc, h->stream)) != BRIE_OK) {
             drop_failed_create(h);
             return rc;
         }
@@ -1146,7 +1155,7 @@ int brie_destroy(brie_handle *h) {
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
                      h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gpart, h->gene_active,
-                     h->ring_kl, h->ring_ll};
+                     h->ring_kl, h->ring_ll, h->Xg_zero, h->Wg_zero};
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
@@ -1503,7 +1512,8 @@ int64_t brie_step_storage_bytes(const brie_handle *h) {
     // LDS-broadcast wide variants: residual r written by the step, read back by wide_design_grad (the tile kernel keeps it on chip)
     int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
     if (h->vwide) {              // P panels: Xc.Wc_loc written once and re-read / re-written P - 1 times, the step's round trip,
-        const int64_t P = (h->p.Kc + BRIE_MAX_KC_WIDE - 1) / BRIE_MAX_KC_WIDE;     // the residual read by P gradient launches
+        int64_t P = (h->p.Kc + BRIE_MAX_KC_WIDE - 1) / BRIE_MAX_KC_WIDE;           // the residual read by P gradient launches
+        if (h->vgwide) P += (h->kgp + BRIE_MAX_KG_WIDE - 1) / BRIE_MAX_KG_WIDE;     // (+ the panels of the gene design)
         gemm_streams = 4 * (2 * P - 1) + 8 + 4 * P;
     }
     if (h->cs == brie::kCountMixed) {                    // genes of u8 quads move 1 byte per count, of u16 quads 2
@@ -1566,14 +1576,23 @@ int cell_finalize_blocks(const brie_handle *h) {
 
 // Kg > 4, forward only (loss_gene_eval reads it): Mbuf = Wg_loc . Xg^T -- the same (rows x K).(K x genes) product as
 // the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
+// dst (Nc, ld) tiled (+)= Wg_loc . Xg^T, in panels of at most 64 gene features (one panel for Kg <= 64)
+void launch_gw_panels(brie_handle *h, float *dst, bool accumulate) {
+    for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE) {
+        const int kp = std::min(h->kgp - k0, BRIE_MAX_KG_WIDE);
+        hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream,
+                           h->Wg + k0, h->Xg + static_cast<size_t>(k0) * h->ld, dst, static_cast<int>(h->p.Nc),
+                           static_cast<int>(h->p.Ng), kp, h->ld, h->row_stride, h->gb_stride, h->rows_per_chunk,
+                           (accumulate || k0 > 0) ? 1 : 0, h->kgp);
+    }
+}
+
 int gwide_forward_mean(brie_handle *h, bool accumulate) {
     if (!h->Mbuf) {
         HIP_TRY(dev_alloc(&h->Mbuf, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float)));
         HIP_TRY(hipMemsetAsync(h->Mbuf, 0, static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float), h->stream));
     }
-    hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, h->Wg,
-                       h->Xg, h->Mbuf, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->kgp, h->ld, h->row_stride,
-                       h->gb_stride, h->rows_per_chunk, accumulate ? 1 : 0, h->kgp);
+    launch_gw_panels(h, h->Mbuf, accumulate);
     HIP_TRY(hipGetLastError());
     return BRIE_OK;
 }
@@ -1848,9 +1867,12 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     brie::CoupledArgs cp{};
     cp.Xg = h->Xg; cp.Wg = h->Wg; cp.cb = h->cb; cp.clam = h->clam; cp.row_partials = h->row_partials;
     cp.Kg = h->p.Kg; cp.cell_mode = h->cell_mode ? 1 : 0; cp.kgp = h->kgp;
+    if (h->vgwide) {                 // Kg > 64: the gene design is in the prior mean the step reads and in gene_design_grad;
+        cp.Xg = h->Xg_zero; cp.Wg = h->Wg_zero; cp.Kg = 0; cp.kgp = h->part_kgp;   // the step keeps the two per-cell sums
+    }
     // Xg tile (kgp x 256 fp32), re-used by the cross-wave fold of the (Kc + 4) per-gene statistics
-    cfg.gw_lds_bytes = h->gwide ? std::max(h->kgp, (brie::kWavesPerBlock - 1) * h->S) * brie::kGenesPerBlock *
-                                      static_cast<int>(sizeof(float)) : 0;
+    cfg.gw_lds_bytes = (h->gwide && !h->vgwide) ? std::max(h->kgp, (brie::kWavesPerBlock - 1) * h->S) * brie::kGenesPerBlock *
+                                                      static_cast<int>(sizeof(float)) : 0;
     brie::CellFinalizeArgs cf{};
     cf.row_partials = h->row_partials; cf.rowstat = h->rowstat; cf.Wg = h->Wg; cf.m_Wg = h->m_Wg; cf.v_Wg = h->v_Wg;
     cf.cb = h->cb; cf.m_cb = h->m_cb; cf.v_cb = h->v_cb; cf.clam = h->clam; cf.m_clam = h->m_clam; cf.v_clam = h->v_clam;
@@ -1858,6 +1880,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     cf.cell_mode = cp.cell_mode; cf.train_b = h->p.train_intercept; cf.train_lam = h->p.train_sigma;
     cf.phase = split ? 1 : 0;
     cf.kgp = h->kgp;
+    cf.part_kgp = h->part_kgp;
     if (h->rowstat_ext) cf.rowstat = h->rowstat_ext;
 
     brie::FinalizeArgs f{};
@@ -1887,6 +1910,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         h->ring_pos += 1;
         if (h->profiling) HIP_TRY(hipEventRecord(h->ev_pool[h->ev_used++], h->stream));
         if (h->vwide) launch_xw_panels(h, h->Rbuf);   // Kc > 64: the prior mean's Xc . Wc_loc, panel by panel (timed with the step)
+        if (h->vgwide) launch_gw_panels(h, h->Rbuf, h->p.Kc > 0);               // Kg > 64: + Wg_loc . Xg^T
         if (use_tile) launch_tile(h, cfg, q, a, ta);
         else if (simple_margin) launch_margin(h, cfg, q, a);
         else launch_step(h, cfg, q, a, cp);
@@ -1898,6 +1922,14 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                                h->n_chunks, alpha, h->gene_active, h->ld);
         } else if (h->wide_like && h->p.Kc > 0 && (rc = wide_backward(h, alpha)) != BRIE_OK)
             return rc;                            // residual buffer -> G = Xc^T . r (MFMA kernel), Adam on Wc_loc
+        if (h->vgwide) {                          // residual buffer -> the Wg_loc gradient r . Xg, panel by panel, into rowstat
+            const int gblocks = static_cast<int>((h->p.Nc + brie::kWavesPerBlock * brie::kGdgRows - 1) /
+                                                 (brie::kWavesPerBlock * brie::kGdgRows));
+            for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE)
+                hipLaunchKernelGGL(brie::gene_design_grad, dim3(gblocks), dim3(brie::kBlock), 0, h->stream, h->Xg, h->Rbuf,
+                                   cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks,
+                                   std::min(h->kgp - k0, BRIE_MAX_KG_WIDE), k0, h->kgp, h->ld, h->row_stride, h->gb_stride);
+        }
         if (h->coupled && lib_reduce && !split) {
             // gene shard of a coupled fit: local sums -> RCCL all-reduce on this stream -> Adam, all enqueued
             brie::CellFinalizeArgs c1 = cf, c2 = cf;

@@ -1327,22 +1327,28 @@ struct CellFinalizeArgs {
     int32_t phase;              // 0: reduce + Adam; 1: reduce only; 2: Adam only (rowstat given)
     float alpha;
     int32_t kgp;
+    int32_t part_kgp;           // pitch of the Wg part of a row chunk; != kgp (Kg > 64): the chunks carry only the two per-cell
+                                // sums, the Wg_loc gradient was written into rowstat by gene_design_grad
 };
 __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a) {
     const int64_t chunk = static_cast<int64_t>(a.kgp + 2) * a.Nc;
     const int64_t e = blockIdx.x * static_cast<int64_t>(kBlock) + threadIdx.x;
     if (e >= chunk) return;
+    const int64_t n_w = static_cast<int64_t>(a.Nc) * a.kgp;
+    const bool direct = a.part_kgp != a.kgp;
     float t;
-    if (a.phase != 2) {
+    if (a.phase != 2 && !(direct && e < n_w)) {
+        const int64_t pchunk = static_cast<int64_t>(a.part_kgp + 2) * a.Nc;
+        const int64_t pe = direct ? e - n_w + static_cast<int64_t>(a.Nc) * a.part_kgp : e;
         double acc = 0.0;
-        for (int g = 0; g < a.gene_blocks; ++g) acc += static_cast<double>(a.row_partials[g * chunk + e]);
+        for (int g = 0; g < a.gene_blocks; ++g) acc += static_cast<double>(a.row_partials[g * pchunk + pe]);
         t = static_cast<float>(acc);
         a.rowstat[e] = t;
         if (a.phase == 1) return;
     } else {
+        if (a.phase == 1) return;
         t = a.rowstat[e];
     }
-    const int64_t n_w = static_cast<int64_t>(a.Nc) * a.kgp;
     if (e < n_w) {
         if (static_cast<int>(e % a.kgp) < a.Kg) {
             float x = a.Wg[e], m = a.m_Wg[e], v = a.v_Wg[e];
@@ -1362,6 +1368,62 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
         float x = a.clam[i], m = a.m_clam[i], v = a.v_clam[i];
         adam_scalar(x, m, v, t, a.alpha);
         a.clam[i] = x; a.m_clam[i] = m; a.v_clam[i] = v;
+    }
+}
+
+// Kg > 64 ("very wide" gene design): the Wg_loc gradient  G[cell, k] = sum_j r[cell, j] Xg[j, k]  from the residual the
+// WIDE variant of the step left in rbuf, one launch per panel of at most 64 features.  Workgroup = 4 waves x kGdgRows
+// cells each; per gene block the panel's Xg tile (<= 64 x 256 fp32) goes through LDS once for the block's 32 cells, the
+// products are reduced 8 features at a time as in the GW variant of the step (lane l ends with feature 8 (l & 7) + (l >> 3)).
+// Written straight into the [Nc][kgp] part of `rowstat` (what cell_finalize applies Adam to and a gene-sharded fit all-reduces).
+constexpr int kGdgRows = 8;
+__global__ __launch_bounds__(kBlock) void gene_design_grad(const float *Xg, const float *rbuf, float *rowstat, int Nc, int Ng,
+                                                           int gene_blocks, int kp, int k0, int kgp, int64_t ld,
+                                                           int64_t row_stride, int64_t gb_stride) {
+    __shared__ float xlds[kKgWideMax * kGenesPerBlock];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * kWavesPerBlock + w) * kGdgRows;
+    float mine[kGdgRows];
+#pragma unroll
+    for (int i = 0; i < kGdgRows; ++i) mine[i] = 0.0f;
+    for (int gb = 0; gb < gene_blocks; ++gb) {
+        __syncthreads();                                   // the previous gene block's tile has been consumed
+        for (int i = threadIdx.x; i < kp * kGenesPerBlock; i += kBlock)
+            xlds[i] = Xg[static_cast<int64_t>(k0 + i / kGenesPerBlock) * ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
+        __syncthreads();
+        const int64_t base = static_cast<int64_t>(gb) * gb_stride + lane * kVec;
+#pragma unroll
+        for (int i = 0; i < kGdgRows; ++i) {
+            const int r = row0 + i;
+            if (r >= Nc) break;                            // wave-uniform
+            F4 rq = ld4(rbuf + base + static_cast<int64_t>(r) * row_stride);
+#pragma unroll
+            for (int v = 0; v < kVec; ++v)                 // padding genes are not part of a cell's sums
+                rq.v[v] = gb * kGenesPerBlock + lane * kVec + v < Ng ? rq.v[v] : 0.0f;
+            float acc = 0.0f;
+            for (int g = 0; g * 8 < kp; ++g) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    t[q] = 0.0f;
+                    if (g * 8 + q < kp) {
+                        const F4 xk = ld4(xlds + (g * 8 + q) * kGenesPerBlock + lane * kVec);
+#pragma unroll
+                        for (int v = 0; v < kVec; ++v) t[q] = fmaf(rq.v[v], xk.v[v], t[q]);
+                    }
+                }
+                const float c = wave_sum8(t, lane);
+                acc = (lane & 7) == g ? c : acc;
+            }
+            mine[i] += acc;
+        }
+    }
+    const int kf = 8 * (lane & 7) + (lane >> 3);
+#pragma unroll
+    for (int i = 0; i < kGdgRows; ++i) {
+        const int r = row0 + i;
+        if (r < Nc && kf < kp) rowstat[static_cast<int64_t>(r) * kgp + k0 + kf] = mine[i];
     }
 }
 

@@ -12,7 +12,7 @@ Deviations from the reference (documented in DESIGN.md):
  * all genes of a shard are fitted concurrently (the reference loops over
    ~`batch_size/Nc`-gene batches); convergence is decided on the shard's summed
    loss trace, or per reference-sized batch with `conv_batch_genes` (what fitBRIE passes);
- * gene features (`Kg <= 64`) and `intercept_mode='cell'` couple the genes of a fit: a gene shard then
+ * gene features (`Kg <= 1024`) and `intercept_mode='cell'` couple the genes of a fit: a gene shard then
    needs `comm=` for the per-step all-reduce; `target='marginLik'` works for every model variant.
 """
 import time

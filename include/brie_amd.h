@@ -77,7 +77,7 @@ typedef struct brie_problem {
     int64_t gene_offset;      /* global index of the shard's first gene (multiple of 4);
                                  keys the noise stream so results do not depend on sharding */
     int32_t Kc;               /* cell features (0..BRIE_MAX_KC_PANELS) */
-    int32_t Kg;               /* gene features (0..BRIE_MAX_KG_WIDE); > 0 couples the genes of a shard */
+    int32_t Kg;               /* gene features (0..BRIE_MAX_KG_PANELS); > 0 couples the genes of a shard */
     int32_t n_layers;         /* 2 or 3 count layers */
     int32_t has_efflen;       /* 0: 2-category likelihood (model_TFProb.py:162-167);
                                  1: effLen likelihood (model_TFProb.py:168-185) */
@@ -96,6 +96,8 @@ typedef struct brie_problem {
                                      model_TFProb.py:84,122-123; no BASELINE config has more than 5) */
 #define BRIE_MAX_KG 4          /* gene features kept in registers; above: Xg tile in LDS */
 #define BRIE_MAX_KG_WIDE 64
+#define BRIE_MAX_KG_PANELS 1024   /* beyond 64: Wg_loc.Xg^T and r.Xg in panels of 64 features around the streaming kernel, like
+                                     a cell design beyond 64 (the reference has no limit, model_TFProb.py:85,124-125) */
 
 typedef struct brie_handle brie_handle;
 

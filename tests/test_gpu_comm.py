@@ -34,7 +34,7 @@ def test_single_rank_communicator_collectives(lib):
     c.close()
 
 
-@pytest.mark.parametrize("Kg,mode", [(2, 'gene'), (6, 'gene'), (0, 'cell'), (3, 'cell')])
+@pytest.mark.parametrize("Kg,mode", [(2, 'gene'), (6, 'gene'), (0, 'cell'), (3, 'cell'), (70, 'cell')])
 def test_in_library_allreduce_equals_unsharded_coupled_fit(lib, Kg, mode):
     """A handle created as ONE gene shard of a coupled fit (sharded=1) with a communicator attached runs
     local sums -> RCCL all-reduce -> Adam inside brie_step; with a world of one rank that is exactly the

@@ -59,7 +59,7 @@ def _worker(rank, world, port, out_dir, KG):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("KG", [2, 6])          # registers (Kg <= 4) / Xg tile in LDS
+@pytest.mark.parametrize("KG", [2, 6, 70])      # registers (Kg <= 4) / Xg tile in LDS / 64-feature panels
 def test_coupled_gene_shards_world2_match_single_fit(lib, tmp_path, KG):
     from tests import util
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), KG), nprocs=2, join=True)

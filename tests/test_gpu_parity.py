@@ -204,7 +204,7 @@ def test_gene_shard_invariance(lib):
 def test_errors_are_loud(lib):
     from brie_amd import _capi
     with pytest.raises(NotImplementedError):
-        _capi.Shard(10, 10, Kg=65)                                  # more gene features than the LDS tile holds
+        _capi.Shard(10, 10, Kg=1025)                                # more gene features than BRIE_MAX_KG_PANELS
     with pytest.raises(NotImplementedError):
         _capi.Shard(10, 12, intercept_mode=1, gene_offset=4)       # coupled modes cannot be gene-sharded
     with pytest.raises(ValueError):
@@ -668,6 +668,39 @@ def test_very_wide_cell_design_runs_in_panels(lib, Kc, L, MC, mode, Kg):
         np.testing.assert_allclose(sh.read(_capi.WC_LOC), o.Wc_loc, atol=2e-4)
     with pytest.raises(NotImplementedError):
         _capi.Shard(Nc, Ng, 1025)
+    sh.close()
+
+
+@pytest.mark.parametrize("Kg,Kc,L,MC,mode", [(70, 0, 2, 1, "gene"), (96, 3, 2, 2, "cell"), (130, 20, 3, 1, "gene"),
+                                             (65, 70, 2, 1, "cell")])
+def test_very_wide_gene_design_runs_in_panels(lib, Kg, Kc, L, MC, mode):
+    """Kg > 64 (the reference has no limit, model_TFProb.py:85,124-125): Wg_loc.Xg^T joins the prior mean panel by panel,
+    the Wg_loc gradient r.Xg is formed from the step's residual panel by panel (a ragged last panel at Kg = 130 and 65;
+    next to no / a narrow / a wide / a very wide cell design; per-cell intercepts).  Same oracle and bounds as Kg <= 64."""
+    from brie_amd import _capi
+    Nc, Ng = 150, 600
+    P = util.problem(Nc, Ng, Kc, L, seed=163)
+    if Kc > 8:
+        P["Xc"] = (P["Xc"] * 0.2).astype(np.float32)
+    P["Xg"] = (np.random.default_rng(11).standard_normal((Ng, Kg)) * 0.3).astype(np.float32)
+    o = util.oracle_model(P, Nc, Ng, Kc, 71, np.float32, Kg=Kg, mode=mode)
+    sh = util.device_shard(P, Nc, Ng, Kc, 71, Kg=Kg, mode=mode)
+    s0 = util.device_state(sh)
+    for k in util.STATE_KEYS:
+        assert util.max_abs_diff(s0[k], getattr(o, k)) < 2e-6, k
+    tr_o = o.minimize(P["counts_pc"], P["Xc"], 6, 0.01, MC)
+    tr_d = sh.step(6, 0.01, MC)
+    np.testing.assert_allclose(tr_d, tr_o, rtol=3e-5)
+    assert_states_close(util.oracle_state(o), util.device_state(sh), bulk=5e-5)
+    np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
+    assert sh.step_storage_bytes() > sh.step_algorithmic_bytes()
+    if Kg == 70:                                           # the other target, and the per-entry accessor's prior mean
+        sh.set_target("marginLik")
+        o.reset_optimizer()
+        sh.reset_optimizer()
+        tr_o = o.minimize(P["counts_pc"], P["Xc"], 3, 0.01, 3, target="marginLik")
+        np.testing.assert_allclose(sh.step(3, 0.01, 3), tr_o, rtol=1e-4)
+        np.testing.assert_allclose(sh.read(_capi.WG_LOC), o.Wg_loc, atol=2e-4)
     sh.close()
 
 

@@ -37,7 +37,7 @@ def test_capi_exports_every_declared_symbol(built_lib):
 def test_capi_struct_layout_matches_header():
     import ctypes
     from brie_amd import _capi
-    assert _capi.MAX_KC == 1024 and _capi.MAX_KG == 64       # BRIE_MAX_KC_PANELS, BRIE_MAX_KG_WIDE of include/brie_amd.h
+    assert _capi.MAX_KC == 1024 and _capi.MAX_KG == 1024     # BRIE_MAX_KC_PANELS, BRIE_MAX_KG_PANELS of include/brie_amd.h
     assert ctypes.sizeof(_capi.BrieProblem) == 72
     assert _capi.BrieProblem.seed.offset == 64 and _capi.BrieProblem.Kc.offset == 32
 
@@ -313,7 +313,7 @@ def test_non_native_byte_order_layers_take_the_numpy_cast():
 def test_unsupported_modes_raise():
     import brie_amd
     with pytest.raises(NotImplementedError):
-        brie_amd.BRIE2(10, 10, Kg=65)
+        brie_amd.BRIE2(10, 10, Kg=1025)
     with pytest.raises(NotImplementedError):
         brie_amd.BRIE2(10, 12, intercept_mode='cell', gene_offset=4)
     m = brie_amd.BRIE2(10, 10)
@@ -416,7 +416,7 @@ def test_c_abi_argument_checks_and_loud_failure_without_a_gpu(built_lib):
         p = _capi.BrieProblem(*[f[name] for name, _ in _capi.BrieProblem._fields_])
         return lib.brie_create(ctypes.byref(p), ctypes.byref(h)), lib.brie_last_error().decode()
     for kw, code, word in ((dict(Nc=0), -1, "bad shape"), (dict(abi_version=1), -1, "abi_version"), (dict(Kc=1025), -4, "Kc=1025"),
-                           (dict(Kg=65), -4, "Kg=65"), (dict(n_layers=4), -1, "n_layers"), (dict(n_layers=3), -1, "third count layer"),
+                           (dict(Kg=1025), -4, "Kg=1025"), (dict(n_layers=4), -1, "n_layers"), (dict(n_layers=3), -1, "third count layer"),
                            (dict(gene_offset=6), -1, "multiple of 4"), (dict(intercept_mode=2), -1, "intercept_mode"),
                            (dict(Kg=2, gene_offset=8), -4, "sharded=1")):
         rc, msg = create(**kw)

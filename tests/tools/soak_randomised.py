@@ -29,6 +29,8 @@ def wide_shapes(n, seed):
         if kind.startswith("wide") and rng.random() < 0.25:
             Kc = int(rng.integers(65, 161))                  # very wide designs: 64-feature panels (round 4)
         Kg = int(rng.integers(1, 65)) if kind.endswith("xg") else 0
+        if Kg and rng.random() < 0.25:
+            Kg = int(rng.integers(65, 161))                  # very wide gene designs, in panels too
         out.append((5000 + i, kind, int(rng.integers(1, 521)), int(rng.integers(1, 1101)), Kc, Kg, L,
                     int(rng.choice([1, 2, 3, 5])), bool(L == 3 or rng.random() < 0.3)))
     return out

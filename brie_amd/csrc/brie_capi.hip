@@ -106,6 +106,7 @@ struct brie_handle {
     bool wide = false;
     bool vwide = false;             // Kc > BRIE_MAX_KC_WIDE or Kg > BRIE_MAX_KG_WIDE: 64-feature panels (see setup_paths)
     bool vgwide = false;            // Kg > BRIE_MAX_KG_WIDE: Wg_loc . Xg^T and r . Xg in panels as well
+    float *XgT = nullptr;           // (ld, kgp) gene-major copy of Xg (Kg > 64: the A operand of gene_design_grad)
     float *Xg_zero = nullptr;       // (4, ld) / (Nc, 4) zeros: what the register slots of the coupled step variant read
     float *Wg_zero = nullptr;       //   when the gene design goes through the panels
     int part_kgp = brie::kKgMax;    // pitch of the Wg part of a row chunk (= kgp unless vgwide)
@@ -1051,7 +1052,8 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     AM(h->mu); AM(h->rho); AM(h->m_mu); AM(h->v_mu); AM(h->m_rho); AM(h->v_rho);
 #undef AM
     A(h->Xc, static_cast<size_t>(p->Nc) * p->Kc);
-    A(h->W, vec * p->Kc); A(h->m_W, vec * p->Kc); A(h->v_W, vec * p->Kc);
+    // (Wc_loc and Xg: 64 readable zero rows beyond the last feature, what the last panel of panel_prior_mean reads past kp)
+    A(h->W, p->Kc ? vec * (p->Kc + BRIE_MAX_KC_WIDE) : 0); A(h->m_W, vec * p->Kc); A(h->v_W, vec * p->Kc);
     A(h->b, vec); A(h->m_b, vec); A(h->v_b, vec);
     A(h->lam, vec); A(h->m_lam, vec); A(h->v_lam, vec);
     A(h->effL, vec * 6);
@@ -1065,13 +1067,13 @@ int brie_create(const brie_problem *p, brie_handle **out) {
         const size_t nc = static_cast<size_t>(p->Nc);
         h->gwide = p->Kg > brie::kKgMax;
         h->kgp = h->gwide ? static_cast<int>(round_up(p->Kg, 4)) : brie::kKgMax;
-        A(h->Xg, vec * h->kgp);
+        A(h->Xg, vec * (h->kgp + BRIE_MAX_KG_WIDE));
         A(h->Wg, nc * h->kgp); A(h->m_Wg, nc * h->kgp); A(h->v_Wg, nc * h->kgp);
         A(h->cb, nc); A(h->m_cb, nc); A(h->v_cb, nc);
         A(h->clam, nc); A(h->m_clam, nc); A(h->v_clam, nc);
         A(h->rowstat, nc * (h->kgp + 2));
         h->part_kgp = p->Kg > BRIE_MAX_KG_WIDE ? brie::kKgMax : h->kgp;
-        if (p->Kg > BRIE_MAX_KG_WIDE) { A(h->Xg_zero, vec * brie::kKgMax); A(h->Wg_zero, nc * brie::kKgMax); }
+        if (p->Kg > BRIE_MAX_KG_WIDE) { A(h->Xg_zero, vec * brie::kKgMax); A(h->Wg_zero, nc * brie::kKgMax); A(h->XgT, vec * h->kgp); }
     }
 #undef A
     setup_paths(h);                 // kernel family: register path, LDS-broadcast wide variants, or the MFMA tile kernel
@@ -1120,7 +1122,7 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
     }
 #define A(ptr, n) if ((rc = alloc_f32(&(ptr), (n), h->stream)) != BRIE_OK) return rc;
     A(h->Xc, static_cast<size_t>(h->p.Nc) * Kc);
-    A(h->W, vec * Kc); A(h->m_W, vec * Kc); A(h->v_W, vec * Kc);
+    A(h->W, Kc ? vec * (Kc + BRIE_MAX_KC_WIDE) : 0); A(h->m_W, vec * Kc); A(h->v_W, vec * Kc);
 #undef A
     h->gpart_elems = h->rbuf_elems = 0;
     h->p.Kc = Kc; h->p.seed = seed; h->p.train_intercept = train_intercept; h->p.train_sigma = train_sigma;
@@ -1155,7 +1157,7 @@ int brie_destroy(brie_handle *h) {
                      h->W, h->m_W, h->v_W, h->b, h->m_b, h->v_b, h->lam, h->m_lam, h->v_lam, h->effL,
                      h->gene_tmp, h->partials, h->Xg, h->Wg, h->m_Wg, h->v_Wg, h->cb, h->m_cb, h->v_cb, h->clam,
                      h->m_clam, h->v_clam, h->row_partials, h->rowstat, h->Mbuf, h->Rbuf, h->Gpart, h->gene_active,
-                     h->ring_kl, h->ring_ll, h->Xg_zero, h->Wg_zero};
+                     h->ring_kl, h->ring_ll, h->Xg_zero, h->Wg_zero, h->XgT};
     for (float *q : ptrs)
         if (q) hipFree(q);
     if (h->loss_parts) hipFree(h->loss_parts);
@@ -1217,6 +1219,13 @@ int brie_upload(brie_handle *h, int which, const float *src, int64_t rows, int64
             for (int64_t k = 0; k < cols; ++k) packed[k * h->ld + j] = tmp[j * cols + k];
         HIP_TRY(hipMemcpyAsync(h->Xg, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
+        if (h->XgT) {                            // gene-major copy, zero beyond (Ng, Kg)
+            std::fill(packed.begin(), packed.end(), 0.0f);
+            for (int64_t j = 0; j < rows; ++j)
+                for (int64_t k = 0; k < cols; ++k) packed[j * h->kgp + k] = tmp[j * cols + k];
+            HIP_TRY(hipMemcpyAsync(h->XgT, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
         h->have_xg = true;
         return BRIE_OK;
     }
@@ -1557,16 +1566,29 @@ int wide_backward(brie_handle *h, float alpha) {
     return BRIE_OK;
 }
 
-// dst (Nc, ld) tiled = Xc . Wc_loc, in panels of at most 64 features (the W tile of a panel sits in LDS)
+// dst (Nc, ld) tiled (+)= X[:, panel] . B[panel, :] for one panel of kp <= 64 features: a handful of features through the
+// LDS-broadcast kernel, more on the matrix cores
+void launch_panel(brie_handle *h, const float *X, int x_ld, const float *B, int kp, float *dst, bool accumulate) {
+    if (kp <= 8) {
+        hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, X, B, dst,
+                           static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), kp, h->ld, h->row_stride, h->gb_stride,
+                           h->rows_per_chunk, accumulate ? 1 : 0, x_ld);
+        return;
+    }
+    const dim3 grid(h->gene_blocks, static_cast<unsigned>((h->p.Nc + brie::kWavesPerBlock * 32 - 1) / (brie::kWavesPerBlock * 32)));
+    if (kp <= 32)
+        hipLaunchKernelGGL((brie::panel_prior_mean<16>), grid, dim3(brie::kBlock), 0, h->stream, X, B, dst,
+                           static_cast<int>(h->p.Nc), kp, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld);
+    else
+        hipLaunchKernelGGL((brie::panel_prior_mean<32>), grid, dim3(brie::kBlock), 0, h->stream, X, B, dst,
+                           static_cast<int>(h->p.Nc), kp, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld);
+}
+
+// dst (Nc, ld) tiled = Xc . Wc_loc, in panels of at most 64 features
 void launch_xw_panels(brie_handle *h, float *dst) {
     const int Kc = h->p.Kc;
-    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE) {
-        const int kp = std::min(Kc - k0, BRIE_MAX_KC_WIDE);
-        hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream,
-                           h->Xc + k0, h->W + static_cast<size_t>(k0) * h->ld, dst, static_cast<int>(h->p.Nc),
-                           static_cast<int>(h->p.Ng), kp, h->ld, h->row_stride, h->gb_stride, h->rows_per_chunk,
-                           k0 > 0 ? 1 : 0, Kc);
-    }
+    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE)
+        launch_panel(h, h->Xc + k0, Kc, h->W + static_cast<size_t>(k0) * h->ld, std::min(Kc - k0, BRIE_MAX_KC_WIDE), dst, k0 > 0);
 }
 
 // Mbuf = Xc . Wc_loc for the forward-only loss_gene pass of a wide design
@@ -1578,13 +1600,9 @@ int cell_finalize_blocks(const brie_handle *h) {
 // the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
 // dst (Nc, ld) tiled (+)= Wg_loc . Xg^T, in panels of at most 64 gene features (one panel for Kg <= 64)
 void launch_gw_panels(brie_handle *h, float *dst, bool accumulate) {
-    for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE) {
-        const int kp = std::min(h->kgp - k0, BRIE_MAX_KG_WIDE);
-        hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream,
-                           h->Wg + k0, h->Xg + static_cast<size_t>(k0) * h->ld, dst, static_cast<int>(h->p.Nc),
-                           static_cast<int>(h->p.Ng), kp, h->ld, h->row_stride, h->gb_stride, h->rows_per_chunk,
-                           (accumulate || k0 > 0) ? 1 : 0, h->kgp);
-    }
+    for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE)
+        launch_panel(h, h->Wg + k0, h->kgp, h->Xg + static_cast<size_t>(k0) * h->ld, std::min(h->kgp - k0, BRIE_MAX_KG_WIDE), dst,
+                     accumulate || k0 > 0);
 }
 
 int gwide_forward_mean(brie_handle *h, bool accumulate) {
@@ -1922,13 +1940,19 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                                h->n_chunks, alpha, h->gene_active, h->ld);
         } else if (h->wide_like && h->p.Kc > 0 && (rc = wide_backward(h, alpha)) != BRIE_OK)
             return rc;                            // residual buffer -> G = Xc^T . r (MFMA kernel), Adam on Wc_loc
-        if (h->vgwide) {                          // residual buffer -> the Wg_loc gradient r . Xg, panel by panel, into rowstat
-            const int gblocks = static_cast<int>((h->p.Nc + brie::kWavesPerBlock * brie::kGdgRows - 1) /
-                                                 (brie::kWavesPerBlock * brie::kGdgRows));
-            for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE)
-                hipLaunchKernelGGL(brie::gene_design_grad, dim3(gblocks), dim3(brie::kBlock), 0, h->stream, h->Xg, h->Rbuf,
-                                   cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks,
-                                   std::min(h->kgp - k0, BRIE_MAX_KG_WIDE), k0, h->kgp, h->ld, h->row_stride, h->gb_stride);
+        if (h->vgwide) {                          // residual buffer -> the Wg_loc gradient r . Xg (MFMA), panel by panel, into rowstat
+            const dim3 ggrid(static_cast<unsigned>((h->p.Nc + 31) / 32));
+            for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE) {
+                const int kp = std::min(h->kgp - k0, BRIE_MAX_KG_WIDE);
+                if (kp <= 32)
+                    hipLaunchKernelGGL((brie::gene_design_grad<1>), ggrid, dim3(brie::kBlock), 0, h->stream, h->XgT, h->Rbuf,
+                                       cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks, kp, k0,
+                                       h->kgp, h->row_stride, h->gb_stride);
+                else
+                    hipLaunchKernelGGL((brie::gene_design_grad<2>), ggrid, dim3(brie::kBlock), 0, h->stream, h->XgT, h->Rbuf,
+                                       cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks, kp, k0,
+                                       h->kgp, h->row_stride, h->gb_stride);
+            }
         }
         if (h->coupled && lib_reduce && !split) {
             // gene shard of a coupled fit: local sums -> RCCL all-reduce on this stream -> Adam, all enqueued

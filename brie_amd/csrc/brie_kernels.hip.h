@@ -1372,58 +1372,170 @@ __global__ __launch_bounds__(kBlock) void cell_finalize(const CellFinalizeArgs a
 }
 
 // Kg > 64 ("very wide" gene design): the Wg_loc gradient  G[cell, k] = sum_j r[cell, j] Xg[j, k]  from the residual the
-// WIDE variant of the step left in rbuf, one launch per panel of at most 64 features.  Workgroup = 4 waves x kGdgRows
-// cells each; per gene block the panel's Xg tile (<= 64 x 256 fp32) goes through LDS once for the block's 32 cells, the
-// products are reduced 8 features at a time as in the GW variant of the step (lane l ends with feature 8 (l & 7) + (l >> 3)).
-// Written straight into the [Nc][kgp] part of `rowstat` (what cell_finalize applies Adam to and a gene-sharded fit all-reduces).
-constexpr int kGdgRows = 8;
-__global__ __launch_bounds__(kBlock) void gene_design_grad(const float *Xg, const float *rbuf, float *rowstat, int Nc, int Ng,
-                                                           int gene_blocks, int kp, int k0, int kgp, int64_t ld,
-                                                           int64_t row_stride, int64_t gb_stride) {
-    __shared__ float xlds[kKgWideMax * kGenesPerBlock];
+// WIDE variant of the step left in rbuf, one launch per panel of at most 64 features, on the matrix cores
+// (v_mfma_f32_32x32x2_f32, exact fp32 fma chain):  D[i = feature][j = cell] += A[i = feature][k = gene] B[k = gene][j = cell].
+// One workgroup = 32 cells x the panel's features over ALL genes of the shard in one fixed order.  The B operand wants,
+// per lane, one cell's residuals along the genes -- a transpose of how they lie in memory -- so each gene block's
+// 32 x 256 residual tile is read row by row (coalesced, prefetched into registers one gene block ahead), goes through LDS
+// (pitch 257: column reads hit distinct banks), and each of the 4 waves takes 64 of its genes; A comes from the GENE-major
+// copy of Xg (XgT, (ld, kgp)): the 32 features of a gene are one 128-B line.  The waves' sums are folded through LDS in a
+// fixed order and written straight into the [Nc][kgp] part of `rowstat` (what cell_finalize applies Adam to and a
+// gene-sharded fit all-reduces).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kGdgPitch = kGenesPerBlock + 1;
+template <int NACC>      // 1: panel of <= 32 features, 2: <= 64
+__global__ __launch_bounds__(kBlock) void gene_design_grad(const float *__restrict__ XgT, const float *__restrict__ rbuf,
+                                                           float *__restrict__ rowstat, int Nc, int Ng, int gene_blocks, int kp,
+                                                           int k0, int kgp, int64_t row_stride, int64_t gb_stride) {
+    __shared__ float rt[32 * kGdgPitch];                   // 32.1 KB; re-used by the final fold (24 KB at NACC = 2)
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row0 = (blockIdx.x * kWavesPerBlock + w) * kGdgRows;
-    float mine[kGdgRows];
+    const int half = lane >> 5, l31 = lane & 31;
+    const int c0 = blockIdx.x * 32;
+    constexpr int RPW = 32 / kWavesPerBlock;               // rows of the tile each wave moves
+    // this wave's rows of the residual tile, clamped to the last cell (zeroed on the way into LDS)
+    const float *rrow[RPW];
+    bool row_ok[RPW];
 #pragma unroll
-    for (int i = 0; i < kGdgRows; ++i) mine[i] = 0.0f;
+    for (int i = 0; i < RPW; ++i) {
+        const int c = c0 + w * RPW + i;
+        row_ok[i] = c < Nc;
+        rrow[i] = rbuf + static_cast<int64_t>(min(c, Nc - 1)) * row_stride + lane * kVec;
+    }
+    bool feat_ok[NACC];
+    int fcol[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        feat_ok[a] = l31 + 32 * a < kp;
+        fcol[a] = k0 + min(l31 + 32 * a, kp - 1);
+    }
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][q] = 0.0f;
+    F4 rn[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) rn[i] = ld4(rrow[i]);    // gene block 0
+    constexpr int STEPS = kGenesPerBlock / kWavesPerBlock / 2;     // MFMA steps of one wave per gene block (2 genes each)
     for (int gb = 0; gb < gene_blocks; ++gb) {
-        __syncthreads();                                   // the previous gene block's tile has been consumed
-        for (int i = threadIdx.x; i < kp * kGenesPerBlock; i += kBlock)
-            xlds[i] = Xg[static_cast<int64_t>(k0 + i / kGenesPerBlock) * ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
+        const int jb = gb * kGenesPerBlock;
+        __syncthreads();                                   // every wave is done reading the previous tile
+#pragma unroll
+        for (int i = 0; i < RPW; ++i)
+#pragma unroll
+            for (int v = 0; v < kVec; ++v)                 // cells beyond Nc and padding genes are not part of the sum
+                rt[(w * RPW + i) * kGdgPitch + lane * kVec + v] = (row_ok[i] && jb + lane * kVec + v < Ng) ? rn[i].v[v] : 0.0f;
         __syncthreads();
-        const int64_t base = static_cast<int64_t>(gb) * gb_stride + lane * kVec;
+        if (gb + 1 < gene_blocks) {                        // in flight during this gene block's MFMAs
 #pragma unroll
-        for (int i = 0; i < kGdgRows; ++i) {
-            const int r = row0 + i;
-            if (r >= Nc) break;                            // wave-uniform
-            F4 rq = ld4(rbuf + base + static_cast<int64_t>(r) * row_stride);
+            for (int i = 0; i < RPW; ++i) rn[i] = ld4(rrow[i] + static_cast<int64_t>(gb + 1) * gb_stride);
+        }
+        const float *xt = XgT + static_cast<int64_t>(jb + w * (kGenesPerBlock / kWavesPerBlock) + half) * kgp;
+        const float *bt = rt + l31 * kGdgPitch + w * (kGenesPerBlock / kWavesPerBlock) + half;
+        constexpr int UB = 8;                              // operand loads in flight
 #pragma unroll
-            for (int v = 0; v < kVec; ++v)                 // padding genes are not part of a cell's sums
-                rq.v[v] = gb * kGenesPerBlock + lane * kVec + v < Ng ? rq.v[v] : 0.0f;
-            float acc = 0.0f;
-            for (int g = 0; g * 8 < kp; ++g) {
-                float t[8];
+        for (int s0 = 0; s0 < STEPS; s0 += UB) {
+            float xv[UB][NACC], bv[UB];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    t[q] = 0.0f;
-                    if (g * 8 + q < kp) {
-                        const F4 xk = ld4(xlds + (g * 8 + q) * kGenesPerBlock + lane * kVec);
+            for (int u = 0; u < UB; ++u) {
+                bv[u] = bt[2 * (s0 + u)];
 #pragma unroll
-                        for (int v = 0; v < kVec; ++v) t[q] = fmaf(rq.v[v], xk.v[v], t[q]);
-                    }
-                }
-                const float c = wave_sum8(t, lane);
-                acc = (lane & 7) == g ? c : acc;
+                for (int a = 0; a < NACC; ++a) xv[u][a] = xt[static_cast<int64_t>(2 * (s0 + u)) * kgp + fcol[a]];
             }
-            mine[i] += acc;
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a)
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(feat_ok[a] ? xv[u][a] : 0.0f, bv[u], acc[a], 0, 0, 0);
         }
     }
-    const int kf = 8 * (lane & 7) + (lane >> 3);
+    __syncthreads();
+    float *red = rt;                                       // (3, NACC, 16, 64) floats
+    if (w > 0) {
 #pragma unroll
-    for (int i = 0; i < kGdgRows; ++i) {
-        const int r = row0 + i;
-        if (r < Nc && kf < kp) rowstat[static_cast<int64_t>(r) * kgp + k0 + kf] = mine[i];
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[(((w - 1) * NACC + a) * 16 + q) * kWave + lane] = acc[a][q];
+    }
+    __syncthreads();
+    if (w > 0) return;
+#pragma unroll
+    for (int ww = 0; ww < kWavesPerBlock - 1; ++ww)
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][q] += red[((ww * NACC + a) * 16 + q) * kWave + lane];
+    // D[i][j]: lane l, reg q -> j = l & 31 (cell), i = (q & 3) + 8 (q >> 2) + 4 (l >> 5) (feature)
+    if (c0 + l31 < Nc) {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int feat = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * a;
+                if (feat < kp) rowstat[static_cast<int64_t>(c0 + l31) * kgp + k0 + feat] = acc[a][q];
+            }
+    }
+}
+
+// dst (Nc, ld) tiled (+)= X . B for a panel of kp <= 2 KSTEPS features on the matrix cores: X (Nc, x_ld) row-major, the
+// panel starting at X (the caller adds k0), B (kp, ld) feature rows.  D[i = cell][j = gene] += A[i = cell][k = feature]
+// B[k = feature][j = gene]; one wave = 32 cells x the 8 32-gene slices of one 256-gene block, the cell rows of the
+// design stay in registers for all of them.  A serial fp32 fma chain over the panel's features, formed 32 x 32 outputs at
+// a time; the panel's sum is added to what dst holds (wide_prior_mean continues the chain from it: last bits differ).
+template <int KSTEPS>
+__global__ __launch_bounds__(kBlock) void panel_prior_mean(const float *__restrict__ X, const float *__restrict__ B,
+                                                           float *__restrict__ M, int Nc, int kp, int64_t ld, int64_t row_stride,
+                                                           int64_t gb_stride, int accumulate, int x_ld) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int c0 = (blockIdx.y * kWavesPerBlock + w) * 32;
+    if (c0 >= Nc) return;                                   // wave-uniform
+    // Every load is unconditional on a clamped index (a load under a lane mask becomes a branch with its own wait, and the
+    // MFMA chain then pays one memory latency per instruction).  Rows of cells beyond Nc compute on a copy of the last
+    // cell and are never stored; features beyond kp are zeroed in A.
+    const int cell = min(c0 + l31, Nc - 1);
+    float a[KSTEPS];
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) a[s] = X[static_cast<int64_t>(cell) * x_ld + min(2 * s + half, kp - 1)];
+    __builtin_amdgcn_sched_barrier(0);                      // all the loads above are in flight before the first select
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) a[s] = (2 * s + half < kp) ? a[s] : 0.0f;
+    // D[i][j]: lane l, reg q -> j = l & 31 (gene), i = (q & 3) + 8 (q >> 2) + 4 (l >> 5) (cell of the tile)
+    float *mp = M + static_cast<int64_t>(blockIdx.x) * gb_stride + static_cast<int64_t>(c0) * row_stride + l31;
+    const int rs = static_cast<int>(row_stride);
+    const int rows_here = min(32, Nc - c0);
+    // B rows beyond kp are read too (and meet zeros in A): the caller's B has 2 KSTEPS readable rows from the panel's start
+    const float *bu = B + blockIdx.x * kGenesPerBlock;       // uniform base + one 32-bit lane offset + per-row scalar offsets
+    const uint32_t ld32 = static_cast<uint32_t>(ld);
+    const uint32_t voff = static_cast<uint32_t>(half) * ld32 + static_cast<uint32_t>(l31);
+    float bcur[KSTEPS], bnxt[KSTEPS];
+    auto load_b = [&](int tile, float (&b)[KSTEPS]) {
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) b[s] = bu[static_cast<uint32_t>(2 * s) * ld32 + static_cast<uint32_t>(tile * 32) + voff];
+    };
+    load_b(0, bcur);
+#pragma unroll
+    for (int tile = 0; tile < kGenesPerBlock / 32; ++tile) {
+        float d[16];
+        if (accumulate) {                                   // consumed after the MFMA chain: their latency is covered by it
+#pragma unroll
+            for (int q = 0; q < 16; ++q) d[q] = mp[min((q & 3) + 8 * (q >> 2) + 4 * half, rows_here - 1) * rs + tile * 32];
+        }
+        if (tile + 1 < kGenesPerBlock / 32) load_b(tile + 1, bnxt);               // in flight during this tile's MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bcur[s], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (i < rows_here) mp[i * rs + tile * 32] = accumulate ? d[q] + acc[q] : acc[q];
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) bcur[s] = bnxt[s];
     }
 }
 
@@ -1462,7 +1574,6 @@ __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const
 // 32 features x 2 cells of Xc:  A[i = feature][k = cell], B[k = cell][j = gene],
 // D[i][j]: lane l, reg q -> j = l & 31, i = (q & 3) + 8 (q >> 2) + 4 (l >> 5).
 // Gpart: (n_chunks, Kc, ld) partial sums, reduced in fp64 by wide_w_adam.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int NACC>      // 1: Kc <= 32, 2: Kc <= 64
 // (Kc = the features of THIS launch; a panel of a wider design passes Xc + k0 with row pitch x_ld, Gpart + k0 * ld and
 //  the chunk stride kc_total of the whole design)

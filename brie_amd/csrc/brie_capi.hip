@@ -1708,7 +1708,12 @@ void adopt_set(brie_handle *h, const StreamedSet &s) {
 
 // rate a handle of this device has been seen to reach (GB/s of storage bytes): what "fast" means on this box
 std::mutex g_place_mu;
-double g_place_best[64] = {};
+double g_place_best[64][2] = {};           // [device][size class of the handle's arrays, see placement_class]
+// Arrays below a gigabyte never reached the 6.0 - 6.3 TB/s of large ones in any process of round 4 (216 sets of the
+// configs[1] shape: fast mode 5.85 - 6.0, none above 6.0; profiles/r4*_placement_auto_c2.jsonl, r4ae_auto_c2.jsonl): their own class
+inline int placement_class(const brie_handle *h) {
+    return static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float) < (size_t(1) << 30) ? 1 : 0;
+}
 
 int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     if (max_tries > 4) max_tries = 4;
@@ -1785,7 +1790,8 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     {
         std::lock_guard<std::mutex> l(g_place_mu);
         const int d = h->p.device & 63;
-        if (best > g_place_best[d]) g_place_best[d] = best;
+        double &seen = g_place_best[d][placement_class(h)];
+        if (best > seen) seen = best;
     }
     h->placement_done = true;
     h->placement_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -1799,16 +1805,20 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
 // kernel's to 1 %, correlation 0.999 at configs[2] -- read 4.93 - 5.30 TB/s in the slow mode, 5.49 - 5.94 in between and
 // 6.0 - 6.24 in the fast one; or 0.97 x the best rate a handle of this process has reached on the device if higher.
 constexpr double kPlacementGoodGBs = 6050.0;
+// ... and for handles whose arrays are below a gigabyte 5850: the search used to run all four sets for them every time
+// (6050 was out of reach) -- 14 - 44 ms of a 0.6-s configs[1] fit even when the first set was already in the fast mode
+constexpr double kPlacementGoodSmallGBs = 5850.0;
 int auto_placement(brie_handle *h) {
     if (h->placement_done) return BRIE_OK;
     h->placement_done = true;
     static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 4; }();
     if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) return BRIE_OK;
     static const double good_env = [] { const char *e = getenv("BRIE_PLACEMENT_GOOD_GBS"); return e ? atof(e) : 0.0; }();
-    double good = good_env > 0.0 ? good_env : kPlacementGoodGBs;
+    const int cls = placement_class(h);
+    double good = good_env > 0.0 ? good_env : (cls == 1 ? kPlacementGoodSmallGBs : kPlacementGoodGBs);
     if (good_env <= 0.0) {
         std::lock_guard<std::mutex> l(g_place_mu);
-        good = std::max(good, 0.97 * g_place_best[h->p.device & 63]);
+        good = std::max(good, 0.97 * g_place_best[h->p.device & 63][cls]);
     }
     return tune_placement(h, tries, good);
 }

@@ -314,8 +314,9 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  * apart), filled by device-to-device copies and probed until one is good; the fastest set is kept, the others are freed when
  * the search is over (results are bit-identical: only addresses change).  brie_step does this by itself before the first
  * step of a handle that streams >= 256 MiB per step: BRIE_PLACEMENT_TRIES sets in all (default 4; 1 = off), good_gbs =
- * BRIE_PLACEMENT_GOOD_GBS (default 6050, or 0.97 x the best rate a handle of this process has reached on the device when
- * that is higher).  Typical cost at configs[2]: 0.17 s (three candidates of 26 GB allocated, one or two copied and probed);
+ * BRIE_PLACEMENT_GOOD_GBS (default 6050 -- 5850 for handles whose arrays are below 1 GiB, which never read faster than
+ * 6.0 TB/s --, or 0.97 x the best rate a handle of that size class has reached in this process on the device when that
+ * is higher).  Typical cost at configs[2]: 0.17 s (three candidates of 26 GB allocated, one or two copied and probed);
  * 0.8 - 3 s when the allocator has a slow moment.
  *  brie_placement_probe: rate of the probe on the arrays as they are (iters timed launches after one warm-up).
  *  brie_placement_tune : the procedure above on demand, at most max_tries <= 4 sets.

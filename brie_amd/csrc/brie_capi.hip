@@ -1755,7 +1755,13 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     auto drop = [](StreamedSet &s) { for (int i = 0; i < s.n; ++i) if (s.p[i]) { (void)hipFree(s.p[i]); s.p[i] = nullptr; } };
     hipError_t e = hipSuccess;
     for (StreamedSet &c : cand) { c.n = first.n; for (int i = 0; i < first.n; ++i) c.bytes[i] = first.bytes[i]; }
-    if (interleave) {
+    // Arrays below a gigabyte are not spread by interleaving ("a few arrays apart" is then no distance, call r4z): their
+    // candidates are allocated one at a time, only when the search gets to them (27 allocations and frees up front were
+    // most of its 15 - 40 ms), and held until the end like the others.
+    static const int lazy_env = [] { const char *e = getenv("BRIE_PLACEMENT_LAZY"); return e ? atoi(e) : -1; }();   // A/B runs
+    const bool lazy = lazy_env >= 0 ? lazy_env != 0 : placement_class(h) == 1;
+    if (lazy) {
+    } else if (interleave) {
         for (int i = 0; i < first.n && e == hipSuccess; ++i)
             for (int k = 0; k < n_cand && e == hipSuccess; ++k) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
     } else {
@@ -1770,6 +1776,10 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     int kept = -1;                               // index into cand, -1 = the first set
     for (int k = 0; k < n_cand && rc == BRIE_OK; ++k) {
         if (best >= good_gbs) break;                                // good enough: the remaining candidates are not needed
+        if (lazy) {
+            for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
+            if (e != hipSuccess) { (void)hipGetLastError(); e = hipSuccess; drop(cand[k]); break; }     // out of memory: keep the best so far
+        }
         for (int i = 0; i < first.n && e == hipSuccess; ++i)
             e = hipMemcpyAsync(cand[k].p[i], first.p[i], first.bytes[i], hipMemcpyDeviceToDevice, h->stream);
         if (e != hipSuccess) { rc = fail(BRIE_ERR_HIP, "placement copy: %s", hipGetErrorString(e)); break; }

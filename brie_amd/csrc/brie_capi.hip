@@ -344,6 +344,16 @@ void configure_tiling(brie_handle *h) {
         // 256 rows at Nc = 50k, 64 rows at Nc = 10k; profiles/history/r01_rows_per_chunk.log).
         rpc = 256;
         while (rpc > 16 && (Nc + rpc - 1) / rpc < 128) rpc /= 2;
+        // The streaming kernel runs one workgroup per CU, so a launch is gene_blocks x n_chunks / 256 rounds of workgroups
+        // and the last, partly filled round is lost time: with n_chunks = 256 (or 128) every round is full (or half full)
+        // WHATEVER the shard's gene count.  Re-swept with the round-4 kernel (profiles/r4at_rpc_*.json): configs[1] 0.4407 ms
+        // at 64 rows (12.3 rounds) -> 0.4304 at 79 (127 chunks, 9.9 rounds); configs[2] 8.170 -> 8.167 at 196 (256 chunks);
+        // an 8-way shard of it 1.0834 -> 1.0744.  The MFMA tile kernel works in 32-row tiles and keeps the powers of two.
+        if (!h->wide_like && Nc >= 6144) {
+            int64_t n = Nc >= 32768 ? 256 : 128;
+            while ((Nc + n - 1) / n > 400) n *= 2;
+            rpc = static_cast<int>((Nc + n - 1) / n);
+        }
     }
     h->rows_per_chunk = rpc;
     h->n_chunks = static_cast<int>((Nc + rpc - 1) / rpc);
@@ -1127,6 +1137,7 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
     h->gpart_elems = h->rbuf_elems = 0;
     h->p.Kc = Kc; h->p.seed = seed; h->p.train_intercept = train_intercept; h->p.train_sigma = train_sigma;
     setup_paths(h);
+    configure_tiling(h);            // the rows per chunk follow the kernel family
     if (h->row_scratch) { HIP_TRY(hipFree(h->row_scratch)); h->row_scratch = nullptr; }   // sized by max(ring, Kc)
     h->have_xc = false;
     h->have_state = false;

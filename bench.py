@@ -383,8 +383,8 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 20; 200 / 500 for the sub-millisecond configs c2 / c1)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: 3; 50 / 100 for c2 / c1)")
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
     ap.add_argument("--mc", type=int, default=1, help="MC_size (API default 1, CLI default 3)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
@@ -407,6 +407,14 @@ def main(argv=None):
     ap.add_argument("--no-psi-check", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args(argv)
+    # A step of configs[1] takes 0.45 ms and one of configs[0] 12 us: 3 + 20 of them are over before the GPU has left its idle
+    # clocks (call r4au: 0.480 ms per launch in such a window, 0.435 ms for the same kernel on the same handle after 45 steps,
+    # 0.440 inside the fit) -- the sub-millisecond configs get a longer warm-up and timed region by default.
+    short = {"c1": (500, 100), "c2": (200, 50)}.get(args.config, (20, 3))
+    if args.steps is None:
+        args.steps = short[0]
+    if args.warmup is None:
+        args.warmup = short[1]
     # RCCL / device-tensor sharing between the ranks needs dmabuf IPC on this driver (exported on the pool already)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus < 1:

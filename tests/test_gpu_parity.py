@@ -424,12 +424,12 @@ def test_coupled_modes_match_oracle(lib, mode, Kg, Kc, L, MC):
     np.testing.assert_allclose(sh.loss_gene(5), o.eval_loss_gene(P["counts_pc"], P["Xc"], 5), rtol=1e-4, atol=1e-3)
 
 
-@pytest.mark.parametrize("Kg", [2, 9])
+@pytest.mark.parametrize("Kg", [2, 9, 70])         # registers / LDS tile / 64-feature panels, through BRIE2.fit
 def test_coupled_fit_through_python_api(lib, Kg):
     import brie_amd
     Nc, Ng, Kc = 80, 70, 1
     P = util.problem(Nc, Ng, Kc, 2, seed=43)
-    Xg = np.random.default_rng(6).standard_normal((Ng, Kg)).astype(np.float32)
+    Xg = (np.random.default_rng(6).standard_normal((Ng, Kg)) * (0.3 if Kg > 64 else 1.0)).astype(np.float32)
     m = brie_amd.BRIE2(Nc, Ng, Kc=Kc, Kg=Kg, intercept_mode='cell', seed=9)
     losses = m.fit(P["counts"], Xc=P["Xc"], Xg=Xg, min_iter=120, max_iter=120, n_loss_gene=5, pseudo_count=0.01,
                    verbose=False)

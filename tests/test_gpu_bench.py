@@ -36,6 +36,7 @@ def test_two_ranks_give_one_complete_line(lib):
                        env=_env(BRIE_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=600, cwd=ROOT)
     d = _line(p)
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["warmup"] == 2 and d["preconditioning"]["probe_launches"] > 0       # the W + K steps as asked; the device kept busy before
     per = d["roofline"]["per_gpu"]
     assert [g["rank"] for g in per] == [0, 1] and sum(g["genes"] for g in per) == d["config"]["Ng"]
     assert all(g["avg_kernel_ms"] > 0 and 0 < g["frac"] < 1 for g in per)

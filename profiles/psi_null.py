@@ -135,14 +135,15 @@ def fixture(case, n):
     print("wrote", out, os.path.getsize(out) >> 10, "KiB")
 
 
-def evaluate(cases, out):
+def evaluate(cases, out, hip_kept=None):
     from tests import util
+    hip_kept = hip_kept or HIP_KEPT
     result = {"rule": util.psi_null_rule.__doc__, "cases": {}}
     tot = {"displaced": [0, 0], "clustered": [0, 0], "quiet_entries_gt_1e-4": [0, 0]}
     for case in cases:
         fn, fh = os.path.join(NULL_DIR, "%s_null.npz" % case), os.path.join(HIP_DIR, "%s_hip.npz" % case)
-        if not os.path.exists(fh):                      # the committed copy of an earlier GPU call
-            fh = os.path.join(HIP_KEPT, "%s_hip.npz" % case)
+        if hip_kept != HIP_KEPT or not os.path.exists(fh):      # the committed copy of a GPU call
+            fh = os.path.join(hip_kept, "%s_hip.npz" % case)
         if not (os.path.exists(fn) and os.path.exists(fh)):
             continue
         c = pd.CASES[case]
@@ -187,6 +188,8 @@ def main():
     ap.add_argument("--evaluate", action="store_true")
     ap.add_argument("--fixture", default=None, metavar="CASE:N")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "psi_null_r04.json"))
+    ap.add_argument("--hip-kept", default=None, help="directory of committed HIP summaries to evaluate (default profiles/psi_null_hip; "
+                    "profiles/psi_null_hip_final_library = call r4bd, the library of the round's last commits)")
     args = ap.parse_args()
     cases = [c for c in args.cases.split(",") if c]
     if args.null:
@@ -199,7 +202,7 @@ def main():
         case, n = args.fixture.split(":")
         fixture(case, int(n))
     if args.evaluate:
-        evaluate(cases, args.out)
+        evaluate(cases, args.out, args.hip_kept)
 
 
 if __name__ == "__main__":

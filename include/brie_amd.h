@@ -279,7 +279,9 @@ int brie_profile_read(brie_handle *h, double *kernel_ms_total, int64_t *n_launch
  * BRIE_Z_LOC, BRIE_Z_STD_LOG, 20..23 = Adam moments m, v of Z_loc and m, v of Z_std_log). */
 int brie_debug_address(brie_handle *h, int which, uint64_t *addr);
 
-/* Tuning knobs of the tiling (0 = library default). */
+/* Tuning knob of the tiling: cells one workgroup streams for its 256-gene block (0 = library default: a function of Nc only,
+ * so that a gene's fp32 partial sums -- and its whole trajectory -- are the same in any gene shard; 128 or 256 chunks for
+ * Nc >= 6144, which keeps every round of workgroups full whatever the shard's gene count). */
 int brie_set_tiling(brie_handle *h, int32_t rows_per_chunk);
 
 /* Algorithmic HBM bytes of one elbo_adam_step launch: Nc*Ng*(48 + 4*n_layers) (fp32 model of

@@ -154,10 +154,17 @@ def evaluate(cases, out, hip_kept=None):
             rep["further_null_draws"] = {}
             for f in extra:
                 r2 = util.psi_null_rule(load_summary(fh), load_summary(os.path.join(NULL_DIR, f)), case, check=False)
+                # ... and the draw itself judged the way the HIP run is: a CPU re-evaluation held against the FIRST draw
+                r3 = util.psi_null_rule(load_summary(os.path.join(NULL_DIR, f)), load_summary(fn), case, check=False)
                 rep["further_null_draws"][f[len(case) + 6:-4]] = {
                     "holds_against_this_draw": r2["holds"], "displaced_genes": r2["displaced_genes"]["o32b_vs_o32"],
                     "clustered_genes": r2["clustered_genes"]["o32b_vs_o32"],
-                    "quiet_gt_1e-4": r2.get("quiet_genes", {}).get("gt_1e-4")}
+                    "quiet_gt_1e-4": r2.get("quiet_genes", {}).get("gt_1e-4"),
+                    "this_draw_judged_like_the_hip_run_against_the_first_draw": {
+                        "holds": r3["holds"], "violated": r3.get("violated"),
+                        "displaced_genes": r3["displaced_genes"], "clustered_genes": r3["clustered_genes"],
+                        "quiet_gt_1e-4": r3.get("quiet_genes", {}).get("gt_1e-4"),
+                        "quiet_p99": r3.get("quiet_genes", {}).get("p99_upper_bin_edge")}}
         rep["steps"], rep["MC_size"] = 6 * int(c["min_iter"] / 6), c["MC"]
         result["cases"][case] = rep
         for k, key in (("displaced", "displaced_genes"), ("clustered", "clustered_genes")):

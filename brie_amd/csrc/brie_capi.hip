@@ -1769,8 +1769,7 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     // Arrays below a gigabyte are not spread by interleaving ("a few arrays apart" is then no distance, call r4z): their
     // candidates are allocated one at a time, only when the search gets to them (27 allocations and frees up front were
     // most of its 15 - 40 ms), and held until the end like the others.
-    static const int lazy_env = [] { const char *e = getenv("BRIE_PLACEMENT_LAZY"); return e ? atoi(e) : -1; }();   // A/B runs
-    const bool lazy = lazy_env >= 0 ? lazy_env != 0 : placement_class(h) == 1;
+    const bool lazy = placement_class(h) == 1;      // (A/B against interleaved up front: no difference, call r4as)
     if (lazy) {
     } else if (interleave) {
         for (int i = 0; i < first.n && e == hipSuccess; ++i)

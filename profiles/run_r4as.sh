@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round 4, GPU call AS: candidates of a configs[1] handle allocated one at a time (lazy = 1) against interleaved up front
-# (lazy = 0), alternating fresh processes on one box (call r4ar: eight lazy processes in a row found no fast set)
+# (lazy = 0), alternating fresh processes on one box (call r4ar: eight lazy processes in a row found no fast set).
+# BRIE_PLACEMENT_LAZY existed for this call only (no difference: the switch is gone, small handles allocate lazily).
 O=gpurun_out
 for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
   for lazy in 0 1; do

@@ -1591,25 +1591,38 @@ __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict_
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[a][q] = 0.0f;
-    constexpr int U = 8;                                   // 8 cell pairs of loads in flight per wave
-    for (int r = row0; r < row_end; r += 2 * U) {
-        float bval[U], aval[U][NACC];
+    constexpr int U = 8;                                   // 8 cell pairs per stage; the next stage's loads are in flight during the MFMAs
+    // every load unconditional on a clamped index, zeroed by a select afterwards (a load under a lane mask is a branch)
+    bool feat_ok[NACC];
+    int fcol[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+        feat_ok[a] = l31 + 32 * a < Kc;
+        fcol[a] = feat_ok[a] ? l31 + 32 * a : 0;
+    }
+    struct Stage { float b[U], a[U][NACC]; };
+    auto load_stage = [&](int r, Stage &S) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int rr = r + 2 * u + half;
-            const bool ok = rr < row_end;
-            bval[u] = ok ? rp[static_cast<int64_t>(rr) * kGenesPerBlock] : 0.0f;
+            const int rr = min(r + 2 * u + half, row_end - 1);
+            S.b[u] = rp[static_cast<int64_t>(rr) * kGenesPerBlock];
 #pragma unroll
-            for (int a = 0; a < NACC; ++a) {
-                const int feat = l31 + 32 * a;
-                aval[u][a] = (ok && feat < Kc) ? Xc[static_cast<int64_t>(rr) * x_ld + feat] : 0.0f;
-            }
+            for (int a = 0; a < NACC; ++a) S.a[u][a] = Xc[static_cast<int64_t>(rr) * x_ld + fcol[a]];
         }
+    };
+    Stage cur, nxt;
+    if (row0 < row_end) load_stage(row0, cur);
+    for (int r = row0; r < row_end; r += 2 * U) {
+        if (r + 2 * U < row_end) load_stage(r + 2 * U, nxt);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+            const bool ok = r + 2 * u + half < row_end;
+            const float bv = ok ? cur.b[u] : 0.0f;
 #pragma unroll
             for (int a = 0; a < NACC; ++a)
-                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(aval[u][a], bval[u], acc[a], 0, 0, 0);
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && feat_ok[a]) ? cur.a[u][a] : 0.0f, bv, acc[a], 0, 0, 0);
+        }
+        cur = nxt;
     }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)

@@ -19,6 +19,10 @@
  *         enter the fp64 totals (the HIP kernels form fp32 partial sums per lane and chunk), and the compiler free to
  *         contract a * b + c into fused multiply-adds.  o32b-vs-o32 is the null distribution the HIP-vs-o32
  *         differences are held against: tests/util.py::psi_null_rule, profiles/psi_null.py)
+ *         The o32b build takes three run-time knobs (brie_oracle_b_config: float or exact Box-Muller, reversed or forward
+ *         cell order, cells per fp32 partial sum) which, with the OpenMP thread count (= where the per-thread sums are cut),
+ *         define the MEMBERS of the pre-registered null ensemble (tests/util.py::psi_ensemble_rule,
+ *         tests/golden/psi_ensemble_manifest.json); the defaults (1, 1, 64) are the single draw of round 4.
  * Nothing in brie_amd/ may link or load this file.
  */
 #include <math.h>
@@ -64,6 +68,13 @@ typedef float real;
 #endif
 #define RC(x) ((real)(x))
 
+/* The cells are cut into PARTS with their own per-gene accumulators, summed in part order: by default one part per OpenMP
+ * thread with the ranges of `omp for schedule(static)` (so the sums depend on the thread count); brie_oracle_set_parts(n)
+ * fixes the number of parts whatever the thread count, which makes a run with "n threads" reproducible on any host. */
+static int g_parts = 0;
+#ifdef BRIE_ORACLE_B
+static int g_b_float_noise = 1, g_b_reverse = 1, g_b_chunk = 64;      /* brie_oracle_b_config */
+#endif
 static double u01(uint32_t x) { return ((double)(x >> 9) + 0.5) * (1.0 / 8388608.0); }
 /* eps is the fp32 value of oracle/philox.py in both precisions (the noise stream is DEFINED in fp32) */
 static void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uint64_t seed, real e[4]) {
@@ -71,6 +82,12 @@ static void normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k, uin
     philox4x32_10(c, (uint32_t)(seed & 0xFFFFFFFFu), (uint32_t)(seed >> 32));
     for (int p = 0; p < 2; ++p) {
 #ifdef BRIE_ORACLE_B     /* Box-Muller in float: the uniforms are exact in fp32, everything after them rounds in fp32 */
+        if (!g_b_float_noise) {
+            const double r = sqrt(-2.0 * log(u01(c[2 * p]))), th = 6.283185307179586476925 * u01(c[2 * p + 1]);
+            e[2 * p] = (real)(float)(r * cos(th));
+            e[2 * p + 1] = (real)(float)(r * sin(th));
+            continue;
+        }
         const float ua = ((float)(c[2 * p] >> 9) + 0.5f) * 0x1p-23f, ub = ((float)(c[2 * p + 1] >> 9) + 0.5f) * 0x1p-23f;
         const float r = sqrtf(-2.0f * logf(ua)), th = 6.283185307179586f * ub;
         e[2 * p] = (real)(r * cosf(th));
@@ -115,10 +132,11 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
 #ifdef _OPENMP
     nthreads = omp_get_max_threads();
 #endif
-    double *acc = (double *)malloc(sizeof(double) * (size_t)nthreads * S * Ng);
+    const int parts = g_parts > 0 ? g_parts : nthreads;
+    double *acc = (double *)malloc(sizeof(double) * (size_t)parts * S * Ng);
     real *lL = (real *)malloc(sizeof(real) * 3 * (size_t)Ng);
 #ifdef BRIE_ORACLE_B
-    float *accf = (float *)malloc(sizeof(float) * (size_t)nthreads * S * Ng);     /* fp32 sums of <= 64 cells */
+    float *accf = (float *)malloc(sizeof(float) * (size_t)parts * S * Ng);     /* fp32 sums of <= 64 cells */
     if (!accf) return -1;
 #endif
     if (!acc || !lL) return -1;
@@ -130,25 +148,23 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
         const int t = t0 + step + 1;
         const real alpha = lr * R_SQRT(RC(1) - R_POW(RC(0.999), (real)t)) / (RC(1) - R_POW(RC(0.9), (real)t));
         const uint32_t draw = draw0 + (uint32_t)step;
-        memset(acc, 0, sizeof(double) * (size_t)nthreads * S * Ng);
-#pragma omp parallel
-        {
-            int tid = 0;
-#ifdef _OPENMP
-            tid = omp_get_thread_num();
-#endif
+        memset(acc, 0, sizeof(double) * (size_t)parts * S * Ng);
+#pragma omp parallel for schedule(static, 1)
+        for (int part = 0; part < parts; ++part) {
+            /* the range `omp for schedule(static)` gives thread `part` of `parts` (libgomp: the first Nc % parts get one more) */
+            const int q_ = Nc / parts, r_ = Nc % parts;
+            const int ii0 = part < r_ ? (q_ + 1) * part : q_ * part + r_, ii1 = ii0 + q_ + (part < r_ ? 1 : 0);
 #ifdef BRIE_ORACLE_B
-            double *a64 = acc + (size_t)tid * S * Ng;
-            float *a = accf + (size_t)tid * S * Ng;
+            double *a64 = acc + (size_t)part * S * Ng;
+            float *a = accf + (size_t)part * S * Ng;
             memset(a, 0, sizeof(float) * (size_t)S * Ng);
             int in_chunk = 0;
 #else
-            double *a = acc + (size_t)tid * S * Ng;
+            double *a = acc + (size_t)part * S * Ng;
 #endif
-#pragma omp for schedule(static)
-            for (int ii = 0; ii < Nc; ++ii) {
+            for (int ii = ii0; ii < ii1; ++ii) {
 #ifdef BRIE_ORACLE_B
-                const int i = Nc - 1 - ii;                 /* the thread's cells in reverse order */
+                const int i = g_b_reverse ? Nc - 1 - ii : ii;      /* the thread's cells in reverse order */
 #else
                 const int i = ii;
 #endif
@@ -194,7 +210,7 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                     }
                 }
 #ifdef BRIE_ORACLE_B
-                if (++in_chunk == 64) {
+                if (++in_chunk >= g_b_chunk) {
                     for (size_t q = 0; q < (size_t)S * Ng; ++q) { a64[q] += (double)a[q]; a[q] = 0.0f; }
                     in_chunk = 0;
                 }
@@ -209,7 +225,7 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
             double tot[64];
             for (int s = 0; s < S; ++s) {
                 tot[s] = 0.0;
-                for (int th = 0; th < nthreads; ++th) tot[s] += acc[((size_t)th * S + s) * Ng + j];
+                for (int th = 0; th < parts; ++th) tot[s] += acc[((size_t)th * S + s) * Ng + j];
             }
             for (int k = 0; k < Kc; ++k) adam(&W[(size_t)k * Ng + j], &m_W[(size_t)k * Ng + j], &v_W[(size_t)k * Ng + j], (real)(-tot[k]), alpha, 0);
             if (p->train_b) adam(&b[j], &m_b[j], &v_b[j], (real)(-tot[Kc]), alpha, 1);
@@ -231,6 +247,19 @@ void brie_oracle_normal4(uint32_t quad, uint32_t cell, uint32_t draw, uint32_t k
     normal4(quad, cell, draw, k, seed, e);
     for (int v = 0; v < 4; ++v) out[v] = (float)e[v];
 }
+
+/* members of the null ensemble: only the o32b build has these knobs (returns 0 there, -1 elsewhere) */
+int brie_oracle_b_config(int float_noise, int reverse, int chunk) {
+#ifdef BRIE_ORACLE_B
+    g_b_float_noise = float_noise != 0; g_b_reverse = reverse != 0; g_b_chunk = chunk > 0 ? chunk : 64;
+    return 0;
+#else
+    (void)float_noise; (void)reverse; (void)chunk;
+    return -1;
+#endif
+}
+
+void brie_oracle_set_parts(int n) { g_parts = n > 0 ? n : 0; }
 
 int brie_oracle_real_bytes(void) { return (int)sizeof(real); }
 

@@ -54,6 +54,9 @@ class COracle(object):
         self.dtype = np.dtype(dtype)
         self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64, variant_b=variant_b))
         assert self.lib.brie_oracle_real_bytes() == self.dtype.itemsize
+        self.lib.brie_oracle_set_parts(ctypes.c_int(0))
+        if variant_b:                      # the knobs are globals of the loaded library: every o32b run starts from the defaults
+            self.lib.brie_oracle_b_config(ctypes.c_int(1), ctypes.c_int(1), ctypes.c_int(64))
         dt = self.dtype
         self.counts = [np.ascontiguousarray(c, dt) for c in counts]
         self.Nc, self.Ng = self.counts[0].shape
@@ -101,6 +104,17 @@ class COracle(object):
 
     def threads(self):
         return int(self.lib.brie_oracle_threads())
+
+    def b_config(self, float_noise=1, reverse=1, chunk=64):
+        """Knobs of the o32b build (a member of the null ensemble, tests/golden/psi_ensemble_manifest.json): Box-Muller in
+        float or exact, the thread's cells in reverse or forward order, cells per fp32 partial sum."""
+        if self.lib.brie_oracle_b_config(ctypes.c_int(int(float_noise)), ctypes.c_int(int(reverse)), ctypes.c_int(int(chunk))) != 0:
+            raise ValueError("b_config: not the o32b build (variant_b=True)")
+
+    def set_parts(self, n):
+        """Cut the cells into n parts (own accumulators, summed in part order) whatever the thread count: the arithmetic
+        of a run on n OpenMP threads, reproducible on any host.  0 = one part per thread (the default)."""
+        self.lib.brie_oracle_set_parts(ctypes.c_int(int(n)))
 
     def set_threads(self, n):
         """OpenMP threads of the fused pass (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks)."""

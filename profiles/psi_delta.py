@@ -88,6 +88,12 @@ CASES = {
                           desc="configs[2] shape, fourth seeds: 256 genes over all cells, 996 steps, MC_size 1"),
     "c3_cli_64_s4": dict(Nc=50000, Ng=64, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=99991, seed=41,
                          desc="configs[2] shape, fourth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
+    # round 5: ONE new held-out set of seeds per shape for the pre-registered null ensemble (profiles/psi_ensemble.py;
+    # tests/golden/psi_ensemble_manifest.json) -- chosen before any run of either side
+    "c2_cli_64_s5": dict(Nc=10000, Ng=64, Kc=1, L=3, theta=1.5, min_iter=5000, MC=3, data_seed=5550123, seed=59,
+                         desc="configs[1] shape, fifth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
+    "c3_cli_64_s5": dict(Nc=50000, Ng=64, Kc=3, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=5550123, seed=59,
+                         desc="configs[2] shape, fifth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
 }
 HELD_OUT_2 = ("c1_cli_s4", "c2_api_512_s4", "c2_cli_128_s4", "mid_api_256_s4", "mid_cli_96_s4", "c3_api_256_s4", "c3_cli_64_s4")
 HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2", "mid_api_256_s3", "mid_cli_96_s3")

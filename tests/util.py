@@ -283,3 +283,95 @@ def psi_null_of(sh, o32, o32b, cols=None, what=""):
     h = gene_summaries(psi_h, o32.Psi, run_params(sh, cols), run_params(o32))
     n = gene_summaries(o32b.Psi, o32.Psi, run_params(o32b), run_params(o32))
     return psi_null_rule(h, n, what)
+
+
+# ---- the pre-registered null ENSEMBLE (round 5) -------------------------------------------------------
+# One null draw is a yardstick noisier than the 1.5x margin of psi_null_rule (three draws of c3_cli_128 left 118-131 /
+# 202-207 / 284-313 scattered entries, docs/evidence_r4.md section 3), so the fit-level rule for the brie-quant default
+# schedule holds the HIP run against an ENSEMBLE of fp32 CPU evaluations, fixed in tests/golden/psi_ensemble_manifest.json
+# (members, cases, seeds, constants) BEFORE any member of the new cases was computed and before HIP ran on the held-out ones.
+ENSEMBLE_FACTOR = 1.25          # each statistic of the judged run <= FACTOR x the ensemble's largest + its floor
+ENSEMBLE_FLOORS = {"moved_genes": lambda Ng, entries: max(2.0, 0.01 * Ng),        # genes
+                   "quiet_rate": lambda Ng, entries: max(1e-5, 20.0 / max(entries, 1)),   # entries beyond 1e-4 per entry
+                   "quiet_p99": lambda Ng, entries: 5e-6}                         # Psi units
+ENSEMBLE_MAX_FLOOR, ENSEMBLE_MAX_FACTOR = 2e-3, 1.5      # worst entry of the genes not displaced: <= max(FLOOR, FACTOR x ensemble)
+ENSEMBLE_SHIFT_CAP = 0.15       # largest own-parameter shift, absolute (as psi_null_rule's rule 5)
+
+
+def comparison_stats(s):
+    """The statistics of ONE comparison (a run vs the fp32 oracle o32; `s` = gene_summaries(run, o32)) that
+    psi_ensemble_rule judges.  Self-contained: the partition into displaced / clustered / quiet genes is that of the
+    comparison itself (psi_null_rule's pairwise 'moved in neither' needs a partner; an ensemble has several)."""
+    Ng, Nc = s["shift"].shape[0], s["Nc"]
+    cluster = max(5, int(1e-3 * Nc))
+    disp = s["shift"] > GENE_SHIFT
+    clus = ~disp & (s["n_gt"] > cluster)
+    quiet = ~(disp | clus)
+    entries = int(quiet.sum()) * Nc
+    n_q = int(s["n_gt"][quiet].sum())
+    return {"genes": int(Ng), "cells": int(Nc), "displaced_genes": int(disp.sum()), "clustered_genes": int(clus.sum()),
+            "moved_genes": int((disp | clus).sum()),
+            "quiet_entries": entries, "quiet_gt_1e-4": n_q, "quiet_rate": n_q / max(entries, 1),
+            "quiet_p99": _p99_from_hist(s["hist"][quiet]) if quiet.any() else 0.0,
+            "undisplaced_max": float(s["max"][~disp].max()) if (~disp).any() else 0.0,
+            "shift_max": float(s["shift"].max()), "all_gt_1e-4": int(s["n_gt"].sum()), "all_max": float(s["max"].max())}
+
+
+def _ensemble_violations(x, members):
+    """Violations of the ensemble rule by the statistics `x` against the list of member statistics."""
+    viol = []
+    Ng = x["genes"]
+    entries = max([x["quiet_entries"]] + [m["quiet_entries"] for m in members])
+    for k in ("moved_genes", "quiet_rate", "quiet_p99"):
+        top = max(m[k] for m in members)
+        bound = ENSEMBLE_FACTOR * top + ENSEMBLE_FLOORS[k](Ng, entries)
+        if not x[k] <= bound:
+            viol.append((k, x[k], top, bound))
+    top = max(m["undisplaced_max"] for m in members)
+    bound = max(ENSEMBLE_MAX_FLOOR, ENSEMBLE_MAX_FACTOR * top)
+    if not x["undisplaced_max"] <= bound:
+        viol.append(("undisplaced_max", x["undisplaced_max"], top, bound))
+    if not x["shift_max"] <= ENSEMBLE_SHIFT_CAP:
+        viol.append(("shift_max", x["shift_max"], ENSEMBLE_SHIFT_CAP, ENSEMBLE_SHIFT_CAP))
+    return viol
+
+
+def psi_ensemble_rule(h, members, what="", check=True):
+    """THE fit-level parity rule since round 5 for the brie-quant default schedule (4 998 steps, MC_size 3): the HIP path
+    against the fp32 CPU restatement o32, held against an ENSEMBLE of further fp32 CPU evaluations of the same algorithm
+    against that same o32 run (same problem, init and noise stream).  `h` = gene_summaries(HIP, o32); `members` = dict
+    name -> gene_summaries(member, o32).  The members are fixed by tests/golden/psi_ensemble_manifest.json (o32b at 2 / 4 /
+    6 / 8 / 12 OpenMP threads + one member with the EXACT noise stream, forward order and 128-cell partial sums), NOT chosen
+    after seeing a HIP run.  Per comparison (comparison_stats): displaced gene = own-parameter shift > 4e-4; clustered =
+    not displaced, more than max(5, 0.1 % of its cells) beyond 1e-4; quiet = neither.  With E_k the LARGEST value of
+    statistic k over the members:
+      1. moved genes (displaced + clustered)        <= 1.25 E_1 + max(2, 1 % of the genes)
+      2. entries of quiet genes beyond 1e-4, per entry  <= 1.25 E_2 + max(1e-5, 20 / entries)
+      3. 99th percentile over the quiet genes        <= 1.25 E_3 + 5e-6
+      4. worst entry of the genes not displaced      <= max(2e-3, 1.5 E_4)
+      5. largest own-parameter shift                 <= 0.15
+    The report also carries the LEAVE-ONE-OUT record of the ensemble itself: every member judged by the same rule against
+    the other members -- the rule's own false-alarm rate on runs that are the reference's arithmetic by construction.
+    A case that fails is reported as failing; the constants above are not revisited."""
+    names = sorted(members)
+    ms = {k: comparison_stats(members[k]) for k in names}
+    x = comparison_stats(h)
+    viol = _ensemble_violations(x, [ms[k] for k in names])
+    loo = {}
+    for k in names:
+        others = [ms[j] for j in names if j != k]
+        if others:
+            v = _ensemble_violations(ms[k], others)
+            loo[k] = [list(t) for t in v]
+    keys = ("moved_genes", "displaced_genes", "clustered_genes", "quiet_gt_1e-4", "quiet_rate", "quiet_p99",
+            "undisplaced_max", "shift_max")
+    rep = {"genes": x["genes"], "cells": x["cells"], "hip_vs_o32": {k: x[k] for k in keys},
+           "ensemble_vs_o32": {n: {k: ms[n][k] for k in keys} for n in names},
+           "leave_one_out": {"members_failing": sorted(k for k, v in loo.items() if v), "of": len(loo),
+                             "violations": {k: v for k, v in loo.items() if v}},
+           "holds": not viol}
+    if viol:
+        rep["violated"] = [list(v) for v in viol]
+    if check:
+        assert not viol, (what, viol, rep)
+    return rep

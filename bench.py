@@ -429,9 +429,22 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if os.environ.get("BRIE_BENCH_ECHO_RANK"):          # launcher test (CPU): what reached the ranks, no GPU touched
+        echo = {"echo": True, "world": world, "argv": argv, "master_addr": os.environ.get("MASTER_ADDR"),
+                "local_world": os.environ.get("LOCAL_WORLD_SIZE")}
+        if os.environ["BRIE_BENCH_ECHO_RANK"] == "shards" and world > 1:
+            # ... and the gene range every rank would fit, gathered over gloo (tests/test_world8_cpu.py: world 8 without GPUs)
+            import torch.distributed as dist
+            from brie_amd.sharding import gene_shard
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            Ng = CONFIGS[args.config]["Ng"]
+            mine = {"rank": rank, "local_rank": local_rank,
+                    "genes": list(gene_shard(Ng, rank, world)) if args.scaling == "strong" else [0, Ng]}
+            box = [None] * world
+            dist.all_gather_object(box, mine)
+            dist.destroy_process_group()
+            echo["shards"] = box
         if rank == 0:
-            print(json.dumps({"echo": True, "world": world, "argv": argv, "master_addr": os.environ.get("MASTER_ADDR"),
-                              "local_world": os.environ.get("LOCAL_WORLD_SIZE")}))
+            print(json.dumps(echo))
         return
 
     import torch

@@ -19,6 +19,8 @@ ABI_VERSION = 2
 MAX_KC = 1024        # 0..8 in registers, 9..64 on the matrix cores inside the streaming pass, beyond in 64-feature panels
 MAX_KG = 1024        # 0..4 in registers, 5..64 as a tile in LDS / on the matrix cores, beyond in 64-feature panels
 
+PLACEMENT_MAX_SETS = 8          # BRIE_PLACEMENT_MAX_SETS
+PLACEMENT_STATES = ("not_run", "good", "best_of_all", "stopped_memory", "stopped_time", "stopped_error", "off")   # brie_placement_state
 EXPORTS = [
     "brie_create", "brie_destroy", "brie_upload", "brie_upload_typed", "brie_upload_sparse", "brie_add_pseudo_count", "brie_init_state",
     "brie_reset_optimizer", "brie_step", "brie_step_begin", "brie_rowstat_buffer", "brie_set_rowstat_buffer",
@@ -31,7 +33,7 @@ EXPORTS = [
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
-    "brie_placement_probe", "brie_placement_tune", "brie_placement_info", "brie_probe_layouts",
+    "brie_placement_probe", "brie_placement_tune", "brie_placement_info", "brie_placement_status", "brie_probe_layouts",
 ]
 COMM_ID_BYTES = 128
 #: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
@@ -131,6 +133,7 @@ def load_library(path=None):
     lib.brie_probe_layouts.argtypes = [i32, i64, i64, i64, i32, vp, i32, vp]
     lib.brie_placement_probe.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_placement_tune.argtypes = [vp, i32, ctypes.c_double]
+    lib.brie_placement_status.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, i32]
     lib.brie_placement_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double),
                                         ctypes.POINTER(ctypes.c_double)]
     lib.brie_last_error.restype = ctypes.c_char_p
@@ -517,11 +520,18 @@ class Shard(object):
         return self.placement_info()
 
     def placement_info(self):
+        """Sets probed, the one in use (0 = the original), their rates, the seconds the search took, how it ended
+        (PLACEMENT_STATES), its peak transient holding of candidate sets and, when it ended short of a fast set, why."""
         t, k, s = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
-        g = (ctypes.c_double * 4)()
+        g = (ctypes.c_double * PLACEMENT_MAX_SETS)()
         _check(self.lib, self.lib.brie_placement_info(self._h, ctypes.byref(t), ctypes.byref(k), g, ctypes.byref(s)))
-        return {"tries": t.value, "kept": k.value, "GBs": [round(g[i], 1) for i in range(t.value)],
-                "seconds": round(s.value, 4)}
+        st, peak, note = ctypes.c_int32(), ctypes.c_int64(), ctypes.create_string_buffer(192)
+        _check(self.lib, self.lib.brie_placement_status(self._h, ctypes.byref(st), ctypes.byref(peak), note, 192))
+        out = {"tries": t.value, "kept": k.value, "GBs": [round(g[i], 1) for i in range(t.value)],
+               "seconds": round(s.value, 4), "status": PLACEMENT_STATES[st.value], "peak_extra_bytes": peak.value}
+        if note.value:
+            out["note"] = note.value.decode()
+        return out
 
     def loglik_mc(self, size=10):
         """(Nc, Ng) Monte-Carlo log-likelihood of every entry under the current target (brie_loglik_mc)."""

@@ -169,9 +169,11 @@ struct brie_handle {
     int64_t prof_launches = 0;
     // placement of the streamed arrays (brie_placement_tune): rates of the sets that were probed, which one was kept
     bool placement_done = false;
-    int placement_tries = 0, placement_kept = 0;
-    double placement_gbs[4] = {0.0, 0.0, 0.0, 0.0};
+    int placement_tries = 0, placement_kept = 0, placement_status = BRIE_PLACEMENT_NOT_RUN;
+    double placement_gbs[BRIE_PLACEMENT_MAX_SETS] = {};
     double placement_seconds = 0.0;
+    int64_t placement_peak_bytes = 0;       // largest transient holding of candidate sets during a search
+    char placement_note[192] = {0};         // why the search ended the way it did (brie_placement_status)
 };
 
 namespace {
@@ -475,6 +477,14 @@ int build_tier_tables(brie_handle *h) {
     return BRIE_OK;
 }
 
+// the streamed arrays were replaced (counts expanded / re-tiered): what the search measured no longer describes them
+void placement_invalidate(brie_handle *h) {
+    h->placement_done = false;
+    h->placement_tries = 0; h->placement_kept = 0; h->placement_status = BRIE_PLACEMENT_NOT_RUN;
+    for (double &g : h->placement_gbs) g = 0.0;
+    h->placement_note[0] = '\0';
+}
+
 int try_compact_counts(brie_handle *h) {
     if (h->compact_tried) return BRIE_OK;
     h->compact_tried = true;
@@ -525,6 +535,7 @@ int try_compact_counts(brie_handle *h) {
     // what compaction saves (2 - 3 arrays of Nc x Ng floats) is memory the caller may be counting on
     for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->c[l])); h->c[l] = nullptr; }
     h->cs = cs;
+    placement_invalidate(h);                      // fresh count arrays (a re-upload after a search): the next step probes again
     return BRIE_OK;
 }
 
@@ -558,6 +569,7 @@ int retier_uniform_u16(brie_handle *h) {
     HIP_TRY(hipFree(tmp));
     for (int l = 0; l < h->p.n_layers; ++l) { HIP_TRY(hipFree(h->cu[l])); h->cu[l] = fresh[l]; }
     h->cs = brie::kCountU16;
+    placement_invalidate(h);                      // fresh count arrays: the next step probes again
     return free_tier_tables(h);
 }
 
@@ -579,6 +591,7 @@ int expand_counts(brie_handle *h) {
     h->cs = brie::kCountF32;
     h->pc = 0.0f;
     h->allow_compact = false;                     // values are no longer integers
+    placement_invalidate(h);                      // fresh count arrays: the next step probes again
     return BRIE_OK;
 }
 
@@ -1642,7 +1655,7 @@ int wide_forward_mean(brie_handle *h) {
 // placement_probe (the step kernel's traffic without arithmetic or effect) is timed on the handle's arrays; while the
 // rate is below `good_gbs` another set is allocated WHILE the current one is still held (other physical pages),
 // filled by device-to-device copies, probed, and the faster set is kept.  A few launches and copies per try.
-int probe_rate(brie_handle *h, int iters, double *gbs) {
+int probe_rate(brie_handle *h, int iters, double *gbs, bool two_per_cu) {
     brie::StepScalars a{};
     a.ld = h->ld; a.row_stride = h->row_stride; a.gb_stride = h->gb_stride;
     a.Nc = static_cast<int32_t>(h->p.Nc); a.Ng = static_cast<int32_t>(h->p.Ng);
@@ -1651,9 +1664,10 @@ int probe_rate(brie_handle *h, int iters, double *gbs) {
     const bool compact = h->cs != brie::kCountF32;
     const void *c[3];
     for (int l = 0; l < 3; ++l) c[l] = compact ? static_cast<const void *>(h->cu[l]) : h->c[l];
-    const bool l3 = h->p.n_layers == 3;
+    const bool l3 = h->mode == brie::kLikEff3;      // the layers the step READS: the third only with effLen (model_TFProb.py:184-185)
     const dim3 grid(h->gene_blocks, h->n_chunks), block(brie::kBlock);
-    const int pad = 81 * 1024;                      // one workgroup per CU, as the step kernel runs (brie_inst.hip)
+    // the step's occupancy (brie_inst.hip): one workgroup per CU for MC_size 1 (2 x pad > 160 KB), two otherwise (3 x pad > 160 KB)
+    const int pad = two_per_cu ? 54 * 1024 : 81 * 1024;
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0));
     HIP_TRY(hipEventCreate(&e1));
@@ -1726,17 +1740,55 @@ inline int placement_class(const brie_handle *h) {
     return static_cast<size_t>(h->p.Nc) * h->ld * sizeof(float) < (size_t(1) << 30) ? 1 : 0;
 }
 
-int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
-    if (max_tries > 4) max_tries = 4;
+// One search: probe the arrays as they are; while the best rate is below `good_gbs`, allocate further candidate sets
+// -- in ROUNDS, every earlier set still held so that the allocator has to reach into other physical stretches --, fill
+// them by device-to-device copies, probe, and keep the fastest; everything else is freed when the search is over.
+// BEST EFFORT: the search is an optimisation, so nothing that goes wrong inside it fails the caller's step --
+// the fastest complete set is re-adopted, the candidates are freed, the HIP error is cleared, the reason is kept in
+// placement_status / placement_note (brie_placement_status) and the function returns BRIE_OK.  Only an error of the
+// caller's EARLIER work on the stream is returned.
+//  * memory: before every round hipMemGetInfo is read afresh and the round takes at most `frac` (BRIE_PLACEMENT_HBM_FRACTION,
+//    default 0.8) of what is free beyond a 2-GiB reserve; an allocation that fails anyway ends the search with what it has.
+//    Peak transient holding = (sets held) x (streamed bytes), reported by brie_placement_status.
+//  * time: no new round and no new candidate once `max_seconds` (BRIE_PLACEMENT_SECONDS, default 3) have passed.
+//  * sets: at most max_sets <= BRIE_PLACEMENT_MAX_SETS (8) in all, the original included.
+int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_cu) {
+    max_sets = std::max(1, std::min(max_sets, static_cast<int>(BRIE_PLACEMENT_MAX_SETS)));
     // BRIE_PLACEMENT_INTERLEAVE=0: candidate sets one after the other, each allocated as a block (A/B runs; the first version)
     static const bool interleave = [] { const char *e = getenv("BRIE_PLACEMENT_INTERLEAVE"); return !(e && e[0] == '0'); }();
+    static const double max_seconds = [] { const char *e = getenv("BRIE_PLACEMENT_SECONDS"); return e ? atof(e) : 3.0; }();
+    static const double frac = [] {
+        const char *e = getenv("BRIE_PLACEMENT_HBM_FRACTION");
+        const double f = e ? atof(e) : 0.8;
+        return f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
+    }();
     const auto t0 = std::chrono::steady_clock::now();
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    HIP_TRY(hipStreamSynchronize(h->stream));               // the caller's earlier work: its errors are its own
+    h->placement_done = true;
+    h->placement_tries = 0; h->placement_kept = 0; h->placement_peak_bytes = 0; h->placement_note[0] = '\0';
+    for (double &g : h->placement_gbs) g = 0.0;
+    auto note = [&](const char *what, const char *detail) {
+        snprintf(h->placement_note, sizeof(h->placement_note), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+    };
+    auto finish = [&](int status) {
+        h->placement_status = status;
+        (void)hipGetLastError();
+        h->placement_seconds += elapsed();
+        return BRIE_OK;
+    };
+    // test hook (tests/test_gpu_placement.py): BRIE_PLACEMENT_INJECT_FAILURE = 1 the first probe, 2 a candidate allocation,
+    // 3 a candidate's probe, 4 a candidate copy fails -- read at every search, so a test can set it for one handle
+    const char *inj_s = getenv("BRIE_PLACEMENT_INJECT_FAILURE");
+    const int inject = inj_s ? atoi(inj_s) : 0;
     const int iters = 3;
     double best = 0.0;
-    int rc = probe_rate(h, iters, &best);
-    if (rc != BRIE_OK) return rc;
-    h->placement_tries = 1; h->placement_kept = 0; h->placement_gbs[0] = best;
+    if (inject == 1 || probe_rate(h, iters, &best, two_per_cu) != BRIE_OK) {      // the arrays stay where they are
+        if (inject == 1) (void)fail(BRIE_ERR_HIP, "injected failure");
+        note("probe of the original set failed", brie_last_error());
+        return finish(BRIE_PLACEMENT_STOPPED_ERROR);
+    }
+    h->placement_tries = 1; h->placement_gbs[0] = best;
     static const bool log_sets = getenv("BRIE_PLACEMENT_LOG") != nullptr;      // experiments: where every set lives
     auto log_set = [&](int t, double rate) {
         if (!log_sets) return;
@@ -1749,78 +1801,96 @@ int tune_placement(brie_handle *h, int max_tries, double good_gbs) {
     const StreamedSet first = streamed_set(h);
     size_t total = 0;
     for (int i = 0; i < first.n; ++i) total += first.bytes[i];
+    auto drop = [](StreamedSet &s) { for (int i = 0; i < s.n; ++i) if (s.p[i]) { (void)hipFree(s.p[i]); s.p[i] = nullptr; } };
     // Candidate sets.  Arrays that lie next to each other in physical memory stream slower than arrays that lie far apart
     // (one slab, the same memory, calls r4k / r4l: packed 5.2 TB/s, the same arrays 18 GB apart 6.3 TB/s in every process),
-    // and a block of fresh allocations is handed out back to back.  So the candidates are allocated INTERLEAVED -- array 0
-    // of every candidate, then array 1 of every candidate, ... -- which puts the arrays of one set a few arrays apart at no
-    // cost; every candidate is probed and all but the fastest set are freed when the search is over (a set that is freed
-    // early is what the next hipMalloc hands out again, call r4a).
-    int n_cand = 0;
-    if (best < good_gbs && max_tries > 1) {
+    // and a block of fresh allocations is handed out back to back.  So the candidates of a round are allocated INTERLEAVED
+    // -- array 0 of every candidate, then array 1 of every candidate, ... -- which puts the arrays of one set a few arrays
+    // apart at no cost.  A set that is freed early is what the next hipMalloc hands out again (call r4a), so every set is
+    // HELD until the search is over: a second round (round 5; the driver's round-4 run needed the last of four sets) has to
+    // land somewhere else.  Arrays below a gigabyte are not spread by interleaving ("a few arrays apart" is then no distance,
+    // call r4z): their candidates come one at a time (27 allocations and frees up front were most of 15 - 40 ms).
+    const int round_size = placement_class(h) == 1 ? 1 : 3;
+    std::vector<StreamedSet> held;                // candidate k is set k + 1
+    int kept = -1, status = -1;
+    while (best < good_gbs && 1 + static_cast<int>(held.size()) < max_sets) {
+        if (elapsed() > max_seconds) { status = BRIE_PLACEMENT_STOPPED_TIME; break; }
         size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        n_cand = max_tries - 1;
-        while (n_cand > 0 && free_b < static_cast<size_t>(n_cand) * total + (size_t(2) << 30)) --n_cand;   // what fits
-    }
-    std::vector<StreamedSet> cand(static_cast<size_t>(n_cand));
-    auto drop = [](StreamedSet &s) { for (int i = 0; i < s.n; ++i) if (s.p[i]) { (void)hipFree(s.p[i]); s.p[i] = nullptr; } };
-    hipError_t e = hipSuccess;
-    for (StreamedSet &c : cand) { c.n = first.n; for (int i = 0; i < first.n; ++i) c.bytes[i] = first.bytes[i]; }
-    // Arrays below a gigabyte are not spread by interleaving ("a few arrays apart" is then no distance, call r4z): their
-    // candidates are allocated one at a time, only when the search gets to them (27 allocations and frees up front were
-    // most of its 15 - 40 ms), and held until the end like the others.
-    const bool lazy = placement_class(h) == 1;      // (A/B against interleaved up front: no difference, call r4as)
-    if (lazy) {
-    } else if (interleave) {
-        for (int i = 0; i < first.n && e == hipSuccess; ++i)
-            for (int k = 0; k < n_cand && e == hipSuccess; ++k) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
-    } else {
-        for (int k = 0; k < n_cand && e == hipSuccess; ++k)
-            for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
-    }
-    if (e != hipSuccess) {                       // out of memory half way: search among what is complete (nothing, usually)
-        (void)hipGetLastError();
-        for (StreamedSet &c : cand) drop(c);
-        n_cand = 0;
-    }
-    int kept = -1;                               // index into cand, -1 = the first set
-    for (int k = 0; k < n_cand && rc == BRIE_OK; ++k) {
-        if (best >= good_gbs) break;                                // good enough: the remaining candidates are not needed
-        if (lazy) {
-            for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&cand[k].p[i], first.bytes[i]);
-            if (e != hipSuccess) { (void)hipGetLastError(); e = hipSuccess; drop(cand[k]); break; }     // out of memory: keep the best so far
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { note("hipMemGetInfo failed", nullptr); status = BRIE_PLACEMENT_STOPPED_ERROR; break; }
+        const size_t reserve = size_t(2) << 30;
+        const size_t usable = free_b > reserve ? static_cast<size_t>(static_cast<double>(free_b - reserve) * frac) : 0;
+        const int n_round = static_cast<int>(std::min<size_t>({static_cast<size_t>(round_size),
+                                                               static_cast<size_t>(max_sets - 1) - held.size(), usable / total}));
+        if (n_round <= 0) { status = BRIE_PLACEMENT_STOPPED_MEMORY; break; }
+        const size_t base = held.size();
+        held.resize(base + static_cast<size_t>(n_round));
+        for (size_t k = base; k < held.size(); ++k) { held[k].n = first.n; for (int i = 0; i < first.n; ++i) held[k].bytes[i] = first.bytes[i]; }
+        hipError_t e = hipSuccess;
+        if (interleave) {
+            for (int i = 0; i < first.n && e == hipSuccess; ++i)
+                for (size_t k = base; k < held.size() && e == hipSuccess; ++k) e = hipMalloc(&held[k].p[i], first.bytes[i]);
+        } else {
+            for (size_t k = base; k < held.size() && e == hipSuccess; ++k)
+                for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&held[k].p[i], first.bytes[i]);
         }
-        for (int i = 0; i < first.n && e == hipSuccess; ++i)
-            e = hipMemcpyAsync(cand[k].p[i], first.p[i], first.bytes[i], hipMemcpyDeviceToDevice, h->stream);
-        if (e != hipSuccess) { rc = fail(BRIE_ERR_HIP, "placement copy: %s", hipGetErrorString(e)); break; }
-        adopt_set(h, cand[k]);
-        double r = 0.0;
-        rc = probe_rate(h, iters, &r);
-        h->placement_gbs[k + 1] = r;
-        h->placement_tries = k + 2;
-        log_set(k + 1, r);
-        if (rc == BRIE_OK && r > best) { best = r; kept = k; h->placement_kept = k + 1; }
+        if (inject == 2 && e == hipSuccess) e = hipErrorOutOfMemory;
+        if (e != hipSuccess) {                     // someone else took the memory in between: search over, keep the best so far
+            (void)hipGetLastError();
+            for (size_t k = base; k < held.size(); ++k) drop(held[k]);
+            held.resize(base);
+            note("candidate allocation failed", hipGetErrorString(e));
+            status = BRIE_PLACEMENT_STOPPED_MEMORY;
+            break;
+        }
+        h->placement_peak_bytes = std::max<int64_t>(h->placement_peak_bytes, static_cast<int64_t>(held.size() * total));
+        for (size_t k = base; k < held.size() && status < 0; ++k) {
+            if (best >= good_gbs) break;                            // good enough: the remaining candidates are not needed
+            if (k > base && elapsed() > max_seconds) { status = BRIE_PLACEMENT_STOPPED_TIME; break; }
+            for (int i = 0; i < first.n && e == hipSuccess; ++i)
+                e = hipMemcpyAsync(held[k].p[i], first.p[i], first.bytes[i], hipMemcpyDeviceToDevice, h->stream);
+            if (inject == 4 && e == hipSuccess) e = hipErrorInvalidValue;
+            if (e != hipSuccess) { note("placement copy failed", hipGetErrorString(e)); status = BRIE_PLACEMENT_STOPPED_ERROR; break; }
+            adopt_set(h, held[k]);
+            double r = 0.0;
+            if (probe_rate(h, iters, &r, two_per_cu) != BRIE_OK || (inject == 3 && fail(BRIE_ERR_HIP, "injected failure") != BRIE_OK)) {
+                note("probe of a candidate set failed", brie_last_error());
+                status = BRIE_PLACEMENT_STOPPED_ERROR;
+                break;
+            }
+            const int set_no = static_cast<int>(k) + 1;
+            h->placement_gbs[set_no] = r;
+            h->placement_tries = set_no + 1;
+            log_set(set_no, r);
+            if (r > best) { best = r; kept = static_cast<int>(k); h->placement_kept = set_no; }
+        }
+        if (status >= 0) break;
     }
-    adopt_set(h, kept < 0 ? first : cand[kept]);
+    if (status < 0) status = best >= good_gbs ? BRIE_PLACEMENT_GOOD : BRIE_PLACEMENT_BEST_OF_ALL;
+    adopt_set(h, kept < 0 ? first : held[static_cast<size_t>(kept)]);     // the fastest COMPLETE set (first is never written to)
     (void)hipStreamSynchronize(h->stream);
-    for (int k = 0; k < n_cand; ++k)
-        if (k != kept) drop(cand[k]);
+    for (size_t k = 0; k < held.size(); ++k)
+        if (static_cast<int>(k) != kept) drop(held[k]);
     if (kept >= 0) { StreamedSet f = first; drop(f); }
-    if (rc != BRIE_OK) return rc;
+    if (status == BRIE_PLACEMENT_BEST_OF_ALL || status == BRIE_PLACEMENT_STOPPED_MEMORY || status == BRIE_PLACEMENT_STOPPED_TIME) {
+        if (!h->placement_note[0]) {
+            char buf[96];
+            snprintf(buf, sizeof(buf), "best of %d sets %.0f GB/s, below the stop rate %.0f GB/s", h->placement_tries, best, good_gbs);
+            note(status == BRIE_PLACEMENT_BEST_OF_ALL ? "no set reached the stop rate"
+                 : (status == BRIE_PLACEMENT_STOPPED_MEMORY ? "stopped by free HBM" : "stopped by the time limit"), buf);
+        }
+    }
     {
         std::lock_guard<std::mutex> l(g_place_mu);
         const int d = h->p.device & 63;
         double &seen = g_place_best[d][placement_class(h)];
         if (best > seen) seen = best;
     }
-    h->placement_done = true;
-    h->placement_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return BRIE_OK;
+    return finish(status);
 }
 
 // automatic tuning before the first step of a handle whose step streams >= 256 MiB.  BRIE_PLACEMENT_TRIES = n (1 = off,
-// default 4: the first set + three interleaved candidates); BRIE_PLACEMENT_GOOD_GBS = the rate at which no further set
-// is tried.  Default 6050: over 26 handles of
+// default 8: the first set + up to seven candidates in rounds of three); BRIE_PLACEMENT_GOOD_GBS = the rate at which no
+// further set is tried.  Default 6050: over 26 handles of
 // configs[1] / configs[2] in four processes (profiles/r4a_placement_c{2,3}.jsonl) the probe -- whose rate equals the step
 // kernel's to 1 %, correlation 0.999 at configs[2] -- read 4.93 - 5.30 TB/s in the slow mode, 5.49 - 5.94 in between and
 // 6.0 - 6.24 in the fast one; or 0.97 x the best rate a handle of this process has reached on the device if higher.
@@ -1828,11 +1898,11 @@ constexpr double kPlacementGoodGBs = 6050.0;
 // ... and for handles whose arrays are below a gigabyte 5850: the search used to run all four sets for them every time
 // (6050 was out of reach) -- 14 - 44 ms of a 0.6-s configs[1] fit even when the first set was already in the fast mode
 constexpr double kPlacementGoodSmallGBs = 5850.0;
-int auto_placement(brie_handle *h) {
+int auto_placement(brie_handle *h, int mc_size) {
     if (h->placement_done) return BRIE_OK;
     h->placement_done = true;
-    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 4; }();
-    if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) return BRIE_OK;
+    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : static_cast<int>(BRIE_PLACEMENT_MAX_SETS); }();
+    if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) { h->placement_status = BRIE_PLACEMENT_OFF; return BRIE_OK; }
     static const double good_env = [] { const char *e = getenv("BRIE_PLACEMENT_GOOD_GBS"); return e ? atof(e) : 0.0; }();
     const int cls = placement_class(h);
     double good = good_env > 0.0 ? good_env : (cls == 1 ? kPlacementGoodSmallGBs : kPlacementGoodGBs);
@@ -1840,7 +1910,7 @@ int auto_placement(brie_handle *h) {
         std::lock_guard<std::mutex> l(g_place_mu);
         good = std::max(good, 0.97 * g_place_best[h->p.device & 63][cls]);
     }
-    return tune_placement(h, tries, good);
+    return tune_placement(h, tries, good, mc_size > 1);      // the step runs two workgroups per CU for MC_size > 1 (brie_inst.hip)
 }
 
 // split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell
@@ -1859,7 +1929,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     if ((rc = io_wait(h)) != BRIE_OK) return rc;
     if ((rc = ensure_partials(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
-    if ((rc = auto_placement(h)) != BRIE_OK) return rc;
+    if ((rc = auto_placement(h, mc_size)) != BRIE_OK) return rc;
     const size_t lp_need = static_cast<size_t>(n_steps) * h->fin_blocks * 2;
     if (lp_need > h->loss_parts_elems) {
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2561,7 +2631,7 @@ int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs) {
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = io_wait(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
-    return probe_rate(h, iters, gbs);
+    return probe_rate(h, iters, gbs, false);
 }
 
 int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs) {
@@ -2572,15 +2642,23 @@ int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs) {
     if ((rc = set_device(h)) != BRIE_OK) return rc;
     if ((rc = io_wait(h)) != BRIE_OK) return rc;
     if ((rc = try_compact_counts(h)) != BRIE_OK) return rc;
-    return tune_placement(h, max_tries, good_gbs);
+    return tune_placement(h, max_tries, good_gbs, false);
 }
 
 int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (tries) *tries = h->placement_tries;
     if (kept) *kept = h->placement_kept;
-    if (gbs) for (int i = 0; i < 4; ++i) gbs[i] = h->placement_gbs[i];
+    if (gbs) for (int i = 0; i < BRIE_PLACEMENT_MAX_SETS; ++i) gbs[i] = h->placement_gbs[i];
     if (seconds) *seconds = h->placement_seconds;
+    return BRIE_OK;
+}
+
+int brie_placement_status(const brie_handle *h, int32_t *status, int64_t *peak_bytes, char *note, int32_t note_len) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (status) *status = h->placement_status;
+    if (peak_bytes) *peak_bytes = h->placement_peak_bytes;
+    if (note && note_len > 0) snprintf(note, static_cast<size_t>(note_len), "%s", h->placement_note);
     return BRIE_OK;
 }
 

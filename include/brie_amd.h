@@ -152,7 +152,11 @@ int brie_reset_optimizer(brie_handle *h);
 /* tfp.math.minimize(loss_fn, num_steps, optimizer) (model_TFProb.py:239-241,
  * 255-257) with Keras Adam(lr) + the clip[-9,9] constraints (:69,81).
  * `loss_trace` (host, n_steps floats, may be NULL) receives the ELBO loss
- * BEFORE each update.  With loss_trace == NULL the call only enqueues work. */
+ * BEFORE each update.  With loss_trace == NULL the call only enqueues work.
+ * The FIRST step of a handle that streams >= 256 MiB per step also compacts integer count layers and runs the placement
+ * search ("Placement of the streamed arrays" below): it blocks for 0.1 - 3 s and transiently holds up to seven further
+ * copies of the handle's streamed arrays (bounded by the free HBM read at that moment; BRIE_PLACEMENT_TRIES=1 switches
+ * it off).  The search is best effort -- it never fails the step -- and changes addresses only, never values. */
 int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
               float *loss_trace);
 
@@ -310,23 +314,48 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  * handle's step kernel streams depends on where the allocator put its arrays: byte-identical code on identical data runs
  * at 8.1 or at 9.5 ms per step at configs[2] -- arrays that lie next to each other in physical
  * memory stream slower than arrays that lie far apart.  The library therefore measures: a probe kernel with the step
- * kernel's traffic and no effect on the data is timed on the handle's arrays; if its rate (GB/s of
- * brie_step_storage_bytes) is below `good_gbs` and HBM has room, up to max_tries - 1 candidate sets are allocated
- * INTERLEAVED (array 0 of every candidate, then array 1 of every candidate, ...: the arrays of one set end up a few arrays
- * apart), filled by device-to-device copies and probed until one is good; the fastest set is kept, the others are freed when
- * the search is over (results are bit-identical: only addresses change).  brie_step does this by itself before the first
- * step of a handle that streams >= 256 MiB per step: BRIE_PLACEMENT_TRIES sets in all (default 4; 1 = off), good_gbs =
- * BRIE_PLACEMENT_GOOD_GBS (default 6050 -- 5850 for handles whose arrays are below 1 GiB, which never read faster than
- * 6.0 TB/s --, or 0.97 x the best rate a handle of that size class has reached in this process on the device when that
- * is higher).  Typical cost at configs[2]: 0.17 s (three candidates of 26 GB allocated, one or two copied and probed);
- * 0.8 - 3 s when the allocator has a slow moment.
- *  brie_placement_probe: rate of the probe on the arrays as they are (iters timed launches after one warm-up).
- *  brie_placement_tune : the procedure above on demand, at most max_tries <= 4 sets.
- *  brie_placement_info : sets probed so far, which one is in use (0 = the original), their rates (gbs[4]) and the
- *                        seconds spent probing, allocating and copying; any pointer may be NULL. */
+ * kernel's traffic and no effect on the data is timed on the handle's arrays; while its rate (GB/s of
+ * brie_step_storage_bytes) is below `good_gbs`, candidate sets are allocated in rounds of three, INTERLEAVED (array 0 of
+ * every candidate, then array 1 of every candidate, ...: the arrays of one set end up a few arrays apart; one candidate at a
+ * time for arrays below 1 GiB), filled by device-to-device copies and probed; every set is held until the search is over
+ * (a freed set is what the allocator hands out again), then the fastest is kept and the others are freed (results are
+ * bit-identical: only addresses change).  brie_step does this by itself before the first step of a handle that streams
+ * >= 256 MiB per step (see brie_step): BRIE_PLACEMENT_TRIES sets in all (default BRIE_PLACEMENT_MAX_SETS = 8; 1 = off),
+ * good_gbs = BRIE_PLACEMENT_GOOD_GBS (default 6050 -- 5850 for handles whose arrays are below 1 GiB, which never read
+ * faster than 6.0 TB/s --, or 0.97 x the best rate a handle of that size class has reached in this process on the device
+ * when that is higher).
+ *  BOUNDS.  Memory: before every round hipMemGetInfo is read afresh and the round takes at most BRIE_PLACEMENT_HBM_FRACTION
+ *  (default 0.8) of the HBM that is free beyond a 2-GiB reserve; with the sets of earlier rounds still held the transient
+ *  peak is (sets held) x brie_step_storage_bytes-worth of arrays -- at configs[2] 26 GB per set, 78 GB after one round,
+ *  182 GB if all seven candidates are needed -- and it is reported by brie_placement_status.  A process that shares the GPU
+ *  and cannot spare that sets BRIE_PLACEMENT_TRIES or BRIE_PLACEMENT_HBM_FRACTION lower.  Time: no new candidate once
+ *  BRIE_PLACEMENT_SECONDS (default 3) have passed.  Typical cost at configs[2]: 0.17 s; 0.8 - 3 s when the allocator has a
+ *  slow moment.
+ *  BEST EFFORT.  Nothing that fails inside the search (probe launch, event, allocation, copy) fails the caller: the fastest
+ *  complete set is re-adopted, the candidates are freed, the HIP error is cleared and the reason is kept for
+ *  brie_placement_status.  The measurements are dropped (and the next step searches again) when the streamed arrays are
+ *  replaced: counts re-uploaded and compacted again, count storage changed, count tiers unified when gene quads are packed.
+ *  brie_placement_probe : rate of the probe on the arrays as they are (iters timed launches after one warm-up).
+ *  brie_placement_tune  : the procedure above on demand, at most max_tries <= BRIE_PLACEMENT_MAX_SETS sets.
+ *  brie_placement_info  : sets probed so far, which one is in use (0 = the original), their rates
+ *                         (gbs[BRIE_PLACEMENT_MAX_SETS]) and the seconds spent probing, allocating and copying.
+ *  brie_placement_status: how the last search ended (BRIE_PLACEMENT_*), its peak transient holding in bytes and a
+ *                         human-readable note (e.g. "no set reached the stop rate: best of 8 sets 5210 GB/s ...").
+ *  Any out-pointer may be NULL. */
+#define BRIE_PLACEMENT_MAX_SETS 8
+typedef enum brie_placement_state {
+    BRIE_PLACEMENT_NOT_RUN = 0,          /* no search yet (or its measurements were dropped) */
+    BRIE_PLACEMENT_GOOD = 1,             /* a set reached the stop rate */
+    BRIE_PLACEMENT_BEST_OF_ALL = 2,      /* every allowed set was probed, none reached the stop rate: the fastest is in use */
+    BRIE_PLACEMENT_STOPPED_MEMORY = 3,   /* free HBM did not allow another round */
+    BRIE_PLACEMENT_STOPPED_TIME = 4,     /* BRIE_PLACEMENT_SECONDS passed */
+    BRIE_PLACEMENT_STOPPED_ERROR = 5,    /* something failed inside the search (note says what); the step goes on */
+    BRIE_PLACEMENT_OFF = 6               /* handle below 256 MiB per step, or BRIE_PLACEMENT_TRIES <= 1 */
+} brie_placement_state;
 int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs);
 int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs);
 int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds);
+int brie_placement_status(const brie_handle *h, int32_t *status, int64_t *peak_bytes, char *note, int32_t note_len);
 
 /* Experiment aid: one slab of slab_bytes, the eight streamed arrays of a 2-layer u8-count problem of (Nc, Ng) placed at the
  * caller's byte offsets (offsets[n_layouts][8]: six state arrays, two count layers; multiples of 16), the placement probe

@@ -29,7 +29,7 @@ EXPORTS = [
     "brie_set_tiling", "brie_step_algorithmic_bytes", "brie_step_storage_bytes", "brie_set_count_storage",
     "brie_get_count_storage", "brie_calibrate_stream", "brie_simulate_psi", "brie_simulate_counts", "brie_device_memory", "brie_trim_memory",
     "brie_last_error", "brie_abi_version",
-    "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
+    "brie_comm_available", "brie_comm_unique_id", "brie_comm_init", "brie_comm_destroy", "brie_comm_rank", "brie_comm_world",
     "brie_comm_allgather", "brie_comm_allreduce", "brie_attach_comm",
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
@@ -112,6 +112,7 @@ def load_library(path=None):
     lib.brie_step_storage_bytes.restype = i64
     lib.brie_set_count_storage.argtypes = [vp, i32]
     lib.brie_get_count_storage.argtypes = [vp]
+    lib.brie_comm_available.argtypes = [i32]
     lib.brie_comm_unique_id.argtypes = [vp]
     lib.brie_comm_init.argtypes = [i32, i32, i32, vp, ctypes.POINTER(vp)]
     lib.brie_comm_destroy.argtypes = [vp]
@@ -153,6 +154,14 @@ class Comm(object):
     """`brie_comm`: an RCCL communicator created through the C ABI (one per process / GPU).
 
     `unique_id()` on rank 0 -> hand the 128 bytes to every rank (any transport) -> `Comm(device, rank, world, id)`."""
+
+    @staticmethod
+    def available(device=0):
+        """None when librccl binds and `device` exists (brie_comm_available), else the reason as a string."""
+        lib = load_library()
+        if lib.brie_comm_available(int(device)) == 0:
+            return None
+        return (lib.brie_last_error() or b"brie_comm_available failed").decode()
 
     @staticmethod
     def unique_id():

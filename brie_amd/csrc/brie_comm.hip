@@ -115,6 +115,14 @@ int comm_device(const brie_comm *c) { return c->device; }
 
 extern "C" {
 
+int brie_comm_available(int32_t device) {
+    if (!rccl().ok) return failf(BRIE_ERR_COMM, "%s", rccl().why);
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return failf(BRIE_ERR_INVALID, "device %d of %d", device, n);
+    return BRIE_OK;
+}
+
 int brie_comm_unique_id(uint8_t *id_out) {
     if (!id_out) return failf(BRIE_ERR_INVALID, "null argument");
     if (!rccl().ok) return failf(BRIE_ERR_COMM, "%s", rccl().why);

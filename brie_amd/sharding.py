@@ -42,7 +42,10 @@ class GeneComm(object):
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
         self.device = device
-        self._native, self._native_tried = None, False
+        self._native, self._native_tried, self.native_error = None, False, None
+
+    def _on_rccl(self):
+        return self.backend == "nccl"
 
     def native_comm(self, device=None):
         """The library's own RCCL communicator (`brie_comm_*` of include/brie_amd.h) over the same ranks, or None.
@@ -54,22 +57,33 @@ class GeneComm(object):
         if self._native is not None or self._native_tried:
             return self._native
         self._native_tried = True
-        if self.backend != "nccl":
+        if not self._on_rccl():
             return None
         from . import _capi
-        # Every rank takes the same steps whatever happens on it: the id travels, each rank tries to build its
-        # communicator, and the ranks then AGREE (an all-reduce over torch.distributed) that all of them succeeded --
-        # one rank falling back to the torch path alone would leave the others waiting in a collective for ever.
-        ok, self.native_error = 1.0, None
+        # Every rank takes the same steps whatever happens on it.  (1) Each rank checks what it can check ALONE -- librccl
+        # binds, its device exists (brie_comm_available) -- and the ranks agree on that BEFORE a unique id exists: a rank
+        # that cannot load RCCL must not leave the others inside ncclCommInitRank.  (2) The id travels, each
+        # rank builds its communicator, and the ranks AGREE again (an all-reduce over torch.distributed) that all of them
+        # succeeded -- one rank falling back to the torch path alone would leave the others waiting in a collective for
+        # ever.  What stays collective: a failure INSIDE ncclCommInitRank on one rank while the others are in it.
+        dev = device if device is not None else (self.device.index if hasattr(self.device, "index") else self.device)
+        dev = int(dev or 0)
+        try:
+            self.native_error = _capi.Comm.available(dev)
+        except Exception as exc:
+            self.native_error = repr(exc)
+        if float(self.allreduce_min([0.0 if self.native_error else 1.0])[0]) < 1.0:
+            self.native_error = self.native_error or "another rank cannot load RCCL / has no such device"
+            return None
+        ok = 1.0
         try:
             box = [_capi.Comm.unique_id() if self.rank == 0 else None]
-        except Exception as exc:             # librccl not loadable on rank 0: the others still need the broadcast
+        except Exception as exc:             # rank 0 could not make an id: the others still need the broadcast
             box, ok, self.native_error = [None], 0.0, repr(exc)
         self.dist.broadcast_object_list(box, src=0, group=self.group)
         if ok and box[0] is not None:
             try:
-                dev = device if device is not None else (self.device.index if hasattr(self.device, "index") else self.device)
-                self._native = _capi.Comm(int(dev or 0), self.rank, self.world, box[0])
+                self._native = _capi.Comm(dev, self.rank, self.world, box[0])
             except Exception as exc:
                 ok, self.native_error = 0.0, repr(exc)
         else:

@@ -211,6 +211,10 @@ int brie_step_end(brie_handle *h, float *loss);
 enum { BRIE_F32 = 0, BRIE_F64 = 1 };
 enum { BRIE_SUM = 0, BRIE_MAX = 1, BRIE_MIN = 2 };
 typedef struct brie_comm brie_comm;
+/* brie_comm_available: BRIE_OK when librccl binds with every symbol this library calls and `device` exists -- the check
+ * every rank makes (and the ranks agree on) BEFORE rank 0 publishes a unique id: a rank that cannot even load RCCL must
+ * not leave the others waiting inside ncclCommInitRank.  A failure of ncclCommInitRank itself remains collective. */
+int brie_comm_available(int32_t device);
 int brie_comm_unique_id(uint8_t *id_out /* BRIE_COMM_ID_BYTES */);
 int brie_comm_init(int32_t device, int32_t rank, int32_t world, const uint8_t *unique_id, brie_comm **out);
 int brie_comm_destroy(brie_comm *c);

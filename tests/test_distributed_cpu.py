@@ -138,3 +138,33 @@ def test_sharded_engine_loop_equals_single_process(tmp_path, case):
     np.testing.assert_array_equal(np.concatenate([r[0]["Psi"], r[1]["Psi"]], axis=1), ref.Psi)
     if case == "straddle":
         assert 20 < int(r[0]["n_losses"]) == len(ref.losses) < 100          # extended, and stopped before max_iter
+
+
+# ---- the library's own communicator is only attempted when EVERY rank can load RCCL ---------------------
+def _agreement_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from brie_amd import _capi
+    from brie_amd.sharding import GeneComm
+    calls = []
+    _capi.Comm.available = staticmethod(lambda device=0: "librccl.so.1 not found (test)" if rank == 1 else None)
+    _capi.Comm.unique_id = staticmethod(lambda: calls.append("unique_id") or b"\0" * _capi.COMM_ID_BYTES)
+    comm = GeneComm()
+    comm._on_rccl = lambda: True                    # gloo ranks standing in for an RCCL group: only the agreement is under test
+    nat = comm.native_comm(device=0)
+    x = np.arange(8, dtype=np.float32).reshape(2, 4) + 10 * rank
+    g = comm.allgather_genes(x, 8, ranges=[(0, 4), (4, 8)], native=None)      # still works, over torch.distributed
+    np.savez(os.path.join(out_dir, "agree%d.npz" % rank), native_none=nat is None, error=str(comm.native_error),
+             calls=len(calls), gathered=g, path=comm.last_gather_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_no_rank_enters_the_rccl_rendezvous_when_one_rank_cannot_load_it(tmp_path):
+    mp.spawn(_agreement_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)       # a hang here = the bug
+    r = [np.load(tmp_path / ("agree%d.npz" % k)) for k in range(2)]
+    assert all(bool(q["native_none"]) for q in r) and all(int(q["calls"]) == 0 for q in r)   # no id was ever made
+    assert "not found" in str(r[1]["error"]) and "another rank" in str(r[0]["error"])
+    np.testing.assert_array_equal(r[0]["gathered"], r[1]["gathered"])
+    assert str(r[0]["path"]) == "torch.distributed"

@@ -31,11 +31,10 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in SOURCES + HEADERS)
 
 
-def compile_library(force=False, fast_math=None, verbose=False, out=None, defines=(), jobs=None):
+def compile_library(force=False, verbose=False, out=None, jobs=None):
     """hipcc --offload-arch=gfx950 -> brie_amd/lib/libbrie_amd.so (cross-compiles without a GPU).
 
-    `out` / `defines` build tuning variants (e.g. -DBRIE_MIN_WAVES=4) next to the default library;
-    select one at run time with the BRIE_AMD_LIB environment variable."""
+    `out`: write the library somewhere else (a clean rebuild to compare with the shipped one)."""
     if out is None and not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -47,11 +46,6 @@ def compile_library(force=False, fast_math=None, verbose=False, out=None, define
     os.makedirs(obj_dir, exist_ok=True)
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    if fast_math is None:
-        fast_math = os.environ.get("BRIE_FAST_MATH")
-    if fast_math is not None:
-        base.append("-DBRIE_FAST_MATH=%d" % int(fast_math))
-    base += ["-D" + d for d in defines]
     units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), []),
              (os.path.join(CSRC, "brie_comm.hip"), os.path.join(obj_dir, "brie_comm.o"), [])]   # RCCL, bound by dlopen
     for mode in range(3):             # MFMA tile kernel of the wide designs: one unit per likelihood mode

@@ -31,16 +31,10 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kGenesPerBlock = kWave * kVec;   // 256 genes per gene block
 constexpr uint32_t kInitDraw = 0xFFFFFFFFu;
 
-// 1 (default): hardware transcendentals (v_exp/v_log/v_sin/v_cos/v_rcp/v_sqrt, ~1 ulp) for the noise
-// stream and the likelihood; 0: ocml correctly-rounded-ish functions.  Both pass the same parity
-// tests (tests/test_gpu_parity.py); the hardware forms keep MC_size=3 HBM-bound (9.2 vs 16.1 ms/step).
-#ifndef BRIE_FAST_MATH
-#define BRIE_FAST_MATH 1
-#endif
-// minimum waves per SIMD requested from the register allocator for the streaming kernels
-#ifndef BRIE_MIN_WAVES
-#define BRIE_MIN_WAVES 1
-#endif
+// Transcendentals are the hardware forms (v_exp / v_log / v_sin / v_cos / v_rcp / v_sqrt, ~1 ulp) for the noise stream, the
+// likelihood and the Adam update: they keep MC_size 3 HBM-bound (9.2 against 16.1 ms per step with the ocml functions).  The
+// strict builds that rounds 2 - 4 kept beside this one (ocml functions, IEEE division in Adam, temporal loads) changed no
+// parity statistic (docs/evidence.md section 2) and are gone; the parity tests hold this build against the fp32 oracle.
 
 // ----------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. SC'11) -> 4 standard normals per gene quad.
@@ -78,17 +72,9 @@ __device__ __forceinline__ float u01_fma(uint32_t x) {
 template <bool LEAN = false>
 __device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float &n0, float &n1) {
     const float ua = LEAN ? u01_fma(xa) : u01(xa), ub = LEAN ? u01_fma(xb) : u01(xb);
-#if BRIE_FAST_MATH
     const float r = __builtin_amdgcn_sqrtf(-2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(ua));
     n0 = r * __builtin_amdgcn_cosf(ub);      // v_cos_f32 takes revolutions: cos(2 pi ub)
     n1 = r * __builtin_amdgcn_sinf(ub);
-#else
-    const float r = sqrtf(-2.0f * logf(ua));
-    float sn, cs;
-    sincospif(2.0f * ub, &sn, &cs);          // angle 2 pi ub without rounding the product
-    n0 = r * cs;
-    n1 = r * sn;
-#endif
 }
 
 // eps for genes 4q..4q+3 of cell `cell` at (draw, k)
@@ -105,18 +91,10 @@ __device__ __forceinline__ void normal4(uint32_t quad, uint32_t cell, uint32_t d
 // scalar math helpers
 // ----------------------------------------------------------------------------
 __device__ __forceinline__ float f_exp(float x) {
-#if BRIE_FAST_MATH
     return __expf(x);
-#else
-    return expf(x);
-#endif
 }
 __device__ __forceinline__ float f_log(float x) {
-#if BRIE_FAST_MATH
     return __logf(x);
-#else
-    return logf(x);
-#endif
 }
 // f_log for the VALU-bound forward passes (loss_gene_eval, margin_step).  Every logarithm on this path takes a normal
 // number >= ~1 (1 + exp(-|z|), a sum of effective lengths, a sum of exp(l - max) >= 1), so the fast build spells out what
@@ -127,7 +105,6 @@ __device__ __forceinline__ float f_log(float x) {
 // instructions are free and the longer dependent chain costs registers (MC_size 3 fell from 2 waves / SIMD to 1).
 template <bool LEAN>
 __device__ __forceinline__ float f_log_sel(float x) {
-#if BRIE_FAST_MATH
     if constexpr (LEAN) {
 #pragma clang fp contract(off)                                        // y * c and the final sum stay two roundings
         const float y = __builtin_amdgcn_logf(x);
@@ -135,12 +112,10 @@ __device__ __forceinline__ float f_log_sel(float x) {
         const float r = y * c;
         return r + __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
     }
-#endif
     return f_log(x);
 }
 template <bool LEAN = false>
 __device__ __forceinline__ float f_log1p(float x) {
-#if BRIE_FAST_MATH
     // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2.
     // LEAN (the forward-only passes): log(1 + x) throughout.  Rounding 1 + x costs at most 6e-8 ABSOLUTE in a term that
     // enters the loss as c * (min(+-z, 0) - log1p) with |z| > 6.9 there -- nothing next to the fp32 sums it is added to --
@@ -149,37 +124,16 @@ __device__ __forceinline__ float f_log1p(float x) {
     // per draw and no packed math at all).
     if constexpr (LEAN) return f_log_sel<true>(1.0f + x);
     return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<LEAN>(1.0f + x);
-#else
-    return log1pf(x);
-#endif
 }
-// BRIE_FAST_MATH=0 is strict throughout: IEEE division and square root (hipcc rounds both correctly by
-// default), ocml exp / log / log1p / sincospi.  The Adam update can be made strict on its own
-// (BRIE_STRICT_ADAM=1 with fast transcendentals): two divisions + two square roots per element.
-#ifndef BRIE_STRICT_ADAM
-#define BRIE_STRICT_ADAM (!BRIE_FAST_MATH)
-#endif
 __device__ __forceinline__ float f_rcp(float x) {
-#if BRIE_FAST_MATH
     return __builtin_amdgcn_rcpf(x);
-#else
-    return 1.0f / x;
-#endif
 }
 __device__ __forceinline__ float f_sqrt(float x) {
-#if BRIE_FAST_MATH
     return __builtin_amdgcn_sqrtf(x);
-#else
-    return sqrtf(x);
-#endif
 }
 // x - (m * alpha) / (sqrt(v) + eps): the Keras Adam update
 __device__ __forceinline__ float adam_update(float x, float m, float v, float alpha) {
-#if BRIE_STRICT_ADAM
-    return x - (m * alpha) / (sqrtf(v) + 1e-7f);
-#else
     return x - (m * alpha) * __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(v) + 1e-7f);
-#endif
 }
 
 struct alignas(16) F4 { float v[4]; };
@@ -192,26 +146,15 @@ __device__ __forceinline__ void st4(float *p, const F4 &a) {
     *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
 }
 
-// streaming (touched once per step) accesses; BRIE_NT=1 marks them non-temporal
-#ifndef BRIE_NT
-#define BRIE_NT 1
-#endif
+// streaming (touched once per step) accesses are non-temporal (+2.5 %, docs/evidence.md section 4.1)
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ F4 ld4s(const float *p) {
-#if BRIE_NT
     const floatx4 t = __builtin_nontemporal_load(reinterpret_cast<const floatx4 *>(p));
     return F4{{t.x, t.y, t.z, t.w}};
-#else
-    return ld4(p);
-#endif
 }
 __device__ __forceinline__ void st4s(float *p, const F4 &a) {
-#if BRIE_NT
     floatx4 t = {a.v[0], a.v[1], a.v[2], a.v[3]};
     __builtin_nontemporal_store(t, reinterpret_cast<floatx4 *>(p));
-#else
-    st4(p, a);
-#endif
 }
 
 // Likelihood modes
@@ -228,11 +171,7 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
     const float az = fabsf(z);
     const float e = f_exp(-az);                   // exp(-|z|) in (0,1]
     const float inv = f_rcp(1.0f + e);
-#if BRIE_FAST_MATH
     const float big = inv, small = e * inv;       // sigmoid(|z|), sigmoid(-|z|)
-#else
-    const float big = inv, small = e / (1.0f + e);
-#endif
     const float sp = z >= 0.0f ? big : small;     // sigmoid(z)
     const float sn = z >= 0.0f ? small : big;     // sigmoid(-z)
     const float l1p = f_log1p<LEAN>(e);
@@ -261,7 +200,6 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
 // for the pair (gfx950 issues packed fp32 at the scalar rate); the transcendentals stay per element.
 typedef float floatx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx2 loglik2_pair(floatx2 z, floatx2 c1, floatx2 c2) {
-#if BRIE_FAST_MATH
     constexpr float kLog2e = 0x1.715476p+0f;                         // what __expf multiplies by
     const floatx2 t = z * kLog2e;
     floatx2 e;
@@ -283,13 +221,6 @@ __device__ __forceinline__ floatx2 loglik2_pair(floatx2 z, floatx2 c1, floatx2 c
     m2.x = fminf(-z.x, 0.0f); m2.y = fminf(-z.y, 0.0f);
     const floatx2 ls1 = m1 - l1p, ls2 = m2 - l1p;                    // log_sigmoid(z), log_sigmoid(-z)
     return c1 * ls1 + c2 * ls2;
-#else
-    floatx2 out;
-    float g;
-    loglik<kLik2, true>(z.x, c1.x, c2.x, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, out.x, g);
-    loglik<kLik2, true>(z.y, c1.y, c2.y, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, out.y, g);
-    return out;
-#endif
 }
 
 // ----------------------------------------------------------------------------
@@ -596,7 +527,7 @@ __device__ __forceinline__ double block_sum_f64(double *sh, double t) {
 // place of the residual r in every prior-parameter statistic (and -q_eps sigma that of the sigma statistic), there is
 // no KL term and the posterior arrays are neither read nor written.  (Uncoupled Kc <= 8 models use margin_step.)
 template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
-__global__ __launch_bounds__(kBlock, BRIE_MIN_WAVES) void elbo_adam_step(
+__global__ __launch_bounds__(kBlock, 1) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,

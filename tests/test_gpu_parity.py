@@ -162,14 +162,18 @@ def test_psi_after_full_default_schedule(lib, Kc):
     seed = 11
     o32 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32)
     o32b = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float32, variant_b=True)
+    o64 = COracle(P["counts_pc"], P["Xc"], seed=seed, dtype=np.float64)
     sh = util.device_shard(P, Nc, Ng, Kc, seed)
     for n, lr in util.staged_schedule(1000):
-        for o in (o32, o32b):
+        for o in (o32, o32b, o64):
             o.reset_optimizer()
             o.minimize(n, lr, 1)
         sh.reset_optimizer()
         sh.step(n, lr, 1, trace=False)
     print("996 steps, Kc=%d:" % Kc, util.psi_null_of(sh, o32, o32b, what="Psi after 996 steps"))
+    # ... and so that the fp32-vs-fp32 yardstick cannot drift: the same fit held against the
+    # precision-independent answer -- the fp64 build of the restatement -- by round 3's rule (tests/util.py::psi_parity_rule)
+    print("against the fp64 oracle:", util.psi_parity_of(sh, o32, o64, what="Psi after 996 steps vs fp64"))
     sh.close()
 
 

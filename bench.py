@@ -552,28 +552,32 @@ def main(argv=None):
         torch.cuda.synchronize()
 
     precondition = {"probe_launches": 0, "seconds": 0.0}
+    plain_steps = 0                              # Adam steps of the "plain" leg below (the oracle re-run of a gene quad counts them)
     if t_w < 0.25 and not args.pmc_child and not args.no_precondition:
         # ... but first the PLAIN figure, measured the way rounds 1 - 3 measured theirs (W warm-up steps, then K timed steps,
         # nothing in between), so that round-over-round comparisons stay like for like; --no-precondition makes
         # that the headline again
-        sh.profile_enable(True)
-        torch.cuda.synchronize()                 # no barrier: whether this leg runs is decided per rank (its own t_w)
-        t_pl = time.perf_counter()
-        sh.step(args.steps, lr, args.mc, trace=False)
-        sh.synchronize()
-        t_pl = time.perf_counter() - t_pl
-        k_pl, n_pl = sh.profile_read()
+        plain = None
+        if world == 1:                           # N = 1 only: with N > 1 rank 0 re-fits other ranks' genes step for step (allgather
+            sh.profile_enable(True)              # check) and must know how many steps every rank took
+            torch.cuda.synchronize()
+            t_pl = time.perf_counter()
+            sh.step(args.steps, lr, args.mc, trace=False)
+            sh.synchronize()
+            t_pl = time.perf_counter() - t_pl
+            k_pl, n_pl = sh.profile_read()
+            plain_steps = args.steps
+            plain = {"ms_per_step": round(t_pl / args.steps * 1e3, 5), "avg_kernel_ms": round(k_pl / max(n_pl, 1), 5),
+                     "frac": round(sh.step_algorithmic_bytes() / (k_pl / max(n_pl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "what": "the same K steps timed directly after the W warm-up steps, before any preconditioning: "
+                             "the figure of rounds 1 - 3"}
         n_probe = int(min(4000, max(8, 0.2 * 6e12 / max(sh.step_storage_bytes(), 1))))
         t_p = time.perf_counter()
         sh.placement_probe(n_probe)
         sh.synchronize()
         precondition = {"probe_launches": n_probe, "seconds": round(time.perf_counter() - t_p, 4),
                         "what": "effect-free placement probe launches between the warm-up steps and the timed region (clocks)",
-                        "plain_without_preconditioning": {
-                            "ms_per_step": round(t_pl / args.steps * 1e3, 5), "avg_kernel_ms": round(k_pl / max(n_pl, 1), 5),
-                            "frac": round(sh.step_algorithmic_bytes() / (k_pl / max(n_pl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                            "what": "the same K steps timed directly after the W warm-up steps, before any preconditioning: "
-                                    "the figure of rounds 1 - 3 (local to this rank)"}}
+                        "plain_without_preconditioning": plain}
         note("clock preconditioning: %r" % (precondition,))
     sh.profile_enable(True)
 
@@ -745,7 +749,8 @@ def main(argv=None):
         # PSI delta ON THE TIMED WORKLOAD: genes are independent and the noise stream is keyed by the global gene
         # index, so the CPU oracle run on one gene quad over all Nc cells is an exact reference for those genes
         from oracle.brie_oracle import OracleBRIE2, add_pseudo_count
-        n_total = args.warmup + 2 * args.steps + 1             # warm-up, the timed pass, the unprofiled pass, the traced step
+        # warm-up, (the plain leg,) the timed pass, the unprofiled pass, the traced step
+        n_total = args.warmup + plain_steps + 2 * args.steps + 1
         o = OracleBRIE2(Nc, 4, Kc, effLen=quad_eff, seed=seed, gene_offset=g0 + q0, dtype=np.float64)
         o.minimize(add_pseudo_count(quad_layers), Xc_host, n_total, lr, args.mc)
         d = np.abs(psi_quad - o.Psi)

@@ -58,10 +58,13 @@ class OracleBRIE2(object):
         # every reduction over cells / genes taken over the REVERSED axis (other association of the fp32 sums).  The
         # null the HIP path's differences to the fp32 oracle are held against for the model variants the C restatement
         # does not cover (tests/test_gpu_parity.py::test_psi_after_full_default_schedule_model_variants).
-        # variant_b = True / 1: both differences; 2: the float32 Box-Muller only; 3: the reversed reductions only (three
-        # members of the family "another fp32 evaluation", for a spread instead of a single draw)
+        # variant_b = True / 1: both differences; 2: the float32 Box-Muller only; 3: the reversed reductions only; 4: float32
+        # Box-Muller + every reduction formed as four contiguous partial sums added in order; 5: the exact noise stream +
+        # three partial sums of the reversed axis (five members of the family "another fp32 evaluation": the null ENSEMBLE
+        # of the model variants, tests/util.py::entry_ensemble_rule)
         self.variant_b = int(variant_b)
-        self._b_noise, self._b_sums = self.variant_b in (1, 2), self.variant_b in (1, 3)
+        self._b_noise = self.variant_b in (1, 2, 4)
+        self._b_sums = {1: "reverse", 3: "reverse", 4: "blocks4", 5: "blocks3_reverse"}.get(self.variant_b)
         self.cell_mode = str(intercept_mode).upper() == 'CELL'          # ref:53-60
         self.par_shape = (self.Nc, 1) if self.cell_mode else (1, self.Ng)
         self.Xg = None
@@ -158,15 +161,28 @@ class OracleBRIE2(object):
 
     # ------------------------------------------------------------- reductions
     def _sum(self, x, axis):
-        """x.sum(axis, keepdims=True); variant_b sums the reversed axis."""
-        if self._b_sums:
+        """x.sum(axis, keepdims=True); variant_b sums the reversed axis and / or in contiguous blocks added in order."""
+        if self._b_sums in ("reverse", "blocks3_reverse"):
             x = np.ascontiguousarray(np.flip(x, axis=axis))
+        if self._b_sums in ("blocks4", "blocks3_reverse"):
+            parts = np.array_split(x, 4 if self._b_sums == "blocks4" else 3, axis=axis)
+            out = parts[0].sum(axis=axis, keepdims=True)
+            for q in parts[1:]:
+                out = out + q.sum(axis=axis, keepdims=True)
+            return out
         return x.sum(axis=axis, keepdims=True)
 
     def _mm(self, a, b):
-        """a @ b; variant_b contracts in reversed order."""
-        if self._b_sums:
-            return np.matmul(np.ascontiguousarray(a[:, ::-1]), np.ascontiguousarray(b[::-1]))
+        """a @ b; variant_b contracts in reversed order and / or in blocks of the contracted axis added in order."""
+        if self._b_sums in ("reverse", "blocks3_reverse"):
+            a, b = np.ascontiguousarray(a[:, ::-1]), np.ascontiguousarray(b[::-1])
+        if self._b_sums in ("blocks4", "blocks3_reverse") and a.shape[1] > 1:
+            n = min(a.shape[1], 4 if self._b_sums == "blocks4" else 3)
+            cuts = np.array_split(np.arange(a.shape[1]), n)
+            out = np.matmul(a[:, cuts[0]], b[cuts[0]])
+            for c in cuts[1:]:
+                out = out + np.matmul(a[:, c], b[c])
+            return out
         return np.matmul(a, b)
 
     # ------------------------------------------------------------- loss

@@ -28,12 +28,14 @@ VARIANTS = {
     "marginLik_mc3": ("gene", 0, 2, 2, 3, "marginLik"),
 }
 Nc, Ng = 200, 520
+NULL_MEMBERS = (1, 2, 3, 4, 5)         # OracleBRIE2(variant_b=...)
 
 
 def run_variant(name, min_iter=1000, seed=41, data_seed=37, null=False):
     """null=False (round 3): HIP and the fp32 NumPy oracle, each against the fp64 one.  null=True (round 4): HIP against
-    the fp32 oracle, next to three further fp32 NumPy evaluations of the same algorithm (OracleBRIE2 variant_b = 1, 2, 3:
-    float Box-Muller and / or reversed reductions) against that same oracle -- the direct fp32-vs-fp32 null."""
+    the fp32 oracle, next to FIVE further fp32 NumPy evaluations of the same algorithm (OracleBRIE2 variant_b = 1 .. 5:
+    float Box-Muller and / or reversed / blocked reductions) against that same oracle -- the null ensemble of the model
+    variants (tests/util.py::entry_ensemble_rule)."""
     from brie_amd import _capi
     from tests import util
     mode, Kg, Kc, L, MC, target = VARIANTS[name]
@@ -44,7 +46,7 @@ def run_variant(name, min_iter=1000, seed=41, data_seed=37, null=False):
         np.random.default_rng(5).standard_normal((Ng, Kg)).astype(np.float32)
     runs = {"o32": util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode)}
     if null:
-        for v in (1, 2, 3):
+        for v in NULL_MEMBERS:
             runs["o32b%d" % v] = util.oracle_model(P, Nc, Ng, Kc, seed, np.float32, Kg=Kg, mode=mode, variant_b=v)
     else:
         runs["o64"] = util.oracle_model(P, Nc, Ng, Kc, seed, np.float64, Kg=Kg, mode=mode)
@@ -72,7 +74,7 @@ def run_variant(name, min_iter=1000, seed=41, data_seed=37, null=False):
     out = {"variant": name, "mode": mode, "Kg": Kg, "Kc": Kc, "count_layers": L, "MC_size": MC, "target": target,
            "model_seed": seed, "data_seed": data_seed, "shape": [Nc, Ng], "steps": 6 * int(min_iter / 6), "seconds": time.time() - t0,
            "compared": "sigmoid(prior mean)" if target == "marginLik" else "Psi"}
-    pairs = [("hip_vs_o32", "hip", "o32")] + [("o32b%d_vs_o32" % v, "o32b%d" % v, "o32") for v in (1, 2, 3)] if null else \
+    pairs = [("hip_vs_o32", "hip", "o32")] + [("o32b%d_vs_o32" % v, "o32b%d" % v, "o32") for v in NULL_MEMBERS] if null else \
         [("hip_vs_o64", "hip", "o64"), ("o32_vs_o64", "o32", "o64")]
     for key, a, b in pairs:
         d = np.abs(psi[a] - psi[b])

@@ -447,3 +447,49 @@ def test_psi_null_rule_on_gene_samples_of_the_full_size_configs_after_the_full_d
     sh.close()
     rep = util.psi_null_rule(h, null, "%s, %d genes x %d cells, 996 steps" % (case, n_use, Nc))
     print("%s: %d genes (%s):" % (case, n_use, "full oracle cache" if n_use == c["Ng"] else "committed fixture"), rep)
+
+
+@pytest.mark.parametrize("case", ["c2_cli_128", "c3_cli_128", "c2_cli_64_s5", "c3_cli_64_s5"])
+def test_psi_ensemble_rule_after_the_brie_quant_default_schedule(lib, case):
+    """The brie-quant default schedule (bin/quant.py:173-177: 4 998 Adam steps = 6 x 833 with a fresh optimiser per stage,
+    MC_size 3) under the driver's eyes (VERDICT r4 items 1 and 3 of "missing"): the first 64 genes of the configs[1] /
+    configs[2] samples over ALL cells (10 000 / 50 000), HIP against the fp32 C restatement (o32), held against the
+    PRE-REGISTERED null ensemble by tests/util.py::psi_ensemble_rule -- six further fp32 CPU evaluations of the same
+    algorithm (o32b with the cells cut into 2 / 4 / 6 / 8 / 12 parts, one member with the exact noise stream).  Members,
+    cases, seeds and constants were committed (tests/golden/psi_ensemble_manifest.json, "registered") before the members were
+    computed; the *_s5 cases are held out: chosen before either side had run on them.  c2_cli_128 and c3_cli_128 are the two
+    cases that failed round 4's single-draw rule on the final library.  The verdict stands as it falls: the report carries
+    the ensemble's own leave-one-out record (how often a member, which IS the reference's arithmetic, fails the same rule).
+    What the test reads is in git: tests/golden/psi_ens_<case>_first64.npz (o32 Psi + parameters, every member's per-gene
+    summaries; sha256 in the manifest's "frozen" section).  Without it the test FAILS with the command that makes it."""
+    import json
+    import os
+    import sys
+    from brie_amd import _capi
+    from tests import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "profiles"))
+    import psi_delta as pd
+    import psi_ensemble as pe
+    fixture = os.path.join(root, "tests", "golden", "psi_ens_%s_first%d.npz" % (case, pe.GENES))
+    if not os.path.exists(fixture):
+        pytest.fail("%s is missing: python profiles/psi_ensemble.py --run --freeze --cases %s   (CPU, hours)"
+                    % (os.path.relpath(fixture, root), case))
+    man = json.load(open(pe.MANIFEST))
+    assert man["frozen"][case]["fixture_sha256"] == pe.sha256(fixture), "fixture differs from the frozen manifest"
+    psi_o32, par_o32, members = pe.load_fixture(case)
+    assert sorted(members) == sorted(pe.MEMBERS)
+    P, c, n = pe.problem(case)
+    sh = util.device_shard(P, c["Nc"], n, c["Kc"], pd.model_seed(pe.CASES[case]["of"]))
+    for k, lr in util.staged_schedule(c["min_iter"]):
+        sh.reset_optimizer()
+        sh.step(k, lr, c["MC"], trace=False)
+    h = util.gene_summaries(sh.read(_capi.PSI), psi_o32, util.run_params(sh), par_o32)
+    sh.close()
+    rep = util.psi_ensemble_rule(h, members, "%s, %d genes x %d cells, 4998 steps, MC_size 3" % (case, n, c["Nc"]), check=False)
+    print("%s:" % case, json.dumps(rep))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):                                   # the verdict as it fell, for profiles/r5/
+        with open(os.path.join(out, "psi_ensemble_%s.json" % case), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    assert rep["holds"], (case, rep.get("violated"), rep["leave_one_out"])

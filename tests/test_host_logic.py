@@ -475,6 +475,66 @@ def test_psi_null_rule_holds_hip_against_a_second_fp32_evaluation():
     assert np.array_equal(sub["n_gt"], full["n_gt"][:64]) and sub["Nc"] == Nc
 
 
+def test_psi_ensemble_rule_holds_a_run_against_the_largest_member_and_reports_its_own_false_alarms():
+    """The rule since round 5 for the brie-quant default schedule (tests/util.py::psi_ensemble_rule): the statistics of ONE
+    comparison are self-contained (comparison_stats), the judged run is held against the LARGEST member value of each with
+    the registered constants, and the ensemble's own leave-one-out record is part of the report."""
+    import json
+    from tests import util
+    rng = np.random.default_rng(6)
+    Nc, Ng, Kc = 4000, 64, 2
+    psi32 = rng.uniform(0.05, 0.95, size=(Nc, Ng)).astype(np.float32)
+    base = {"Wc_loc": rng.normal(size=(Kc, Ng)), "intercept": rng.normal(size=Ng), "sigma_log": rng.normal(size=Ng) * 0.1}
+
+    def run(noise=2e-6, displaced=(), clustered=(), scattered=0, shift=2e-3, seed=0):
+        r = np.random.default_rng(seed)
+        psi = psi32.astype(np.float64) + r.normal(size=psi32.shape) * noise
+        par = {k: v.copy() for k, v in base.items()}
+        for j in displaced:
+            par["intercept"][j] += shift
+            psi[:, j] += 0.25 * shift
+        for j in clustered:
+            psi[r.choice(Nc, Nc // 50, replace=False), j] += 3e-4
+        rows = r.choice(Nc, scattered, replace=False)
+        for i in range(scattered):                                     # round-robin over genes 24..63: below the cluster size
+            psi[rows[i], 24 + i % 40] += 2e-4
+        return util.gene_summaries(psi, psi32, par, base)
+
+    members = {"t2": run(displaced=(1, 2), scattered=30, seed=2), "t4": run(displaced=(3,), clustered=(5,), scattered=60, seed=3),
+               "t6": run(displaced=(1, 4, 6), scattered=45, seed=4), "x3": run(scattered=20, seed=5)}
+    st = util.comparison_stats(members["t4"])
+    assert st["displaced_genes"] == 1 and st["clustered_genes"] == 1 and st["moved_genes"] == 2
+    assert st["quiet_entries"] == (Ng - 2) * Nc and st["quiet_gt_1e-4"] == 60 and st["shift_max"] == pytest.approx(2e-3)
+    rep = util.psi_ensemble_rule(run(displaced=(7, 8, 9), scattered=70, seed=1), members, "synthetic")
+    assert rep["holds"] and rep["hip_vs_o32"]["moved_genes"] == 3 and rep["hip_vs_o32"]["quiet_gt_1e-4"] == 70, rep
+    assert rep["leave_one_out"]["of"] == 4 and rep["leave_one_out"]["members_failing"] == []
+    # largest member: 3 moved genes -> 1.25 x 3 + 2 = 5.75; 60 entries of 62 x 4000 -> 1.25 x 60 + 20 = 95
+    for bad, what in ((dict(displaced=tuple(range(10, 16))), "moved_genes"), (dict(scattered=110), "quiet_rate"),
+                      (dict(noise=1.2e-5), "quiet_p99"), (dict(displaced=(3,), shift=0.2), "shift_max")):
+        r = util.psi_ensemble_rule(run(seed=1, **bad), members, "synthetic", check=False)
+        assert not r["holds"] and r["violated"][0][0] == what, (bad, r.get("violated"))
+    with pytest.raises(AssertionError):
+        util.psi_ensemble_rule(run(seed=1, scattered=110), members, "synthetic")
+    # a member that is an outlier of its own ensemble shows up in the leave-one-out record (the rule's false-alarm rate)
+    odd = dict(members, t12=run(scattered=160, seed=9))
+    r = util.psi_ensemble_rule(run(seed=1), odd, "synthetic")
+    assert r["leave_one_out"]["members_failing"] == ["t12"] and r["leave_one_out"]["of"] == 5
+    # the registered manifest carries exactly these constants, members and the held-out cases
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    man = json.load(open(os.path.join(root, "tests", "golden", "psi_ensemble_manifest.json")))
+    reg = man["registered"]
+    assert reg["constants"]["factor"] == util.ENSEMBLE_FACTOR and reg["constants"]["max_factor"] == util.ENSEMBLE_MAX_FACTOR
+    assert reg["constants"]["max_floor"] == util.ENSEMBLE_MAX_FLOOR and reg["constants"]["shift_cap"] == util.ENSEMBLE_SHIFT_CAP
+    assert sorted(reg["members"]) == ["t12", "t2", "t4", "t6", "t8", "x3"] and reg["genes"] == 64
+    assert sorted(k for k, v in reg["cases"].items() if v["held_out"]) == ["c2_cli_64_s5", "c3_cli_64_s5"]
+    # entry-level form for the coupled model variants: same constants
+    m = {"a": {"n_gt_1e-4": 100, "p99": 2e-5, "max": 1e-3}, "b": {"n_gt_1e-4": 160, "p99": 3e-5, "max": 4e-3}}
+    ok = util.entry_ensemble_rule({"n_gt_1e-4": 200, "p99": 4e-5, "max": 5e-3}, m, 104000)
+    assert ok["holds"] and ok["leave_one_out"]["members_failing"] == ["b"]
+    bad = util.entry_ensemble_rule({"n_gt_1e-4": 230, "p99": 4e-5, "max": 7e-3}, m, 104000, check=False)
+    assert [v[0] for v in bad["violated"]] == ["rate", "max"]
+
+
 def test_psi_parity_rule_counts_moved_genes_as_genes_and_scattered_entries_as_entries():
     """The parity rule itself (tests/util.py::psi_parity_rule, revision 2) on synthetic runs: what it lets pass and what
     it refuses -- so that the rule the GPU tests and bench.py lean on is pinned on the CPU too."""

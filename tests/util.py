@@ -375,3 +375,35 @@ def psi_ensemble_rule(h, members, what="", check=True):
     if check:
         assert not viol, (what, viol, rep)
     return rep
+
+
+def entry_ensemble_rule(h, members, n, what="", check=True):
+    """The ensemble rule for the COUPLED model variants (gene features with per-cell weights, per-cell intercept, ...): one sign
+    event in a parameter shared by a row reaches every gene of that cell, so the gene-level partition of psi_ensemble_rule has
+    no meaning and its ENTRY-level statistics are applied to the whole matrix, with the same constants: over the `n` entries,
+    `h` and every member a dict with 'n_gt_1e-4', 'p99', 'max' of |dPsi| against the fp32 oracle;
+      entries beyond 1e-4, per entry  <= 1.25 E + max(1e-5, 20 / n);   p99 <= 1.25 E + 5e-6;   max <= max(2e-3, 1.5 E)
+    with E the largest value over the members, and the members' own leave-one-out record beside it."""
+    def viol_of(x, ms):
+        v = []
+        top = max(m["n_gt_1e-4"] for m in ms) / float(n)
+        if not x["n_gt_1e-4"] / float(n) <= ENSEMBLE_FACTOR * top + ENSEMBLE_FLOORS["quiet_rate"](0, n):
+            v.append(("rate", x["n_gt_1e-4"] / float(n), top))
+        top = max(m["p99"] for m in ms)
+        if not x["p99"] <= ENSEMBLE_FACTOR * top + ENSEMBLE_FLOORS["quiet_p99"](0, n):
+            v.append(("p99", x["p99"], top))
+        top = max(m["max"] for m in ms)
+        if not x["max"] <= max(ENSEMBLE_MAX_FLOOR, ENSEMBLE_MAX_FACTOR * top):
+            v.append(("max", x["max"], top))
+        return v
+    names = sorted(members)
+    viol = viol_of(h, [members[k] for k in names])
+    loo = {k: viol_of(members[k], [members[j] for j in names if j != k]) for k in names}
+    rep = {"entries": int(n), "hip_vs_o32": {k: h[k] for k in ("n_gt_1e-4", "p99", "max")},
+           "ensemble_vs_o32": {k: {q: members[k][q] for q in ("n_gt_1e-4", "p99", "max")} for k in names},
+           "leave_one_out": {"members_failing": sorted(k for k, v in loo.items() if v), "of": len(names)}, "holds": not viol}
+    if viol:
+        rep["violated"] = [list(v) for v in viol]
+    if check:
+        assert not viol, (what, viol, rep)
+    return rep

@@ -1544,10 +1544,15 @@ int64_t brie_step_storage_bytes(const brie_handle *h) {
     if (!h) return 0;
     // LDS-broadcast wide variants: residual r written by the step, read back by wide_design_grad (the tile kernel keeps it on chip)
     int64_t gemm_streams = (h->wide_like && !h->tile) ? 8 : 0;
-    if (h->vwide) {              // P panels: Xc.Wc_loc written once and re-read / re-written P - 1 times, the step's round trip,
-        int64_t P = (h->p.Kc + BRIE_MAX_KC_WIDE - 1) / BRIE_MAX_KC_WIDE;           // the residual read by P gradient launches
-        if (h->vgwide) P += (h->kgp + BRIE_MAX_KG_WIDE - 1) / BRIE_MAX_KG_WIDE;     // (+ the panels of the gene design)
-        gemm_streams = 4 * (2 * P - 1) + 8 + 4 * P;
+    if (h->vwide) {
+        // the prior-mean array: written by the first forward launch (the cell design's), read and written by the gene design's; read by the step, which writes the residual back (8);
+        // the residual read once per backward launch: one per 256 cell features, one per 64 gene features
+        const int64_t Kc = h->p.Kc;
+        const int64_t fwd_launches = (Kc > 0 ? 1 : 0) + (h->vgwide ? 1 : 0);       // (designs of <= 64 features: one panel)
+        const int64_t fwd = fwd_launches > 0 ? 4 + 8 * (fwd_launches - 1) : 0;
+        const int64_t bwd_c = Kc > 0 ? (Kc + 255) / 256 : 0;
+        const int64_t bwd_g = h->vgwide ? (h->kgp + BRIE_MAX_KG_WIDE - 1) / BRIE_MAX_KG_WIDE : 0;
+        gemm_streams = fwd + 8 + 4 * (bwd_c + bwd_g);
     }
     if (h->cs == brie::kCountMixed) {                    // genes of u8 quads move 1 byte per count, of u16 quads 2
         int64_t genes16 = 0;
@@ -1572,16 +1577,25 @@ namespace {
 int wide_backward(brie_handle *h, float alpha) {
     const dim3 grid(h->gene_blocks, h->n_gchunks), block(512);
     const int Kc = h->p.Kc;
-    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE) {            // one launch per 64-feature panel (one for Kc <= 64)
-        const int kp = std::min(Kc - k0, BRIE_MAX_KC_WIDE);
+    // one launch per 256 features (one for Kc <= 256): the residual is read once per launch, every feature keeps its own
+    // accumulator, so the sums are those of the 64-feature launches of round 4 bit for bit
+    constexpr int kGroup = 256;
+    for (int k0 = 0; k0 < Kc; k0 += kGroup) {
+        const int kp = std::min(Kc - k0, kGroup);
         const float *xp = h->Xc + k0;
         float *gp = h->Gpart + static_cast<size_t>(k0) * h->ld;
-        if (kp <= 32)
-            hipLaunchKernelGGL((brie::wide_design_grad<1>), grid, block, 0, h->stream, xp, h->Rbuf, gp,
-                               static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc);
-        else
-            hipLaunchKernelGGL((brie::wide_design_grad<2>), grid, block, 0, h->stream, xp, h->Rbuf, gp,
-                               static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc);
+#define BRIE_WDG(NACC)                                                                                                  \
+    hipLaunchKernelGGL((brie::wide_design_grad<NACC>), grid, block, 0, h->stream, xp, h->Rbuf, gp,                     \
+                       static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc)
+#define BRIE_WDG_LDS(NACC)                                                                                              \
+    hipLaunchKernelGGL((brie::wide_design_grad_lds<NACC>), grid, block, 0, h->stream, xp, h->Rbuf, gp,                 \
+                       static_cast<int>(h->p.Nc), kp, h->ld, h->gb_stride, h->gchunk_rows, Kc, Kc)
+        if (kp <= 32) BRIE_WDG(1);
+        else if (kp <= 64) BRIE_WDG(2);
+        else if (kp <= 128) BRIE_WDG_LDS(4);           // design operands shared through LDS: 2.55 instead of 3.05 ms per 128
+        else BRIE_WDG_LDS(8);                          // features at configs[2] (calls r5g, r5h)
+#undef BRIE_WDG_LDS
+#undef BRIE_WDG
     }
     const int64_t nW = static_cast<int64_t>(h->p.Kc) * h->ld;
     hipLaunchKernelGGL(brie::wide_w_adam, dim3(grid_1d(nW)), dim3(256), 0, h->stream, h->W, h->m_W, h->v_W, h->Gpart, nW,
@@ -1590,8 +1604,7 @@ int wide_backward(brie_handle *h, float alpha) {
     return BRIE_OK;
 }
 
-// dst (Nc, ld) tiled (+)= X[:, panel] . B[panel, :] for one panel of kp <= 64 features: a handful of features through the
-// LDS-broadcast kernel, more on the matrix cores
+// dst (Nc, ld) tiled (+)= X . B over kp <= 64 features: a handful through the LDS-broadcast kernel, more on the matrix cores
 void launch_panel(brie_handle *h, const float *X, int x_ld, const float *B, int kp, float *dst, bool accumulate) {
     if (kp <= 8) {
         hipLaunchKernelGGL(brie::wide_prior_mean, dim3(h->gene_blocks, h->n_chunks), dim3(brie::kBlock), 0, h->stream, X, B, dst,
@@ -1608,11 +1621,23 @@ void launch_panel(brie_handle *h, const float *X, int x_ld, const float *B, int 
                            static_cast<int>(h->p.Nc), kp, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld);
 }
 
-// dst (Nc, ld) tiled = Xc . Wc_loc, in panels of at most 64 features
+// dst (Nc, ld) tiled (+)= X . B over any number of features: more than 64 in ONE launch of fused_prior_mean (dst read at
+// most once, written once; round 4 launched once per 64-feature panel: 16.5 instead of 14.7 ms per step at Kc = 128, call r5m)
+void launch_panels(brie_handle *h, const float *X, int x_ld, const float *B, int K, float *dst, bool accumulate) {
+    if (K > 64) {
+        const dim3 grid(h->gene_blocks, static_cast<unsigned>((h->p.Nc + brie::kFpmWaves * 32 - 1) / (brie::kFpmWaves * 32)));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(brie::fused_prior_mean), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  brie::kFpmLdsBytes);
+        hipLaunchKernelGGL(brie::fused_prior_mean, grid, dim3(brie::kFpmWaves * brie::kWave), brie::kFpmLdsBytes, h->stream, X, B, dst,
+                           static_cast<int>(h->p.Nc), K, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld);
+        return;
+    }
+    launch_panel(h, X, x_ld, B, K, dst, accumulate);
+}
+
+// dst (Nc, ld) tiled = Xc . Wc_loc
 void launch_xw_panels(brie_handle *h, float *dst) {
-    const int Kc = h->p.Kc;
-    for (int k0 = 0; k0 < Kc; k0 += BRIE_MAX_KC_WIDE)
-        launch_panel(h, h->Xc + k0, Kc, h->W + static_cast<size_t>(k0) * h->ld, std::min(Kc - k0, BRIE_MAX_KC_WIDE), dst, k0 > 0);
+    if (h->p.Kc > 0) launch_panels(h, h->Xc, h->p.Kc, h->W, h->p.Kc, dst, false);
 }
 
 // Mbuf = Xc . Wc_loc for the forward-only loss_gene pass of a wide design
@@ -1624,9 +1649,7 @@ int cell_finalize_blocks(const brie_handle *h) {
 // the wide cell design's Xc . Wc_loc, so the same kernel with (Wg_loc, Xg) in the roles of (Xc, Wc_loc)
 // dst (Nc, ld) tiled (+)= Wg_loc . Xg^T, in panels of at most 64 gene features (one panel for Kg <= 64)
 void launch_gw_panels(brie_handle *h, float *dst, bool accumulate) {
-    for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE)
-        launch_panel(h, h->Wg + k0, h->kgp, h->Xg + static_cast<size_t>(k0) * h->ld, std::min(h->kgp - k0, BRIE_MAX_KG_WIDE), dst,
-                     accumulate || k0 > 0);
+    launch_panels(h, h->Wg, h->kgp, h->Xg, h->kgp, dst, accumulate);
 }
 
 int gwide_forward_mean(brie_handle *h, bool accumulate) {

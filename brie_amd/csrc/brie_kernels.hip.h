@@ -1470,6 +1470,113 @@ __global__ __launch_bounds__(kBlock) void panel_prior_mean(const float *__restri
     }
 }
 
+// The same product over ANY number of features in ONE launch (round 5; rounds 3 - 4 launched panel_prior_mean once per
+// 64-feature panel and re-read / re-wrote the 4-GB array every time).  What the first attempts of this round showed (calls
+// r5c - r5f): every wave re-loading its operands from L1 / L2 makes the texture path the bottleneck (strided dword loads of the
+// design rows: 3.6 - 4.1 ms per 128 features), staging them through LDS with the loads of a stage waited for one after the
+// other leaves the matrix cores idle for a memory latency per stage (3.4 ms).  So: a double-buffered tiled product.
+//   One 512-thread workgroup = 8 waves = 256 cells x one 256-gene block.  The features are walked in STAGES of 32: the
+//   stage's B tile (32 x 256, shared by the 8 waves; pitch 288 floats: the two half-waves of an operand read hit disjoint
+//   banks) and every wave's 32 x 32 design tile (pitch 34) live in one of two LDS buffers; while a stage is multiplied
+//   (128 MFMAs per wave: v_mfma_f32_32x32x2_f32, A from registers, B one ds_read_b32 per MFMA, feature pair outermost =
+//   8 independent accumulator sets) the next stage's tiles are in flight from global memory into registers (coalesced:
+//   16-B pieces of B, one cell's 32 features per half-wave of A) and are written to the other buffer afterwards -- one
+//   barrier per stage.  A wave holds the 32 x 256 outputs of its cells in registers for the whole launch.
+// ONE serial fp32 fma chain per output over all features in feature order, continued from what dst holds with
+// `accumulate` -- the arithmetic of wide_prior_mean (the per-panel launches added per-panel sums instead: last bits differ).
+constexpr int kFpmStage = 32;                               // features per stage
+constexpr int kFpmPitchB = kGenesPerBlock + 32;
+constexpr int kFpmPitchA = kFpmStage + 2;
+constexpr int kFpmWaves = 8;
+constexpr int kFpmBufFloats = kFpmStage * kFpmPitchB + kFpmWaves * 32 * kFpmPitchA;
+constexpr int kFpmLdsBytes = 2 * kFpmBufFloats * 4;
+__global__ __launch_bounds__(kFpmWaves * kWave) void fused_prior_mean(const float *__restrict__ X, const float *__restrict__ B,
+                                                                      float *__restrict__ M, int Nc, int kp, int64_t ld,
+                                                                      int64_t row_stride, int64_t gb_stride, int accumulate,
+                                                                      int x_ld) {
+    extern __shared__ float fpm_lds[];
+    constexpr int NT = kFpmWaves * kWave;
+    constexpr int NB = kFpmStage * (kGenesPerBlock / 4) / NT;           // 16-B pieces of a B tile per thread: 4
+    constexpr int NA = 32 / 2;                                          // design-tile loads per lane: 16 (2 cells per load)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = lane >> 5, l31 = lane & 31;
+    const int c0 = (blockIdx.y * kFpmWaves + w) * 32;
+    const int rows_here = min(32, Nc - c0);                 // <= 0: a wave beyond the last cell computes on copies, stores nothing
+    // D[i][j]: lane l, reg q -> j = l & 31 (gene), i = (q & 3) + 8 (q >> 2) + 4 (l >> 5) (cell of the tile)
+    float *mp = M + static_cast<int64_t>(blockIdx.x) * gb_stride + static_cast<int64_t>(min(c0, Nc - 1)) * row_stride + l31;
+    const int rs = static_cast<int>(row_stride);
+    const float *bg = B + blockIdx.x * kGenesPerBlock;
+    const uint32_t ld32 = static_cast<uint32_t>(ld), xld32 = static_cast<uint32_t>(x_ld);
+    const int n_stages = (kp + kFpmStage - 1) / kFpmStage;
+    floatx4 vb[NB];            // (a native vector: the HIP float4 struct kept this array in scratch memory)
+    float va[NA];
+    // rows of B beyond kp are read (the caller's B has 64 readable rows beyond the last feature) and meet zeros in A; cells
+    // beyond Nc are copies of the last cell and never stored; all loads unconditional on clamped indices
+    auto fetch = [&](int stage) {
+        const int k0 = stage * kFpmStage;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = j * NT + threadIdx.x;
+            // uniform base + ONE 32-bit lane offset (64-bit per-lane addresses for the 20 loads of a stage cost 40
+            // registers, and over the budget the compiler spilled the prefetched tile to scratch -- waiting for the loads
+            // to land BEFORE the stage's first MFMA: a memory latency per stage, 0.62 of the MFMA rate, calls r5g - r5k)
+            vb[j] = *reinterpret_cast<const floatx4 *>(bg + (static_cast<uint32_t>(k0 + i / (kGenesPerBlock / 4)) * ld32 +
+                                                            static_cast<uint32_t>((i % (kGenesPerBlock / 4)) * 4)));
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            va[j] = X[static_cast<uint32_t>(min(c0 + 2 * j + half, Nc - 1)) * xld32 + static_cast<uint32_t>(min(k0 + l31, kp - 1))];
+    };
+    auto stash = [&](int stage) {
+        float *bt = fpm_lds + (stage & 1) * kFpmBufFloats;
+        float *at = bt + kFpmStage * kFpmPitchB + w * (32 * kFpmPitchA);
+        const bool ok = stage * kFpmStage + l31 < kp;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int i = j * NT + threadIdx.x;
+            *reinterpret_cast<floatx4 *>(bt + (i / (kGenesPerBlock / 4)) * kFpmPitchB + (i % (kGenesPerBlock / 4)) * 4) = vb[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) at[(2 * j + half) * kFpmPitchA + l31] = ok ? va[j] : 0.0f;
+    };
+    fetch(0);
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            acc[t][q] = accumulate ? mp[min((q & 3) + 8 * (q >> 2) + 4 * half, max(rows_here, 1) - 1) * rs + t * 32] : 0.0f;
+    stash(0);
+    __syncthreads();
+    for (int stage = 0; stage < n_stages; ++stage) {
+        if (stage + 1 < n_stages) fetch(stage + 1);         // in flight during this stage's MFMAs
+        const float *bt = fpm_lds + (stage & 1) * kFpmBufFloats;
+        const float *at = bt + kFpmStage * kFpmPitchB + w * (32 * kFpmPitchA);
+        float a[kFpmStage / 2];
+#pragma unroll
+        for (int s = 0; s < kFpmStage / 2; ++s) a[s] = at[l31 * kFpmPitchA + 2 * s + half];
+        const float *bl = bt + half * kFpmPitchB + l31;
+#pragma unroll
+        for (int s = 0; s < kFpmStage / 2; ++s) {
+            float b[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b[t] = bl[2 * s * kFpmPitchB + t * 32];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[t], 0, 0, 0);
+        }
+        if (stage + 1 < n_stages) stash(stage + 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+            if (i < rows_here) mp[i * rs + t * 32] = acc[t][q];
+        }
+}
+
 // wide designs, forward only (loss_gene_eval reads it): Mbuf = Xc . Wc_loc, tiled like the state arrays
 // (Kc = the features of THIS launch, at most kWideKcMax: a panel of a wider design starts at Xc + k0 with row pitch x_ld
 //  and at W + k0 * ld, and accumulates)
@@ -1505,9 +1612,8 @@ __global__ __launch_bounds__(kBlock) void wide_prior_mean(const float *Xc, const
 // 32 features x 2 cells of Xc:  A[i = feature][k = cell], B[k = cell][j = gene],
 // D[i][j]: lane l, reg q -> j = l & 31, i = (q & 3) + 8 (q >> 2) + 4 (l >> 5).
 // Gpart: (n_chunks, Kc, ld) partial sums, reduced in fp64 by wide_w_adam.
-template <int NACC>      // 1: Kc <= 32, 2: Kc <= 64
-// (Kc = the features of THIS launch; a panel of a wider design passes Xc + k0 with row pitch x_ld, Gpart + k0 * ld and
-//  the chunk stride kc_total of the whole design)
+template <int NACC>      // 32-feature accumulator sets: 1: Kc <= 32, 2: Kc <= 64 features (wider launches: wide_design_grad_lds)
+// (Kc = the features of THIS launch, x_ld the row pitch of Xc, kc_total the chunk stride of Gpart)
 __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict__ Xc, const float *__restrict__ R,
                                                         float *__restrict__ Gpart, int Nc, int Kc, int64_t ld,
                                                         int64_t gb_stride, int rows_per_chunk, int x_ld, int kc_total) {
@@ -1554,6 +1660,96 @@ __global__ __launch_bounds__(512) void wide_design_grad(const float *__restrict_
                 acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32((ok && feat_ok[a]) ? cur.a[u][a] : 0.0f, bv, acc[a], 0, 0, 0);
         }
         cur = nxt;
+    }
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int feat = (q & 3) + 8 * (q >> 2) + 4 * half + 32 * a;
+            if (feat < Kc)
+                Gpart[(static_cast<int64_t>(blockIdx.y) * kc_total + feat) * ld + blockIdx.x * kGenesPerBlock + w * 32 + l31] =
+                    acc[a][q];
+        }
+}
+
+// The same reduction for MORE than 64 features per launch (round 5): every wave of the workgroup needs the same design
+// operands (it only owns another 32-gene slice), and with one 256-B operand load per wave and MFMA the texture path, not
+// the matrix cores, set the pace (84 TFLOP/s, call r5g).  Here the design rows of a stage (16 cells x all features of the
+// launch, zero beyond Kc / the chunk's last cell) are staged ONCE per workgroup into one of two LDS buffers (pitch = 32 mod
+// 64 floats: the two half-waves of an operand read hit disjoint banks) while the previous stage is multiplied; the residual
+// operands stay per-wave register loads, one stage ahead.  Every feature keeps its own accumulator and the cells are walked
+// in the same order: the sums are those of wide_design_grad bit for bit.
+template <int NACC>      // 32-feature accumulator sets: 4: <= 128, 8: <= 256 features per launch
+__global__ __launch_bounds__(512) void wide_design_grad_lds(const float *__restrict__ Xc, const float *__restrict__ R,
+                                                            float *__restrict__ Gpart, int Nc, int Kc, int64_t ld,
+                                                            int64_t gb_stride, int rows_per_chunk, int x_ld, int kc_total) {
+    constexpr int F = 32 * NACC, PA = F + 32, U = 8, CELLS = 2 * U;
+    constexpr int NA = CELLS * F / 512;                    // design floats per thread and stage: 4 / 8
+    __shared__ float at[2][CELLS * PA];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x >> 6;                        // gene slice 0..7
+    const int half = lane >> 5, l31 = lane & 31;
+    const int row0 = blockIdx.y * rows_per_chunk;
+    const int row_end = min(row0 + rows_per_chunk, Nc);
+    if (row0 >= row_end) return;                           // block-uniform
+    const float *rp = R + static_cast<int64_t>(blockIdx.x) * gb_stride + w * 32 + l31;
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][q] = 0.0f;
+    float va[NA], bcur[U], bnxt[U];
+    // every load unconditional on a clamped index, zeroed by a select afterwards (a load under a lane mask is a branch)
+    auto fetch_a = [&](int r) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 512 + threadIdx.x, c = idx / F, f = idx % F;
+            va[j] = Xc[static_cast<int64_t>(min(r + c, row_end - 1)) * x_ld + min(f, Kc - 1)];
+        }
+    };
+    auto stash_a = [&](int r, int buf) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 512 + threadIdx.x, c = idx / F, f = idx % F;
+            at[buf][c * PA + f] = (r + c < row_end && f < Kc) ? va[j] : 0.0f;
+        }
+    };
+    auto fetch_b = [&](int r, float (&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = rp[static_cast<int64_t>(min(r + 2 * u + half, row_end - 1)) * kGenesPerBlock];
+    };
+    fetch_a(row0);
+    fetch_b(row0, bcur);
+    stash_a(row0, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int r = row0; r < row_end; r += CELLS) {
+        const bool more = r + CELLS < row_end;
+        if (more) { fetch_a(r + CELLS); fetch_b(r + CELLS, bnxt); }     // in flight during this stage's MFMAs
+        const float *al = at[buf] + half * PA + l31;
+        // software pipeline, pinned with scheduling barriers: the design operands of cell pair u + 1 are read from LDS
+        // before the MFMAs of pair u issue (see fused_prior_mean)
+        float av[2][NACC];
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) av[0][a] = al[32 * a];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float bv = r + 2 * u + half < row_end ? bcur[u] : 0.0f;
+            if (u + 1 < U) {
+#pragma unroll
+                for (int a = 0; a < NACC; ++a) av[(u + 1) & 1][a] = al[2 * (u + 1) * PA + 32 * a];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < NACC; ++a)
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u & 1][a], bv, acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) stash_a(r + CELLS, buf ^ 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) bcur[u] = bnxt[u];
+        buf ^= 1;
+        __syncthreads();
     }
 #pragma unroll
     for (int a = 0; a < NACC; ++a)

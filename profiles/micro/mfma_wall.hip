@@ -1,0 +1,49 @@
+// Wall-clock rate of v_mfma_f32_32x32x2_f32 over the WHOLE chip, bare (8 independent accumulator sets per wave, 2 waves per
+// SIMD, no memory traffic) and with one ds_read_b32 per MFMA -- the ceiling the panel kernels of DESIGN 4.4 are held against:
+//   hipcc --offload-arch=gfx950 -O3 profiles/micro/mfma_wall.hip -o /tmp/mfma_wall && /tmp/mfma_wall
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool LDS>
+__global__ __launch_bounds__(512) void k(float *o, int n, float a, float b) {
+    __shared__ float sh[64 * 288];
+    for (int i = threadIdx.x; i < 64 * 288; i += 512) sh[i] = b;
+    __syncthreads();
+    f32x16 D[8];
+    for (int c = 0; c < 8; ++c) for (int q = 0; q < 16; ++q) D[c][q] = 0.f;
+    const float *bl = sh + (threadIdx.x & 63);
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, LDS ? bl[((i & 7) * 8 + c) * 288] : b, D[c], 0, 0, 0);
+    }
+    float s = 0;
+    for (int c = 0; c < 8; ++c) for (int q = 0; q < 16; ++q) s += D[c][q];
+    o[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+int main() {
+    float *o;
+    hipMalloc(&o, 4096 * 512 * sizeof(float));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int lds = 0; lds < 2; ++lds)
+        for (int blocks : {256, 512, 2048}) {
+            for (int n : {2000, 8000, 32000}) {         // ~0.5 ms .. ~7 ms per launch at 256 blocks
+                float best = 1e30f, last = 0;
+                for (int rep = 0; rep < 4; ++rep) {
+                    hipEventRecord(e0);
+                    if (lds) hipLaunchKernelGGL(k<true>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    else hipLaunchKernelGGL(k<false>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                    hipEventElapsedTime(&last, e0, e1);
+                    if (last < best) best = last;
+                }
+                const double flop = 2.0 * 32 * 32 * 2 * 8.0 * n * 8 /*waves*/ * blocks;
+                printf("{\"lds_operand\": %d, \"blocks\": %d, \"mfma_per_wave\": %d, \"ms_best\": %.3f, \"ms_last\": %.3f, \"TFLOPs\": %.1f}\n",
+                       lds, blocks, 8 * n, best, last, flop / (best * 1e-3) / 1e12);
+            }
+        }
+    return 0;
+}

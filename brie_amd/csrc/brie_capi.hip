@@ -2065,16 +2065,15 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             return rc;                            // residual buffer -> G = Xc^T . r (MFMA kernel), Adam on Wc_loc
         if (h->vgwide) {                          // residual buffer -> the Wg_loc gradient r . Xg (MFMA), panel by panel, into rowstat
             const dim3 ggrid(static_cast<unsigned>((h->p.Nc + 31) / 32));
-            for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE) {
-                const int kp = std::min(h->kgp - k0, BRIE_MAX_KG_WIDE);
-                if (kp <= 32)
-                    hipLaunchKernelGGL((brie::gene_design_grad<1>), ggrid, dim3(brie::kBlock), 0, h->stream, h->XgT, h->Rbuf,
-                                       cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks, kp, k0,
-                                       h->kgp, h->row_stride, h->gb_stride);
-                else
-                    hipLaunchKernelGGL((brie::gene_design_grad<2>), ggrid, dim3(brie::kBlock), 0, h->stream, h->XgT, h->Rbuf,
-                                       cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks, kp, k0,
-                                       h->kgp, h->row_stride, h->gb_stride);
+            for (int k0 = 0; k0 < h->kgp; k0 += BRIE_MAX_KG_WIDE) {     // one launch per 64 gene features (4 accumulator sets per
+                const int kp = std::min(h->kgp - k0, BRIE_MAX_KG_WIDE);    // wave need > 256 registers with this kernel's unrolling)
+#define BRIE_GDG(NACC)                                                                                                  \
+    hipLaunchKernelGGL((brie::gene_design_grad<NACC>), ggrid, dim3(brie::kBlock), 0, h->stream, h->XgT, h->Rbuf,       \
+                       cf.rowstat, static_cast<int>(h->p.Nc), static_cast<int>(h->p.Ng), h->gene_blocks, kp, k0,       \
+                       h->kgp, h->row_stride, h->gb_stride)
+                if (kp <= 32) BRIE_GDG(1);
+                else BRIE_GDG(2);
+#undef BRIE_GDG
             }
         }
         if (h->coupled && lib_reduce && !split) {

@@ -138,7 +138,7 @@ def run_all(cases, runs, cores):
         started = False
         for j in list(jobs):
             parts = 8 if j[1] == "o32" else MEMBERS[j[1]]["parts"]
-            t = next(d for d in (4, 3, 2, 1) if parts % d == 0)            # threads divide the parts: no idle rounds
+            t = next(d for d in (4, 3, 2, 1) if parts % d == 0 and d <= cores)   # threads divide the parts: no idle rounds
             if used + t <= cores:
                 env = dict(os.environ, OMP_NUM_THREADS=str(t), OMP_WAIT_POLICY="active")
                 live.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--one", "%s:%s:%d" % (j[0], j[1], t)],

@@ -4,8 +4,6 @@ timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_comm.py te
 tail -4 $O/r5m_pytest_wide.log
 timeout 900 python profiles/wide_ab.py --rounds 2 --steps 4 --cases 128:0,256:0,3:128,70:0 > $O/r5m_panels_at_c3.log 2>&1
 tail -1 $O/r5m_panels_at_c3.log
-BRIE_WDG_LDS=0 timeout 900 python profiles/wide_ab.py --rounds 2 --steps 4 --cases 128:0,256:0 > $O/r5m_panels_at_c3_wdg_per_wave.log 2>&1
-tail -1 $O/r5m_panels_at_c3_wdg_per_wave.log
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r5m -o t -- python3 $R/profiles/wide_ab.py --rounds 1 --steps 4 --cases 128:0,256:0,3:128 > $O/r5m_run.log 2>&1
 f=$(find /tmp/r5m -name "*kernel_stats.csv" | head -1)

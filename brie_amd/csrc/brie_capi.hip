@@ -1775,7 +1775,7 @@ inline int placement_class(const brie_handle *h) {
 //    Peak transient holding = (sets held) x (streamed bytes), reported by brie_placement_status.
 //  * time: no new round and no new candidate once `max_seconds` (BRIE_PLACEMENT_SECONDS, default 3) have passed.
 //  * sets: at most max_sets <= BRIE_PLACEMENT_MAX_SETS (8) in all, the original included.
-int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_cu) {
+int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_cu, double next_round_gbs = 0.0) {
     max_sets = std::max(1, std::min(max_sets, static_cast<int>(BRIE_PLACEMENT_MAX_SETS)));
     // BRIE_PLACEMENT_INTERLEAVE=0: candidate sets one after the other, each allocated as a block (A/B runs; the first version)
     static const bool interleave = [] { const char *e = getenv("BRIE_PLACEMENT_INTERLEAVE"); return !(e && e[0] == '0'); }();
@@ -1836,7 +1836,11 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
     const int round_size = placement_class(h) == 1 ? 1 : 3;
     std::vector<StreamedSet> held;                // candidate k is set k + 1
     int kept = -1, status = -1;
-    while (best < good_gbs && 1 + static_cast<int>(held.size()) < max_sets) {
+    // `good_gbs` ends the search at once; `next_round_gbs` <= good_gbs is what it takes NOT to start a further round once one
+    // round of candidates has been probed: a first set between the two buys exactly one round (three candidates), not eight
+    // sets (round 5: first sets at 6.09 - 6.12 TB/s where the kept ones of other processes read 6.16 - 6.33)
+    if (next_round_gbs <= 0.0 || next_round_gbs > good_gbs) next_round_gbs = good_gbs;
+    while (best < (held.empty() ? good_gbs : next_round_gbs) && 1 + static_cast<int>(held.size()) < max_sets) {
         if (elapsed() > max_seconds) { status = BRIE_PLACEMENT_STOPPED_TIME; break; }
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { note("hipMemGetInfo failed", nullptr); status = BRIE_PLACEMENT_STOPPED_ERROR; break; }
@@ -1888,7 +1892,7 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
         }
         if (status >= 0) break;
     }
-    if (status < 0) status = best >= good_gbs ? BRIE_PLACEMENT_GOOD : BRIE_PLACEMENT_BEST_OF_ALL;
+    if (status < 0) status = best >= next_round_gbs ? BRIE_PLACEMENT_GOOD : BRIE_PLACEMENT_BEST_OF_ALL;
     adopt_set(h, kept < 0 ? first : held[static_cast<size_t>(kept)]);     // the fastest COMPLETE set (first is never written to)
     (void)hipStreamSynchronize(h->stream);
     for (size_t k = 0; k < held.size(); ++k)
@@ -1918,6 +1922,9 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
 // kernel's to 1 %, correlation 0.999 at configs[2] -- read 4.93 - 5.30 TB/s in the slow mode, 5.49 - 5.94 in between and
 // 6.0 - 6.24 in the fast one; or 0.97 x the best rate a handle of this process has reached on the device if higher.
 constexpr double kPlacementGoodGBs = 6050.0;
+// ... and a first set below 6150 still buys ONE round of candidates (call r5q: the bench handle stopped on a first set at 6.11
+// TB/s, `frac` 0.855, where the sets kept by 30 other processes of the round read 6.16 - 6.33, 0.854 - 0.874)
+constexpr double kPlacementStopAtOnceGBs = 6150.0;
 // ... and for handles whose arrays are below a gigabyte 5850: the search used to run all four sets for them every time
 // (6050 was out of reach) -- 14 - 44 ms of a 0.6-s configs[1] fit even when the first set was already in the fast mode
 constexpr double kPlacementGoodSmallGBs = 5850.0;
@@ -1933,7 +1940,8 @@ int auto_placement(brie_handle *h, int mc_size) {
         std::lock_guard<std::mutex> l(g_place_mu);
         good = std::max(good, 0.97 * g_place_best[h->p.device & 63][cls]);
     }
-    return tune_placement(h, tries, good, mc_size > 1);      // the step runs two workgroups per CU for MC_size > 1 (brie_inst.hip)
+    const double at_once = (good_env > 0.0 || cls == 1) ? good : std::max(good, kPlacementStopAtOnceGBs);
+    return tune_placement(h, tries, at_once, mc_size > 1, good);     // the step runs two workgroups per CU for MC_size > 1 (brie_inst.hip)
 }
 
 // split = 0: n_steps complete steps.  split = 1 (n_steps == 1): everything up to the reduced per-cell

@@ -327,7 +327,7 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  * >= 256 MiB per step (see brie_step): BRIE_PLACEMENT_TRIES sets in all (default BRIE_PLACEMENT_MAX_SETS = 8; 1 = off),
  * good_gbs = BRIE_PLACEMENT_GOOD_GBS (default 6050 -- 5850 for handles whose arrays are below 1 GiB, which never read
  * faster than 6.0 TB/s --, or 0.97 x the best rate a handle of that size class has reached in this process on the device
- * when that is higher).
+ * when that is higher; a first set of a large handle between 6050 and 6150 still buys ONE round of candidates).
  *  BOUNDS.  Memory: before every round hipMemGetInfo is read afresh and the round takes at most BRIE_PLACEMENT_HBM_FRACTION
  *  (default 0.8) of the HBM that is free beyond a 2-GiB reserve; with the sets of earlier rounds still held the transient
  *  peak is (sets held) x brie_step_storage_bytes-worth of arrays -- at configs[2] 26 GB per set, 78 GB after one round,

@@ -50,6 +50,11 @@ MEMBERS = {"t2": dict(parts=2, float_noise=1, reverse=1, chunk=64),
 # round 4's cases (their 128-gene caches of t4 / t6 / t8 are sliced) and ONE new held-out set of seeds per shape
 CASES = {"c2_cli_128": dict(of="c2_cli_128"), "c3_cli_128": dict(of="c3_cli_128"),
          "c2_cli_64_s5": dict(of="c2_cli_64_s5", held_out=True), "c3_cli_64_s5": dict(of="c3_cli_64_s5", held_out=True)}
+# addendum 1 (registered after the four cases above had been judged, before anything ran on these): three more held-out cases
+ADDENDUM_1 = {"c2_cli_64_s6": dict(of="c2_cli_64_s6", held_out=True), "c3_cli_64_s6": dict(of="c3_cli_64_s6", held_out=True),
+              "mid_cli_64_s6": dict(of="mid_cli_64_s6", held_out=True)}
+REGISTERED_FIRST = tuple(CASES)
+CASES.update(ADDENDUM_1)
 OLD_DRAWS = {"t4": "_t4", "t6": "", "t8": "_t8"}           # suffixes of profiles/_psi_cache/<case>_float32b<suffix>.npz
 
 
@@ -162,14 +167,21 @@ def register():
                          "shift_cap": util.ENSEMBLE_SHIFT_CAP, "floors": "moved_genes max(2, 1 % genes); quiet_rate max(1e-5, 20 / entries); "
                          "quiet_p99 5e-6", "psi_tol": util.PSI_TOL, "gene_shift": util.GENE_SHIFT},
            "genes": GENES, "members": MEMBERS, "member_build": "gcc -O3 -DBRIE_ORACLE_B -ffp-contract=fast -mfma -fopenmp oracle/brie_oracle.c",
-           "cases": {k: dict({kk: vv for kk, vv in pd.CASES[v["of"]].items()}, model_seed=pd.model_seed(v["of"]),
-                             held_out=bool(v.get("held_out"))) for k, v in CASES.items()},
+           "cases": {k: dict({kk: vv for kk, vv in pd.CASES[CASES[k]["of"]].items()}, model_seed=pd.model_seed(CASES[k]["of"]),
+                             held_out=bool(CASES[k].get("held_out"))) for k in REGISTERED_FIRST},
            "note": "registered before the members of the *_s5 cases (and t2 / t12 / x3 of the others) were computed and before "
                    "the HIP path ran on the *_s5 cases; t4 / t6 / t8 of c2_cli_128 / c3_cli_128 are round 4's draws"}
     man = json.load(open(MANIFEST)) if os.path.exists(MANIFEST) else {}
     if "registered" in man and man["registered"] != json.loads(json.dumps(reg)):
         raise SystemExit("the manifest is already registered with other contents: not overwritten")
     man["registered"] = reg
+    add = {"cases": {k: dict({kk: vv for kk, vv in pd.CASES[v["of"]].items()}, model_seed=pd.model_seed(v["of"]), held_out=True)
+                     for k, v in ADDENDUM_1.items()},
+           "note": "same rule, constants and members as `registered`; added after the four cases of `registered` had been judged on the "
+                   "GPU (call r5q: all hold) and before any run of either side on these three"}
+    if "registered_addendum_1" in man and man["registered_addendum_1"] != json.loads(json.dumps(add)):
+        raise SystemExit("addendum 1 is already registered with other contents: not overwritten")
+    man["registered_addendum_1"] = add
     with open(MANIFEST, "w") as fh:
         json.dump(man, fh, indent=1, sort_keys=True)
     print("registered", MANIFEST)
@@ -229,7 +241,7 @@ def load_fixture(case):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cases", default=",".join(CASES))
+    ap.add_argument("--cases", default=",".join(CASES))      # (run / freeze skip what exists)
     ap.add_argument("--runs", default=",".join(["o32"] + list(MEMBERS)))
     ap.add_argument("--register", action="store_true")
     ap.add_argument("--run", action="store_true")

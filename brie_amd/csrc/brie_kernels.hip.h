@@ -1721,6 +1721,11 @@ __global__ __launch_bounds__(512) void wide_design_grad_lds(const float *__restr
     fetch_a(row0);
     fetch_b(row0, bcur);
     stash_a(row0, 0);
+    // The first stage's residual operands must have LANDED before the loop: with a load still pending on them at loop entry
+    // the compiler's wait-count insertion, which merges the state of the preheader and of the back edge, made EVERY
+    // iteration wait for five of the loads it had just issued for the next stage before its first MFMA (s_waitcnt vmcnt(7)
+    // ... vmcnt(0) down the stage: a memory latency per 16 cells; seen in the ISA after call r5r).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0), expcnt(7), lgkmcnt(15)
     __syncthreads();
     int buf = 0;
     for (int r = row0; r < row_end; r += CELLS) {

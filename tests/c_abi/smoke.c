@@ -73,12 +73,32 @@ int main(void) {
         brie_comm *comm = NULL;
         float v[4] = {1.0f, 2.0f, 3.0f, 4.0f}, g[4];
         double d[2] = {0.5, -1.0};
+        CHECK(brie_comm_available(0));                           /* what every rank checks alone before an id exists */
+        if (brie_comm_available(9999) == BRIE_OK) { fprintf(stderr, "device 9999 accepted\n"); return 1; }
         CHECK(brie_comm_unique_id(id));
         CHECK(brie_comm_init(0, 0, 1, id, &comm));
         CHECK(brie_comm_allgather(comm, v, 4, g));
         CHECK(brie_comm_allreduce(comm, d, 2, BRIE_F64, BRIE_SUM));
         if (memcmp(v, g, sizeof v) != 0 || d[0] != 0.5 || brie_comm_world(comm) != 1) { fprintf(stderr, "comm\n"); return 1; }
         CHECK(brie_comm_destroy(comm));
+    }
+    /* round 5: the placement search on demand from plain C -- two sets, unreachable stop rate: best effort, says how it ended */
+    {
+        int32_t tries = 0, kept = 0, status = -1;
+        int64_t peak = 0;
+        double gbs[BRIE_PLACEMENT_MAX_SETS], secs = 0.0, rate = 0.0;
+        char why[192];
+        CHECK(brie_placement_probe(h, 2, &rate));
+        CHECK(brie_placement_tune(h, 2, 1e30));
+        CHECK(brie_placement_info(h, &tries, &kept, gbs, &secs));
+        CHECK(brie_placement_status(h, &status, &peak, why, (int32_t)sizeof why));
+        if (!(rate > 0.0) || tries != 2 || kept < 0 || kept > 1 || status != BRIE_PLACEMENT_BEST_OF_ALL || peak <= 0 || !why[0]) {
+            fprintf(stderr, "placement: rate %g tries %d kept %d status %d peak %lld note \"%s\"\n", rate, (int)tries, (int)kept,
+                    (int)status, (long long)peak, why);
+            return 1;
+        }
+        float tr3[2];
+        CHECK(brie_step(h, 2, 0.02f, 1, tr3));                   /* the moved arrays step on */
     }
     if (brie_step(h, 1, 0.02f, 0, NULL) == BRIE_OK) { fprintf(stderr, "mc_size 0 accepted\n"); return 1; }
     printf("loss %.3f -> %.3f  mean_psi %.6f  loss_gene0 %.3f  last_error \"%s\"\n", trace[0], trace[STEPS - 1],

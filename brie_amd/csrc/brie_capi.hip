@@ -1625,11 +1625,19 @@ void launch_panel(brie_handle *h, const float *X, int x_ld, const float *B, int 
 // most once, written once; round 4 launched once per 64-feature panel: 16.5 instead of 14.7 ms per step at Kc = 128, call r5m)
 void launch_panels(brie_handle *h, const float *X, int x_ld, const float *B, int K, float *dst, bool accumulate) {
     if (K > 64) {
-        const dim3 grid(h->gene_blocks, static_cast<unsigned>((h->p.Nc + brie::kFpmWaves * 32 - 1) / (brie::kFpmWaves * 32)));
+        // persistent: one workgroup per CU walks the (gene block x 256-cell block) tiles round-robin
+        static int cus[64] = {};
+        int &n_cu = cus[h->p.device & 63];
+        if (n_cu == 0) {
+            hipDeviceProp_t prop;
+            n_cu = hipGetDeviceProperties(&prop, h->p.device) == hipSuccess ? prop.multiProcessorCount : 256;
+        }
+        const int64_t n_tiles = static_cast<int64_t>(h->gene_blocks) * ((h->p.Nc + brie::kFpmWaves * 32 - 1) / (brie::kFpmWaves * 32));
+        const dim3 grid(static_cast<unsigned>(std::min<int64_t>(n_tiles, n_cu)));
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(brie::fused_prior_mean), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   brie::kFpmLdsBytes);
         hipLaunchKernelGGL(brie::fused_prior_mean, grid, dim3(brie::kFpmWaves * brie::kWave), brie::kFpmLdsBytes, h->stream, X, B, dst,
-                           static_cast<int>(h->p.Nc), K, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld);
+                           static_cast<int>(h->p.Nc), K, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld, h->gene_blocks);
         return;
     }
     launch_panel(h, X, x_ld, B, K, dst, accumulate);

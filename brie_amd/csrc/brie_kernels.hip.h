@@ -1482,18 +1482,24 @@ __global__ __launch_bounds__(kBlock) void panel_prior_mean(const float *__restri
 //   8 independent accumulator sets) the next stage's tiles are in flight from global memory into registers (coalesced:
 //   16-B pieces of B, one cell's 32 features per half-wave of A) and are written to the other buffer afterwards -- one
 //   barrier per stage.  A wave holds the 32 x 256 outputs of its cells in registers for the whole launch.
-// ONE serial fp32 fma chain per output over all features in feature order, continued from what dst holds with
-// `accumulate` -- the arithmetic of wide_prior_mean (the per-panel launches added per-panel sums instead: last bits differ).
+// ONE serial fp32 fma chain per output over all features in feature order, from zero; with `accumulate` the chain's sum is
+// added to what dst holds (wide_prior_mean continues the chain from it, round 4 added per-panel sums: last bits differ).
 constexpr int kFpmStage = 32;                               // features per stage
 constexpr int kFpmPitchB = kGenesPerBlock + 32;
 constexpr int kFpmPitchA = kFpmStage + 2;
 constexpr int kFpmWaves = 8;
 constexpr int kFpmBufFloats = kFpmStage * kFpmPitchB + kFpmWaves * 32 * kFpmPitchA;
 constexpr int kFpmLdsBytes = 2 * kFpmBufFloats * 4;
+// PERSISTENT over output tiles: the grid is one workgroup per CU (the LDS buffers allow no more), workgroup i takes the
+// tiles i, i + gridDim.x, ... (tile = gene block x 256-cell block, the cell block running fastest: the workgroups that
+// run together share a gene block's B tiles in L2); the first stage of the NEXT tile is fetched during the last stage
+// of the current one, so only the first tile of a workgroup pays a memory latency before its first MFMA and the epilogue
+// stores drain under the next tile's MFMAs (the one-tile-per-workgroup version left the matrix cores idle 30 % of the
+// time: SQ_VALU_MFMA_BUSY_CYCLES, call r5u).
 __global__ __launch_bounds__(kFpmWaves * kWave) void fused_prior_mean(const float *__restrict__ X, const float *__restrict__ B,
                                                                       float *__restrict__ M, int Nc, int kp, int64_t ld,
                                                                       int64_t row_stride, int64_t gb_stride, int accumulate,
-                                                                      int x_ld) {
+                                                                      int x_ld, int gene_blocks) {
     extern __shared__ float fpm_lds[];
     constexpr int NT = kFpmWaves * kWave;
     constexpr int NB = kFpmStage * (kGenesPerBlock / 4) / NT;           // 16-B pieces of a B tile per thread: 4
@@ -1501,20 +1507,19 @@ __global__ __launch_bounds__(kFpmWaves * kWave) void fused_prior_mean(const floa
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, l31 = lane & 31;
-    const int c0 = (blockIdx.y * kFpmWaves + w) * 32;
-    const int rows_here = min(32, Nc - c0);                 // <= 0: a wave beyond the last cell computes on copies, stores nothing
-    // D[i][j]: lane l, reg q -> j = l & 31 (gene), i = (q & 3) + 8 (q >> 2) + 4 (l >> 5) (cell of the tile)
-    float *mp = M + static_cast<int64_t>(blockIdx.x) * gb_stride + static_cast<int64_t>(min(c0, Nc - 1)) * row_stride + l31;
     const int rs = static_cast<int>(row_stride);
-    const float *bg = B + blockIdx.x * kGenesPerBlock;
     const uint32_t ld32 = static_cast<uint32_t>(ld), xld32 = static_cast<uint32_t>(x_ld);
     const int n_stages = (kp + kFpmStage - 1) / kFpmStage;
+    const int n_ct = (Nc + kFpmWaves * 32 - 1) / (kFpmWaves * 32);       // 256-cell blocks
+    const int n_tiles = gene_blocks * n_ct;
     floatx4 vb[NB];            // (a native vector: the HIP float4 struct kept this array in scratch memory)
     float va[NA];
     // rows of B beyond kp are read (the caller's B has 64 readable rows beyond the last feature) and meet zeros in A; cells
     // beyond Nc are copies of the last cell and never stored; all loads unconditional on clamped indices
-    auto fetch = [&](int stage) {
+    auto fetch = [&](int tile, int stage) {
         const int k0 = stage * kFpmStage;
+        const float *bg = B + (tile / n_ct) * kGenesPerBlock;
+        const int c0 = ((tile % n_ct) * kFpmWaves + w) * 32;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int i = j * NT + threadIdx.x;
@@ -1528,8 +1533,8 @@ __global__ __launch_bounds__(kFpmWaves * kWave) void fused_prior_mean(const floa
         for (int j = 0; j < NA; ++j)
             va[j] = X[static_cast<uint32_t>(min(c0 + 2 * j + half, Nc - 1)) * xld32 + static_cast<uint32_t>(min(k0 + l31, kp - 1))];
     };
-    auto stash = [&](int stage) {
-        float *bt = fpm_lds + (stage & 1) * kFpmBufFloats;
+    auto stash = [&](int buf, int stage) {
+        float *bt = fpm_lds + buf * kFpmBufFloats;
         float *at = bt + kFpmStage * kFpmPitchB + w * (32 * kFpmPitchA);
         const bool ok = stage * kFpmStage + l31 < kp;
 #pragma unroll
@@ -1540,41 +1545,69 @@ __global__ __launch_bounds__(kFpmWaves * kWave) void fused_prior_mean(const floa
 #pragma unroll
         for (int j = 0; j < NA; ++j) at[(2 * j + half) * kFpmPitchA + l31] = ok ? va[j] : 0.0f;
     };
-    fetch(0);
-    f32x16 acc[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q)
-            acc[t][q] = accumulate ? mp[min((q & 3) + 8 * (q >> 2) + 4 * half, max(rows_here, 1) - 1) * rs + t * 32] : 0.0f;
-    stash(0);
+    int tile = blockIdx.x;
+    if (tile >= n_tiles) return;                            // block-uniform
+    fetch(tile, 0);
+    stash(0, 0);
     __syncthreads();
-    for (int stage = 0; stage < n_stages; ++stage) {
-        if (stage + 1 < n_stages) fetch(stage + 1);         // in flight during this stage's MFMAs
-        const float *bt = fpm_lds + (stage & 1) * kFpmBufFloats;
-        const float *at = bt + kFpmStage * kFpmPitchB + w * (32 * kFpmPitchA);
-        float a[kFpmStage / 2];
+    int buf = 0;
+    for (; tile < n_tiles; tile += gridDim.x) {
+        f32x16 acc[8];
 #pragma unroll
-        for (int s = 0; s < kFpmStage / 2; ++s) a[s] = at[l31 * kFpmPitchA + 2 * s + half];
-        const float *bl = bt + half * kFpmPitchB + l31;
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int s = 0; s < kFpmStage / 2; ++s) {
-            float b[8];
+            for (int q = 0; q < 16; ++q) acc[t][q] = 0.0f;
+        for (int stage = 0; stage < n_stages; ++stage) {
+            // what comes next: this tile's next stage, or the first stage of the workgroup's next tile
+            const bool last = stage + 1 == n_stages;
+            const int nt = last ? tile + static_cast<int>(gridDim.x) : tile, ns = last ? 0 : stage + 1;
+            const bool more = nt < n_tiles;
+            if (more) fetch(nt, ns);                        // in flight during this stage's MFMAs
+            const float *bt = fpm_lds + buf * kFpmBufFloats;
+            const float *at = bt + kFpmStage * kFpmPitchB + w * (32 * kFpmPitchA);
+            float a[kFpmStage / 2];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) b[t] = bl[2 * s * kFpmPitchB + t * 32];
+            for (int s = 0; s < kFpmStage / 2; ++s) a[s] = at[l31 * kFpmPitchA + 2 * s + half];
+            const float *bl = bt + half * kFpmPitchB + l31;
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[t], 0, 0, 0);
+            for (int s = 0; s < kFpmStage / 2; ++s) {
+                float b[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) b[t] = bl[2 * s * kFpmPitchB + t * 32];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[t], 0, 0, 0);
+            }
+            if (more) stash(buf ^ 1, ns);
+            buf ^= 1;
+            __syncthreads();
         }
-        if (stage + 1 < n_stages) stash(stage + 1);
-        __syncthreads();
+        // epilogue of the tile; D[i][j]: lane l, reg q -> j = l & 31 (gene), i = (q & 3) + 8 (q >> 2) + 4 (l >> 5) (cell)
+        const int c0 = ((tile % n_ct) * kFpmWaves + w) * 32;
+        const int rows_here = min(32, Nc - c0);             // <= 0: a wave beyond the last cell computed on copies, stores nothing
+        float *mp = M + static_cast<int64_t>(tile / n_ct) * gb_stride + static_cast<int64_t>(min(c0, Nc - 1)) * row_stride + l31;
+        if (accumulate) {                                   // uniform; one 32-gene slice at a time (16 loads in flight, not 128)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                float d[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) d[q] = mp[min((q & 3) + 8 * (q >> 2) + 4 * half, max(rows_here, 1) - 1) * rs + t * 32];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                    if (i < rows_here) mp[i * rs + t * 32] = d[q] + acc[t][q];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
+                    if (i < rows_here) mp[i * rs + t * 32] = acc[t][q];
+                }
+        }
     }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int i = (q & 3) + 8 * (q >> 2) + 4 * half;
-            if (i < rows_here) mp[i * rs + t * 32] = acc[t][q];
-        }
 }
 
 // wide designs, forward only (loss_gene_eval reads it): Mbuf = Xc . Wc_loc, tiled like the state arrays

@@ -1,12 +1,15 @@
 // Wall-clock rate of v_mfma_f32_32x32x2_f32 over the WHOLE chip, bare (8 independent accumulator sets per wave, 2 waves per
-// SIMD, no memory traffic) and with one ds_read_b32 per MFMA -- the ceiling the panel kernels of DESIGN 4.4 are held against:
+// SIMD, no memory traffic), with one ds_read_b32 per MFMA, and with the barrier / LDS-write pattern of a stage -- the ceiling the panel kernels of DESIGN 4.4 are held against:
 //   hipcc --offload-arch=gfx950 -O3 profiles/micro/mfma_wall.hip -o /tmp/mfma_wall && /tmp/mfma_wall
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <bool LDS>
+// MODE 0: bare; 1: one ds_read_b32 per MFMA; 2: that + a workgroup barrier every 128 MFMAs per wave (a stage of
+// fused_prior_mean); 3: that + 20 LDS writes per thread before every barrier (the stage's tiles being stashed)
+template <int MODE>
 __global__ __launch_bounds__(512) void k(float *o, int n, float a, float b) {
+    constexpr bool LDS = MODE >= 1;
     __shared__ float sh[64 * 288];
     for (int i = threadIdx.x; i < 64 * 288; i += 512) sh[i] = b;
     __syncthreads();
@@ -16,6 +19,11 @@ __global__ __launch_bounds__(512) void k(float *o, int n, float a, float b) {
     for (int i = 0; i < n; ++i) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) D[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, LDS ? bl[((i & 7) * 8 + c) * 288] : b, D[c], 0, 0, 0);
+        if (MODE >= 2 && (i & 15) == 15) {
+            if (MODE >= 3)
+                for (int j = 0; j < 20; ++j) sh[(j * 512 + threadIdx.x) % (64 * 288)] = b + D[0][0] * 0.0f;
+            __syncthreads();
+        }
     }
     float s = 0;
     for (int c = 0; c < 8; ++c) for (int q = 0; q < 16; ++q) s += D[c][q];
@@ -27,21 +35,23 @@ int main() {
     hipMalloc(&o, 4096 * 512 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int lds = 0; lds < 2; ++lds)
-        for (int blocks : {256, 512, 2048}) {
-            for (int n : {2000, 8000, 32000}) {         // ~0.5 ms .. ~7 ms per launch at 256 blocks
+    for (int lds = 0; lds < 4; ++lds)
+        for (int blocks : {256, 2048}) {
+            for (int n : {8000, 32000}) {               // ~3.5 ms .. ~14 ms per launch at 256 blocks
                 float best = 1e30f, last = 0;
                 for (int rep = 0; rep < 4; ++rep) {
                     hipEventRecord(e0);
-                    if (lds) hipLaunchKernelGGL(k<true>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
-                    else hipLaunchKernelGGL(k<false>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    if (lds == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    else if (lds == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    else if (lds == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
+                    else hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(512), 0, 0, o, n, 1.0f, 0.5f);
                     hipEventRecord(e1);
                     hipEventSynchronize(e1);
                     hipEventElapsedTime(&last, e0, e1);
                     if (last < best) best = last;
                 }
                 const double flop = 2.0 * 32 * 32 * 2 * 8.0 * n * 8 /*waves*/ * blocks;
-                printf("{\"lds_operand\": %d, \"blocks\": %d, \"mfma_per_wave\": %d, \"ms_best\": %.3f, \"ms_last\": %.3f, \"TFLOPs\": %.1f}\n",
+                printf("{\"mode\": %d, \"blocks\": %d, \"mfma_per_wave\": %d, \"ms_best\": %.3f, \"ms_last\": %.3f, \"TFLOPs\": %.1f}\n",
                        lds, blocks, 8 * n, best, last, flop / (best * 1e-3) / 1e12);
             }
         }

@@ -48,6 +48,24 @@ def test_two_ranks_give_one_complete_line(lib):
     assert "holds" in d["psi_delta_vs_cpu_ref"]["rule"]
 
 
+def test_eight_ranks_on_one_gpu_give_one_complete_line(lib):
+    """The world the driver's scaling run ends at (BASELINE configs[3]: eight gene shards), on ONE device over gloo: the
+    launcher, the eight shards of configs[1] (5 000 genes -> 8 x 628 / 604), barrier + maximum over ranks, the gather of
+    every rank's per-gene vectors in rank order, rank 0's bit-for-bit re-fit of a gene quad of each of the seven other shards."""
+    args = ["--config", "c2", "--steps", "5", "--warmup", "2", "--no-pmc", "--no-e2e", "--no-f32-leg", "--no-cpu-baseline", "--no-psi-check"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + args,
+                       env=_env(BRIE_BENCH_SINGLE_DEVICE="1"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    d = _line(p)
+    per = d["roofline"]["per_gpu"]
+    assert d["n_gpus"] == 8 and [g["rank"] for g in per] == list(range(8)) and sum(g["genes"] for g in per) == d["config"]["Ng"] == 5000
+    assert all(g["genes"] > 0 and g["genes"] % 4 == 0 for g in per)
+    ga = d["allgather"]
+    assert ga["backend"] == "gloo" and ga["recomputed_on_rank0"]["bit_identical"] is True
+    starts = [sum(g["genes"] for g in per[:k]) for k in range(1, 8)]
+    assert ga["recomputed_on_rank0"]["first_gene_of_quads"] == starts and len(ga["ms_per_step_per_rank"]) == 8
+    assert d["ms_per_step"] == pytest.approx(max(ga["ms_per_step_per_rank"]), rel=1e-6)       # MAX over ranks
+
+
 def test_one_rank_on_rccl_runs_the_gather_through_both_communicators(lib):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

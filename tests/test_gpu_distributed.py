@@ -83,7 +83,7 @@ FIT = dict(min_iter=120, max_iter=120, n_loss_gene=5, verbose=False, seed=3)
 FNC, FNG, FKC = 60, 44, 2
 
 
-def _fit_worker(rank, world, port, out_dir):
+def _fit_worker(rank, world, port, out_dir, ng=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -91,7 +91,7 @@ def _fit_worker(rank, world, port, out_dir):
     from brie_amd.sharding import GeneComm
     from oracle.synth import make_problem
     from tests.fakes import FakeAnnData
-    P = make_problem(FNC, FNG, Kc=FKC, L=3, seed=21)
+    P = make_problem(FNC, ng or FNG, Kc=FKC, L=3, seed=21)
     ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1], 'ambiguous': P["counts"][2]},
                      effLen=P["effLen"])
     res = brie_amd.fitBRIE(ad, Xc=P["Xc"], LRT_index=[1], comm=GeneComm(), **FIT)
@@ -171,3 +171,55 @@ def test_coupled_sharded_fitBRIE_with_emulate_batches_stops_like_the_single_proc
     for key in ("sigma", "gene_coeff", "loss_gene", "cell_coeff"):
         np.testing.assert_array_equal(r[0][key], r[1][key])                       # gathered / replicated: same on both ranks
         np.testing.assert_allclose(r[0][key], getattr(ref, key), rtol=2e-3, atol=2e-3, err_msg=key)
+
+
+# ---- the target world of EIGHT ranks on one device (round 5) --------------------------------------------------
+def test_coupled_gene_shards_world8_match_single_fit(lib, tmp_path):
+    """The per-step exchange of a gene-sharded COUPLED fit with eight ranks (gene features in an LDS tile, per-cell intercepts):
+    eight shards of 68 / 44 genes on cuda:0, the per-cell statistics all-reduced over gloo every step -- against the unsharded
+    fit.  (520 genes over 8 ranks: 7 x 68 + 44.)"""
+    from tests import util
+    KG = 6
+    mp.spawn(_worker, args=(8, _free_port(), str(tmp_path), KG), nprocs=8, join=True)
+    P = _problem(KG)
+    full = util.device_shard(P, NC, NG, KC, 61, Kg=KG, mode="cell")
+    tr = full.step(STEPS, 0.01, 1)
+    ref = util.device_state(full)
+    r = [np.load(tmp_path / ("rank%d.npz" % k)) for k in range(8)]
+    assert [tuple(q["g"]) for q in r] == [(68 * k, min(68 * (k + 1), NG)) for k in range(8)]
+    np.testing.assert_allclose(r[0]["trace"], tr, rtol=1e-5)
+    for q in r[1:]:
+        np.testing.assert_array_equal(r[0]["trace"], q["trace"])
+        for key in ("Wg_loc", "intercept", "sigma_log"):          # replicated per-cell parameters: identical on every rank
+            np.testing.assert_array_equal(r[0][key], q[key])
+    for key in ("Wg_loc", "intercept", "sigma_log"):
+        np.testing.assert_allclose(r[0][key], ref[key], atol=2e-5)
+    for key in ("Z_loc", "Z_std_log", "Wc_loc"):                  # gene-sharded state, in rank order
+        got = np.concatenate([q[key] for q in r], axis=1)
+        d = np.abs(got - ref[key])
+        assert np.percentile(d, 99.9) < 2e-5 and d.max() < 1e-3, key
+
+
+def test_fitBRIE_gene_sharded_world8_real_engine(lib, tmp_path):
+    """fitBRIE with the HIP engine over eight ranks on cuda:0 (120 genes: 7 x 16 + 8; LRT, effLen): every per-gene result
+    equals the single-process fit bit for bit, the gathered layer on rank 0 is in rank order."""
+    import brie_amd
+    from oracle.synth import make_problem
+    from tests.fakes import FakeAnnData
+    ng = 120
+    mp.spawn(_fit_worker, args=(8, _free_port(), str(tmp_path), ng), nprocs=8, join=True)
+    P = make_problem(FNC, ng, Kc=FKC, L=3, seed=21)
+    ad = FakeAnnData({'isoform1': P["counts"][0], 'isoform2': P["counts"][1], 'ambiguous': P["counts"][2]},
+                     effLen=P["effLen"])
+    ref = brie_amd.fitBRIE(ad, Xc=P["Xc"], LRT_index=[1], **FIT)
+    r = [np.load(tmp_path / ("fit%d.npz" % k)) for k in range(8)]
+    bounds = [tuple(int(x) for x in q["gene_range"]) for q in r]
+    assert bounds == [(16 * k, min(16 * (k + 1), ng)) for k in range(8)]
+    assert all(bounds[k][1] == bounds[k + 1][0] for k in range(7))
+    for key in ("sigma", "intercept", "cell_coeff", "loss_gene", "ELBO_gain", "pval"):
+        for q in r[1:]:
+            np.testing.assert_array_equal(r[0][key], q[key])
+        np.testing.assert_array_equal(r[0][key], getattr(ref, key), err_msg=key)
+    np.testing.assert_allclose(r[0]["losses"], ref.losses, rtol=1e-6)
+    np.testing.assert_array_equal(r[0]["Psi_full"], ref.Psi)
+    np.testing.assert_array_equal(np.concatenate([q["Psi_shard"] for q in r], axis=1), ref.Psi)

@@ -93,6 +93,11 @@ CASES = {
                          desc="configs[2] shape, sixth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
     "mid_cli_64_s6": dict(Nc=20000, Ng=64, Kc=2, L=3, theta=2.0, min_iter=5000, MC=3, data_seed=777001, seed=67,
                           desc="20k cells x 64 genes, effLen, Kc=2 (no config's shape), sixth seeds, 4998 steps, MC_size 3"),
+    # round 5, addendum 2: the API schedule (996 steps, MC_size 1) under the ensemble rule as well -- two held-out cases
+    "c2_api_64_s7": dict(Nc=10000, Ng=64, Kc=1, L=3, theta=1.5, min_iter=1000, MC=1, data_seed=888002, seed=71,
+                         desc="configs[1] shape, seventh seeds: 64 genes over all cells, 996 steps, MC_size 1"),
+    "c3_api_64_s7": dict(Nc=50000, Ng=64, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1, data_seed=888002, seed=71,
+                         desc="configs[2] shape, seventh seeds: 64 genes over all cells, 996 steps, MC_size 1"),
 }
 HELD_OUT_2 = ("c1_cli_s4", "c2_api_512_s4", "c2_cli_128_s4", "mid_api_256_s4", "mid_cli_96_s4", "c3_api_256_s4", "c3_cli_64_s4")
 HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2", "mid_api_256_s3", "mid_cli_96_s3")

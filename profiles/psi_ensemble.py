@@ -53,9 +53,15 @@ CASES = {"c2_cli_128": dict(of="c2_cli_128"), "c3_cli_128": dict(of="c3_cli_128"
 # addendum 1 (registered after the four cases above had been judged, before anything ran on these): three more held-out cases
 ADDENDUM_1 = {"c2_cli_64_s6": dict(of="c2_cli_64_s6", held_out=True), "c3_cli_64_s6": dict(of="c3_cli_64_s6", held_out=True),
               "mid_cli_64_s6": dict(of="mid_cli_64_s6", held_out=True)}
+# addendum 2 (after addenda and cases above had been judged): the API schedule (BRIE2.fit defaults: 996 steps, MC_size 1) under
+# the same rule -- round 4's three gene-sample cases (first 64 genes; o32 and t6 sliced from round 4's caches) and two held-out
+ADDENDUM_2 = {"c2_api_512": dict(of="c2_api_512"), "c3_api_512": dict(of="c3_api_512"), "c3_api_512_s2": dict(of="c3_api_512_s2"),
+              "c2_api_64_s7": dict(of="c2_api_64_s7", held_out=True), "c3_api_64_s7": dict(of="c3_api_64_s7", held_out=True)}
 REGISTERED_FIRST = tuple(CASES)
 CASES.update(ADDENDUM_1)
+CASES.update(ADDENDUM_2)
 OLD_DRAWS = {"t4": "_t4", "t6": "", "t8": "_t8"}           # suffixes of profiles/_psi_cache/<case>_float32b<suffix>.npz
+SLICED = ("c2_cli_128", "c3_cli_128", "c2_api_512", "c3_api_512", "c3_api_512_s2")      # cases with round-4 caches of more genes
 
 
 def sha256(path):
@@ -83,7 +89,7 @@ def path_of(case, run):
 
 def _slice_old(case, run):
     """Round 4's caches hold 128 genes of c2_cli_128 / c3_cli_128: o32 and the draws at 4 / 6 / 8 threads."""
-    if CASES[case]["of"] != case or case.endswith("_s5"):
+    if case not in SLICED:
         return None
     if run == "o32":
         src = os.path.join(pd.CACHE, "%s_float32.npz" % case)
@@ -182,6 +188,14 @@ def register():
     if "registered_addendum_1" in man and man["registered_addendum_1"] != json.loads(json.dumps(add)):
         raise SystemExit("addendum 1 is already registered with other contents: not overwritten")
     man["registered_addendum_1"] = add
+    add2 = {"cases": {k: dict({kk: vv for kk, vv in pd.CASES[v["of"]].items()}, model_seed=pd.model_seed(v["of"]),
+                              held_out=bool(v.get("held_out"))) for k, v in ADDENDUM_2.items()},
+            "note": "the API schedule (996 steps, MC_size 1) under the same rule, constants and members; registered after call r5zz; "
+                    "c2_api_512 / c3_api_512 / c3_api_512_s2 are round 4's gene-sample cases (HIP has run on them many times: in "
+                    "sample), the *_s7 cases are held out"}
+    if "registered_addendum_2" in man and man["registered_addendum_2"] != json.loads(json.dumps(add2)):
+        raise SystemExit("addendum 2 is already registered with other contents: not overwritten")
+    man["registered_addendum_2"] = add2
     with open(MANIFEST, "w") as fh:
         json.dump(man, fh, indent=1, sort_keys=True)
     print("registered", MANIFEST)

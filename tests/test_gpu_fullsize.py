@@ -449,6 +449,44 @@ def test_psi_null_rule_on_gene_samples_of_the_full_size_configs_after_the_full_d
     print("%s: %d genes (%s):" % (case, n_use, "full oracle cache" if n_use == c["Ng"] else "committed fixture"), rep)
 
 
+def _judge_by_the_ensemble(case):
+    """HIP through the case's whole staged schedule on its first 64 genes x all cells, held against the committed ensemble
+    fixture by tests/util.py::psi_ensemble_rule; the verdict is written next to the bench files for profiles/r5/."""
+    import json
+    import os
+    import sys
+    from brie_amd import _capi
+    from tests import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "profiles"))
+    import psi_delta as pd
+    import psi_ensemble as pe
+    fixture = os.path.join(root, "tests", "golden", "psi_ens_%s_first%d.npz" % (case, pe.GENES))
+    if case not in pe.REGISTERED_FIRST and case not in json.load(open(pe.MANIFEST)).get("frozen", {}):
+        pytest.skip("%s is registered (addendum) but its members are not computed and frozen yet" % case)
+    if not os.path.exists(fixture):
+        pytest.fail("%s is missing: python profiles/psi_ensemble.py --run --freeze --cases %s   (CPU, hours)"
+                    % (os.path.relpath(fixture, root), case))
+    man = json.load(open(pe.MANIFEST))
+    assert man["frozen"][case]["fixture_sha256"] == pe.sha256(fixture), "fixture differs from the frozen manifest"
+    psi_o32, par_o32, members = pe.load_fixture(case)
+    assert sorted(members) == sorted(pe.MEMBERS)
+    P, c, n = pe.problem(case)
+    sh = util.device_shard(P, c["Nc"], n, c["Kc"], pd.model_seed(pe.CASES[case]["of"]))
+    for k, lr in util.staged_schedule(c["min_iter"]):
+        sh.reset_optimizer()
+        sh.step(k, lr, c["MC"], trace=False)
+    h = util.gene_summaries(sh.read(_capi.PSI), psi_o32, util.run_params(sh), par_o32)
+    sh.close()
+    rep = util.psi_ensemble_rule(h, members, "%s, %d genes x %d cells, %d steps, MC_size %d" % (case, n, c["Nc"], 6 * int(c["min_iter"] / 6), c["MC"]), check=False)
+    print("%s:" % case, json.dumps(rep))
+    out = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out):                                   # the verdict as it fell, for profiles/r5/
+        with open(os.path.join(out, "psi_ensemble_%s.json" % case), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    assert rep["holds"], (case, rep.get("violated"), rep["leave_one_out"])
+
+
 @pytest.mark.parametrize("case", ["c2_cli_128", "c3_cli_128", "c2_cli_64_s5", "c3_cli_64_s5",
                                   "c2_cli_64_s6", "c3_cli_64_s6", "mid_cli_64_s6"])
 def test_psi_ensemble_rule_after_the_brie_quant_default_schedule(lib, case):
@@ -464,36 +502,12 @@ def test_psi_ensemble_rule_after_the_brie_quant_default_schedule(lib, case):
     the ensemble's own leave-one-out record (how often a member, which IS the reference's arithmetic, fails the same rule).
     What the test reads is in git: tests/golden/psi_ens_<case>_first64.npz (o32 Psi + parameters, every member's per-gene
     summaries; sha256 in the manifest's "frozen" section).  Without it the test FAILS with the command that makes it."""
-    import json
-    import os
-    import sys
-    from brie_amd import _capi
-    from tests import util
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "profiles"))
-    import psi_delta as pd
-    import psi_ensemble as pe
-    fixture = os.path.join(root, "tests", "golden", "psi_ens_%s_first%d.npz" % (case, pe.GENES))
-    if case in pe.ADDENDUM_1 and case not in json.load(open(pe.MANIFEST)).get("frozen", {}):
-        pytest.skip("%s is registered (addendum 1) but its members are not computed and frozen yet" % case)
-    if not os.path.exists(fixture):
-        pytest.fail("%s is missing: python profiles/psi_ensemble.py --run --freeze --cases %s   (CPU, hours)"
-                    % (os.path.relpath(fixture, root), case))
-    man = json.load(open(pe.MANIFEST))
-    assert man["frozen"][case]["fixture_sha256"] == pe.sha256(fixture), "fixture differs from the frozen manifest"
-    psi_o32, par_o32, members = pe.load_fixture(case)
-    assert sorted(members) == sorted(pe.MEMBERS)
-    P, c, n = pe.problem(case)
-    sh = util.device_shard(P, c["Nc"], n, c["Kc"], pd.model_seed(pe.CASES[case]["of"]))
-    for k, lr in util.staged_schedule(c["min_iter"]):
-        sh.reset_optimizer()
-        sh.step(k, lr, c["MC"], trace=False)
-    h = util.gene_summaries(sh.read(_capi.PSI), psi_o32, util.run_params(sh), par_o32)
-    sh.close()
-    rep = util.psi_ensemble_rule(h, members, "%s, %d genes x %d cells, 4998 steps, MC_size 3" % (case, n, c["Nc"]), check=False)
-    print("%s:" % case, json.dumps(rep))
-    out = os.path.join(root, "gpurun_out")
-    if os.path.isdir(out):                                   # the verdict as it fell, for profiles/r5/
-        with open(os.path.join(out, "psi_ensemble_%s.json" % case), "w") as fh:
-            json.dump(rep, fh, indent=1)
-    assert rep["holds"], (case, rep.get("violated"), rep["leave_one_out"])
+    _judge_by_the_ensemble(case)
+
+
+@pytest.mark.parametrize("case", ["c2_api_512", "c3_api_512", "c3_api_512_s2", "c2_api_64_s7", "c3_api_64_s7"])
+def test_psi_ensemble_rule_after_the_api_default_schedule(lib, case):
+    """The BRIE2.fit default schedule (6 x 166 Adam steps, MC_size 1; model_TFProb.py:234-241) under the SAME ensemble rule,
+    members and constants (manifest: registered_addendum_2): round 4's three gene-sample cases -- which
+    test_psi_null_rule_on_gene_samples_... above still holds against round 4's single draw -- and two held-out sets of seeds."""
+    _judge_by_the_ensemble(case)

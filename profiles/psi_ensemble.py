@@ -228,13 +228,11 @@ def freeze(cases):
             files[m] = {"sha256": sha256(path_of(case, m)), "seconds": round(float(z["seconds"]), 1), "origin": str(z["origin"])}
         out = os.path.join(GOLDEN, "psi_ens_%s_first%d.npz" % (case, GENES))
         np.savez_compressed(out, **blob)
-        # the ensemble's own record under the rule (leave-one-out), HIP not involved
-        rep = util.psi_ensemble_rule(summ["t6"], {k: v for k, v in summ.items() if k != "t6"}, case, check=False)
+        # (+ the ensemble's own record under the rule: leave-one-out, HIP not involved)
         man["frozen"][case] = {"files": files, "fixture": os.path.basename(out), "fixture_sha256": sha256(out),
                                "leave_one_out_of_all_members": _loo(summ)}
         print("froze %s -> %s (%d KiB); leave-one-out failures: %s" % (case, out, os.path.getsize(out) >> 10,
                                                                         man["frozen"][case]["leave_one_out_of_all_members"]))
-        del rep
     with open(MANIFEST, "w") as fh:
         json.dump(man, fh, indent=1, sort_keys=True)
 

@@ -65,3 +65,28 @@ def test_what_the_gpu_parity_tests_read_is_in_git_not_in_a_cache():
         fx = os.path.join(ROOT, "tests", "golden", r["fixture"])
         assert os.path.exists(fx) and os.path.getsize(fx) < (32 << 20), (case, fx)
         assert "psi_null.py --null" in r["regenerate"] and all(len(f["sha256"]) == 64 for f in r["files"].values())
+
+
+def test_the_documents_cite_files_that_exist_and_profiles_stays_pruned():
+    """`profiles/` keeps what the documents cite (under 250 tracked files), and what they cite by an explicit
+    path is in the tree -- a pruned artefact must not leave a dangling citation behind (wildcard / brace patterns and the
+    documents of earlier rounds, whose header points at the git history, are not checked)."""
+    import re
+    import subprocess
+    missing = []
+    for doc in ("DESIGN.md", "README.md", "BASELINE.md", "SCALE.md", "INTEGRATION.md", os.path.join("docs", "evidence_r5.md"),
+                os.path.join("profiles", "README.md")):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in set(re.findall(r"profiles/[A-Za-z0-9_./{},*<>-]+", text)):
+            path = m.rstrip(".,);:")
+            if any(ch in path for ch in "{*<") or path.endswith("/"):
+                continue
+            if not os.path.exists(os.path.join(ROOT, path)):
+                missing.append((doc, path))
+    assert not missing, missing
+    try:
+        tracked = subprocess.run(["git", "ls-files", "profiles"], cwd=ROOT, capture_output=True, text=True, check=True).stdout.split()
+    except (OSError, subprocess.CalledProcessError):
+        return                                                     # not a git checkout (the GPU box's snapshot)
+    if tracked:
+        assert len(tracked) < 250, len(tracked)

@@ -98,6 +98,12 @@ CASES = {
                          desc="configs[1] shape, seventh seeds: 64 genes over all cells, 996 steps, MC_size 1"),
     "c3_api_64_s7": dict(Nc=50000, Ng=64, Kc=3, L=2, theta=1.5, min_iter=1000, MC=1, data_seed=888002, seed=71,
                          desc="configs[2] shape, seventh seeds: 64 genes over all cells, 996 steps, MC_size 1"),
+    # round 5, addendum 3: the two BASELINE shapes the ensemble had not seen -- configs[4] (DMG mode: 100k cells, 2 layers, 5
+    # covariates) and configs[0] (200 x 500, no covariate) -- at the brie-quant default schedule, eighth seeds, held out
+    "c5_cli_64_s8": dict(Nc=100000, Ng=64, Kc=5, L=2, theta=1.5, min_iter=5000, MC=3, data_seed=999003, seed=73,
+                         desc="configs[4] shape (100k cells, Kc=5, 2 layers), eighth seeds: 64 genes over all cells, 4998 steps, MC_size 3"),
+    "c1_kc0_cli_s8": dict(Nc=200, Ng=500, Kc=0, L=2, theta=3.0, min_iter=5000, MC=3, data_seed=999003, seed=73,
+                          desc="configs[0] shape (200 x 500, no covariate), eighth seeds, 4998 steps, MC_size 3"),
 }
 HELD_OUT_2 = ("c1_cli_s4", "c2_api_512_s4", "c2_cli_128_s4", "mid_api_256_s4", "mid_cli_96_s4", "c3_api_256_s4", "c3_cli_64_s4")
 HELD_OUT = ("c2_api_512_s2", "c3_api_512_s2", "c2_cli_128_s2", "c3_cli_128_s2", "mid_api_256_s3", "mid_cli_96_s3")

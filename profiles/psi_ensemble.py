@@ -57,9 +57,12 @@ ADDENDUM_1 = {"c2_cli_64_s6": dict(of="c2_cli_64_s6", held_out=True), "c3_cli_64
 # the same rule -- round 4's three gene-sample cases (first 64 genes; o32 and t6 sliced from round 4's caches) and two held-out
 ADDENDUM_2 = {"c2_api_512": dict(of="c2_api_512"), "c3_api_512": dict(of="c3_api_512"), "c3_api_512_s2": dict(of="c3_api_512_s2"),
               "c2_api_64_s7": dict(of="c2_api_64_s7", held_out=True), "c3_api_64_s7": dict(of="c3_api_64_s7", held_out=True)}
+# addendum 3 (after everything above had been judged): the two BASELINE shapes no case had -- configs[4] and configs[0] -- held out
+ADDENDUM_3 = {"c5_cli_64_s8": dict(of="c5_cli_64_s8", held_out=True), "c1_kc0_cli_s8": dict(of="c1_kc0_cli_s8", held_out=True)}
 REGISTERED_FIRST = tuple(CASES)
 CASES.update(ADDENDUM_1)
 CASES.update(ADDENDUM_2)
+CASES.update(ADDENDUM_3)
 OLD_DRAWS = {"t4": "_t4", "t6": "", "t8": "_t8"}           # suffixes of profiles/_psi_cache/<case>_float32b<suffix>.npz
 SLICED = ("c2_cli_128", "c3_cli_128", "c2_api_512", "c3_api_512", "c3_api_512_s2")      # cases with round-4 caches of more genes
 
@@ -141,7 +144,7 @@ def run_one(case, run, threads):
 def run_all(cases, runs, cores):
     """Every missing (case, run) as its own process, at most `cores` threads in flight."""
     jobs = [(c, r) for c in cases for r in runs if not os.path.exists(path_of(c, r))]
-    jobs.sort(key=lambda j: (not j[0].startswith("c3"), j[1] != "o32"))        # long ones first
+    jobs.sort(key=lambda j: (not j[0].startswith(("c5", "c3")), j[1] != "o32"))        # long ones first
     live = []
     while jobs or live:
         live = [(p, t) for p, t in live if p.poll() is None]
@@ -196,6 +199,14 @@ def register():
     if "registered_addendum_2" in man and man["registered_addendum_2"] != json.loads(json.dumps(add2)):
         raise SystemExit("addendum 2 is already registered with other contents: not overwritten")
     man["registered_addendum_2"] = add2
+    add3 = {"cases": {k: dict({kk: vv for kk, vv in pd.CASES[v["of"]].items()}, model_seed=pd.model_seed(v["of"]), held_out=True)
+                      for k, v in ADDENDUM_3.items()},
+            "note": "same rule, constants and members; registered after the twelve cases above had been judged (all hold) and before "
+                    "any run of either side on these two: the BASELINE shapes no case had (configs[4]: 100 000 cells, 2 layers, "
+                    "Kc = 5; configs[0]: 200 cells, Kc = 0), brie-quant default schedule, first 64 genes"}
+    if "registered_addendum_3" in man and man["registered_addendum_3"] != json.loads(json.dumps(add3)):
+        raise SystemExit("addendum 3 is already registered with other contents: not overwritten")
+    man["registered_addendum_3"] = add3
     with open(MANIFEST, "w") as fh:
         json.dump(man, fh, indent=1, sort_keys=True)
     print("registered", MANIFEST)

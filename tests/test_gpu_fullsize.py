@@ -488,7 +488,7 @@ def _judge_by_the_ensemble(case):
 
 
 @pytest.mark.parametrize("case", ["c2_cli_128", "c3_cli_128", "c2_cli_64_s5", "c3_cli_64_s5",
-                                  "c2_cli_64_s6", "c3_cli_64_s6", "mid_cli_64_s6"])
+                                  "c2_cli_64_s6", "c3_cli_64_s6", "mid_cli_64_s6", "c5_cli_64_s8", "c1_kc0_cli_s8"])
 def test_psi_ensemble_rule_after_the_brie_quant_default_schedule(lib, case):
     """The brie-quant default schedule (bin/quant.py:173-177: 4 998 Adam steps = 6 x 833 with a fresh optimiser per stage,
     MC_size 3) under the driver's eyes (VERDICT r4 items 1 and 3 of "missing"): the first 64 genes of the configs[1] /
@@ -497,7 +497,9 @@ def test_psi_ensemble_rule_after_the_brie_quant_default_schedule(lib, case):
     algorithm (o32b with the cells cut into 2 / 4 / 6 / 8 / 12 parts, one member with the exact noise stream).  Members,
     cases, seeds and constants were committed (tests/golden/psi_ensemble_manifest.json, "registered") before the members were
     computed; the *_s5 cases are held out: chosen before either side had run on them; the *_s6 cases (one of them a shape no
-    config has: 20 000 cells, effLen, Kc = 2) are a second held-out set, registered after the first four had been judged.  c2_cli_128 and c3_cli_128 are the two
+    config has: 20 000 cells, effLen, Kc = 2) are a second held-out set, registered after the first four had been judged; the
+    *_s8 cases (registered_addendum_3, after all the others) are the two BASELINE shapes no case had: configs[4] (100 000 cells,
+    Kc = 5) and configs[0] (200 cells, no covariate).  c2_cli_128 and c3_cli_128 are the two
     cases that failed round 4's single-draw rule on the final library.  The verdict stands as it falls: the report carries
     the ensemble's own leave-one-out record (how often a member, which IS the reference's arithmetic, fails the same rule).
     What the test reads is in git: tests/golden/psi_ens_<case>_first64.npz (o32 Psi + parameters, every member's per-gene

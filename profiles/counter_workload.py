@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--launches", type=int, default=4)
     ap.add_argument("--draws", type=int, default=500)
     ap.add_argument("--genes", type=int, default=0, help="use only the first N genes (shorter counter runs)")
+    ap.add_argument("--mc", type=int, default=1, help="MC_size of the step kernels (3 = the brie-quant default)")
     args = ap.parse_args()
     import torch
     import bench
@@ -53,17 +54,17 @@ def main():
     del layers
     torch.cuda.empty_cache()
     sh.init_state()
-    sh.step(3, 0.005, 1, trace=False)
+    sh.step(3, 0.005, args.mc, trace=False)
     sh.synchronize()
     t0 = time.perf_counter()
     if args.what == "loss_gene":
         for _ in range(args.launches):
             sh.loss_gene(args.draws)
     else:
-        sh.step(args.launches, 0.005, 1, trace=False)
+        sh.step(args.launches, 0.005, args.mc, trace=False)
     sh.synchronize()
     el = (time.perf_counter() - t0) / args.launches
-    print(json.dumps({"what": args.what, "shape": [Nc, ng], "Kc": Kc, "Kg": Kg, "launches": args.launches,
+    print(json.dumps({"what": args.what, "shape": [Nc, ng], "Kc": Kc, "Kg": Kg, "MC_size": args.mc, "launches": args.launches,
                       "draws": args.draws if args.what == "loss_gene" else None, "s_per_launch": el,
                       "algorithmic_bytes_per_step": sh.step_algorithmic_bytes(), "storage_bytes_per_step": sh.step_storage_bytes(),
                       "count_storage": sh.count_storage}))

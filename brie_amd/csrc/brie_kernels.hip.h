@@ -101,8 +101,11 @@ __device__ __forceinline__ float f_log(float x) {
 // __logf does for a normal input -- v_log_f32 times ln2 as an extended-precision product -- and leaves away the
 // denormal-input rescue (compare, two selects, ldexp, subtract) and the infinity check (compare, select) it wraps around
 // that: 7 VALU instructions per logarithm that can never fire here.  Bit-identical to __logf for every positive normal
-// fp32 value (all 2.13e9 checked: profiles/micro/fast_log.hip).  The HBM-bound step kernels keep __logf: there the
-// instructions are free and the longer dependent chain costs registers (MC_size 3 fell from 2 waves / SIMD to 1).
+// fp32 value (all 2.13e9 checked: profiles/micro/fast_log.hip).  The HBM-bound step kernels (MC_size 1, run-time MC_size)
+// keep __logf: there the instructions are free.  The MC_size 3 step instantiations take the lean form since round 5 (with
+// the small-argument branch of f_log1p kept: same bits) -- at first try it had cost them their second wave per SIMD (the
+// two-sided f_log1p compiled to branches, a few registers over 256); written as one select and with two waves per SIMD
+// asked for in __launch_bounds__ it does not.
 template <bool LEAN>
 __device__ __forceinline__ float f_log_sel(float x) {
     if constexpr (LEAN) {
@@ -114,7 +117,7 @@ __device__ __forceinline__ float f_log_sel(float x) {
     }
     return f_log(x);
 }
-template <bool LEAN = false>
+template <bool LEAN = false, bool LEANLOG = LEAN>
 __device__ __forceinline__ float f_log1p(float x) {
     // x = exp(-|z|) in (0,1]: log(1+x) loses nothing above ~1e-4; below, x - x*x/2.
     // LEAN (the forward-only passes): log(1 + x) throughout.  Rounding 1 + x costs at most 6e-8 ABSOLUTE in a term that
@@ -123,7 +126,13 @@ __device__ __forceinline__ float f_log1p(float x) {
     // compiler pair their arithmetic into v_pk_* instructions (the branchy form compiled to 4 x s_and_saveexec ... s_or
     // per draw and no packed math at all).
     if constexpr (LEAN) return f_log_sel<true>(1.0f + x);
-    return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<LEAN>(1.0f + x);
+    // LEANLOG alone (the VALU-bound step instantiations): the same two-sided form, the same bits -- only the logarithm's
+    // never-firing rescue code is left away (f_log_sel)
+    if constexpr (LEANLOG) {             // both sides formed, then ONE select: the lane's four elements stay one basic block
+        const float lg = f_log_sel<true>(1.0f + x), sm = x * (1.0f - 0.5f * x);
+        return x < 1e-3f ? sm : lg;
+    }
+    return x < 1e-3f ? x * (1.0f - 0.5f * x) : f_log_sel<false>(1.0f + x);
 }
 __device__ __forceinline__ float f_rcp(float x) {
     return __builtin_amdgcn_rcpf(x);
@@ -163,7 +172,7 @@ enum : int { kLik2 = 0,      // 2 categories, no effLen   (model_TFProb.py:162-1
              kLikEff3 = 2 }; // effLen, 3 count layers    (model_TFProb.py:184-185)
 
 // Per-sample log-likelihood l(z) and dl/dz for one element.
-template <int MODE, bool LEAN = false>
+template <int MODE, bool LEAN = false, bool LEANLOG = LEAN>
 __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
                                        float L0, float L4, float L5,
                                        float lL0, float lL4, float lL5,
@@ -174,7 +183,7 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
     const float big = inv, small = e * inv;       // sigmoid(|z|), sigmoid(-|z|)
     const float sp = z >= 0.0f ? big : small;     // sigmoid(z)
     const float sn = z >= 0.0f ? small : big;     // sigmoid(-z)
-    const float l1p = f_log1p<LEAN>(e);
+    const float l1p = f_log1p<LEAN, LEANLOG>(e);
     const float ls1 = fminf(z, 0.0f) - l1p;       // log_sigmoid(z)
     const float ls2 = fminf(-z, 0.0f) - l1p;      // log_sigmoid(-z)
     if (MODE == kLik2) {
@@ -182,7 +191,7 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
         g = c1 - (c1 + c2) * sp;
     } else {
         const float D = sp * L0 + sn * L4 + L5;
-        const float lD = f_log_sel<LEAN>(D);
+        const float lD = f_log_sel<LEANLOG>(D);
         const float iD = f_rcp(D);
         const float phi1 = sp * L0 * iD, phi2 = sn * L4 * iD;
         float N = c1 + c2;
@@ -526,8 +535,14 @@ __device__ __forceinline__ double block_sum_f64(double *sh, double t) {
 // from the PRIOR N(m, sigma), the samples are combined with an online log-mean-exp, q = sum_k w_k dl/dz_k takes the
 // place of the residual r in every prior-parameter statistic (and -q_eps sigma that of the sigma statistic), there is
 // no KL term and the posterior arrays are neither read nor written.  (Uncoupled Kc <= 8 models use margin_step.)
+#ifndef BRIE_LEANLOG_COND
+#define BRIE_LEANLOG_COND (MC == 3)
+#endif
+#ifndef BRIE_TWO_WAVES_COND
+#define BRIE_TWO_WAVES_COND (MC == 3 && KC <= 7)
+#endif
 template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
-__global__ __launch_bounds__(kBlock, 1) void elbo_adam_step(
+__global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
@@ -539,6 +554,15 @@ __global__ __launch_bounds__(kBlock, 1) void elbo_adam_step(
     extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
     constexpr int S = KC + 4;
     constexpr int KCX = KC > 0 ? KC : 1;
+    // Three samples per step (the brie-quant default): with the effLen likelihood the one VALU-bound step (pipes busy 0.90,
+    // profiles/r5/r5_counters_c2_step_mc3.txt).  Its logarithms -- 2 per element and sample, 1 without effLen -- go without
+    // __logf's rescue code for denormal / infinite inputs that cannot occur here (f_log_sel): 18 % fewer VALU instructions, the
+    // same state bits (profiles/r5/r5_lib_ab_leanlog.json: 15 shapes; in two of them the loss TRACE moves by one ulp of its
+    // fp32 total -- the likelihood VALUE contracts differently, its derivative does not).  Two waves per SIMD are asked for by
+    // name (BRIE_TWO_WAVES_COND in __launch_bounds__): the allocator lands within a few registers of 256 either side, and up to
+    // Kc = 7 the 0 - 108 bytes of scratch that costs are cheaper than a lone wave per SIMD (Kc = 4: 0.62 -> 0.53 ms, Kc = 7:
+    // 0.69 -> 0.59 at 10k x 5k; at Kc = 8, 148 bytes, 0.65 -> 0.88: left to the allocator, 0.62).
+    constexpr bool kLeanLog = BRIE_LEANLOG_COND;
     // GW: the cross-wave fold reuses the (dynamic) Xg tile once the row loop is over -- keeps 2 workgroups per CU
     __shared__ float red_static[GW ? 1 : (kWavesPerBlock - 1) * S * kGenesPerBlock];
     __shared__ float wlds[WIDE ? kWideKcMax * kGenesPerBlock : 1];      // W tile of this gene block
@@ -749,8 +773,8 @@ __global__ __launch_bounds__(kBlock, 1) void elbo_adam_step(
                     for (int v = 0; v < kVec; ++v) {
                         const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
                         float l, g;
-                        loglik<MODE>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
-                                     lL0[v], lL4[v], lL5[v], l, g);
+                        loglik<MODE, false, kLeanLog>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
+                                                      lL0[v], lL4[v], lL5[v], l, g);
                         ll[v] += l;
                         gbar[v] += g;
                         gse[v] = fmaf(g, e[v], gse[v]);

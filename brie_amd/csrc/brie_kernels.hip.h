@@ -96,14 +96,20 @@ __device__ __forceinline__ float f_exp(float x) {
 __device__ __forceinline__ float f_log(float x) {
     return __logf(x);
 }
-// f_log for the VALU-bound forward passes (loss_gene_eval, margin_step).  Every logarithm on this path takes a normal
-// number >= ~1 (1 + exp(-|z|), a sum of effective lengths, a sum of exp(l - max) >= 1), so the fast build spells out what
-// __logf does for a normal input -- v_log_f32 times ln2 as an extended-precision product -- and leaves away the
-// denormal-input rescue (compare, two selects, ldexp, subtract) and the infinity check (compare, select) it wraps around
-// that: 7 VALU instructions per logarithm that can never fire here.  Bit-identical to __logf for every positive normal
-// fp32 value (all 2.13e9 checked: profiles/micro/fast_log.hip).  The HBM-bound step kernels (MC_size 1, run-time MC_size)
-// keep __logf: there the instructions are free.  The MC_size 3 step instantiations take the lean form since round 5 (with
-// the small-argument branch of f_log1p kept: same bits) -- at first try it had cost them their second wave per SIMD (the
+// f_log for the VALU-bound passes (loss_gene_eval, margin_step; the MC_size 3 step instantiations since round 5).  Every
+// logarithm on this path takes a normal number >= ~1 (1 + exp(-|z|), a sum of effective lengths, a sum of exp(l - max) >= 1),
+// so the lean form spells out what the compiler's lowering of __logf does for a normal input -- v_log_f32 times ln2 as an
+// extended-precision product, r = y c, r + fma(y, cc, fma(y, c, -r)) -- and leaves away the denormal-input rescue (compare,
+// two selects, ldexp, subtract) and the infinity check (compare, select) it wraps around that: 7 VALU instructions per
+// logarithm that can never fire here.  Within ONE ulp of __logf, not bit-identical to it: this compiler contracts the
+// lowering's last add into fma(y, c, .), one rounding where the spelled-out form keeps two, and the last bit differs for
+// 32 % of the positive normal inputs (profiles/micro/fast_log.hip, re-run in round 5: 690 802 480 of 2 130 706 432; rounds 3 - 4
+// claimed identity here, wrongly for this toolchain).  In the ELBO step a logarithm enters the log-likelihood VALUE only
+// -- the loss trace -- never a derivative (loglik: g is made of sigmoids and the phi's): the state trajectory cannot
+// change, and does not (profiles/r5/r5_lib_ab_leanlog.json).  With target="marginLik" the values weight the samples:
+// there the forward kernels have used this form since round 3, under the oracle tolerances of the tests.  The HBM-bound
+// step kernels (MC_size 1, run-time MC_size) keep __logf: there the instructions are free.  In the MC_size 3 instantiations
+// the small-argument branch of f_log1p is kept; at first try the lean form had cost them their second wave per SIMD (the
 // two-sided f_log1p compiled to branches, a few registers over 256); written as one select and with two waves per SIMD
 // asked for in __launch_bounds__ it does not.
 template <bool LEAN>
@@ -126,8 +132,8 @@ __device__ __forceinline__ float f_log1p(float x) {
     // compiler pair their arithmetic into v_pk_* instructions (the branchy form compiled to 4 x s_and_saveexec ... s_or
     // per draw and no packed math at all).
     if constexpr (LEAN) return f_log_sel<true>(1.0f + x);
-    // LEANLOG alone (the VALU-bound step instantiations): the same two-sided form, the same bits -- only the logarithm's
-    // never-firing rescue code is left away (f_log_sel)
+    // LEANLOG alone (the VALU-bound step instantiations): the same two-sided form -- only the logarithm's never-firing
+    // rescue code is left away (f_log_sel: within one ulp of __logf)
     if constexpr (LEANLOG) {             // both sides formed, then ONE select: the lane's four elements stay one basic block
         const float lg = f_log_sel<true>(1.0f + x), sm = x * (1.0f - 0.5f * x);
         return x < 1e-3f ? sm : lg;
@@ -556,9 +562,10 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
     constexpr int KCX = KC > 0 ? KC : 1;
     // Three samples per step (the brie-quant default): with the effLen likelihood the one VALU-bound step (pipes busy 0.90,
     // profiles/r5/r5_counters_c2_step_mc3.txt).  Its logarithms -- 2 per element and sample, 1 without effLen -- go without
-    // __logf's rescue code for denormal / infinite inputs that cannot occur here (f_log_sel): 18 % fewer VALU instructions, the
-    // same state bits (profiles/r5/r5_lib_ab_leanlog.json: 15 shapes; in two of them the loss TRACE moves by one ulp of its
-    // fp32 total -- the likelihood VALUE contracts differently, its derivative does not).  Two waves per SIMD are asked for by
+    // __logf's rescue code for denormal / infinite inputs that cannot occur here (f_log_sel): 18 % fewer VALU instructions.  A
+    // logarithm enters the likelihood VALUE only, never its derivative, and the lean form is within one ulp of __logf: the
+    // state bits cannot change and do not (profiles/r5/r5_lib_ab_leanlog.json: 15 shapes; in two of them the loss TRACE
+    // moves by one ulp of its fp32 total).  Two waves per SIMD are asked for by
     // name (BRIE_TWO_WAVES_COND in __launch_bounds__): the allocator lands within a few registers of 256 either side, and up to
     // Kc = 7 the 0 - 108 bytes of scratch that costs are cheaper than a lone wave per SIMD (Kc = 4: 0.62 -> 0.53 ms, Kc = 7:
     // 0.69 -> 0.59 at 10k x 5k; at Kc = 8, 148 bytes, 0.65 -> 0.88: left to the allocator, 0.62).

@@ -132,6 +132,7 @@ def load_library(path=None):
     lib.brie_host_register.argtypes = [vp, i64]
     lib.brie_host_unregister.argtypes = [vp]
     lib.brie_probe_layouts.argtypes = [i32, i64, i64, i64, i32, vp, i32, vp]
+    lib.brie_probe_vmm.argtypes = [i32, i64, i64, i32, i32, vp, vp, i32, vp, vp]
     lib.brie_placement_probe.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_placement_tune.argtypes = [vp, i32, ctypes.c_double]
     lib.brie_placement_status.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, i32]
@@ -282,6 +283,20 @@ def probe_layouts(Nc, Ng, slab_bytes, offsets, iters=3, device=0):
     _check(lib, lib.brie_probe_layouts(int(device), int(Nc), int(Ng), int(slab_bytes), off.shape[0], off.ctypes.data, int(iters),
                                        out.ctypes.data))
     return out
+
+
+def probe_vmm(Nc, Ng, n_layers, chunk_bytes, order, iters=3, device=0):
+    """(GB/s, seconds to build) of the placement probe on sets of streamed arrays built from the HIP virtual-memory API
+    (brie_probe_vmm): per layout a physical chunk size and the order the chunks are created in (0 array after array,
+    1 round robin over the arrays, 2 plain hipMalloc)."""
+    lib = load_library()
+    cb = np.ascontiguousarray(chunk_bytes, np.int64)
+    od = np.ascontiguousarray(order, np.int32)
+    assert cb.shape == od.shape and cb.ndim == 1
+    gbs, secs = np.zeros(cb.shape[0], np.float64), np.zeros(cb.shape[0], np.float64)
+    _check(lib, lib.brie_probe_vmm(int(device), int(Nc), int(Ng), int(n_layers), cb.shape[0], cb.ctypes.data, od.ctypes.data,
+                                   int(iters), gbs.ctypes.data, secs.ctypes.data))
+    return gbs, secs
 
 
 def host_convert_slab(a):

@@ -2750,6 +2750,115 @@ int brie_probe_layouts(int32_t device, int64_t Nc, int64_t Ng, int64_t slab_byte
     return BRIE_OK;
 }
 
+// Experiment aid (round 6): the streamed arrays of a u8-count problem of (Nc, Ng) built from the HIP virtual-
+// memory API -- one address range per array, backed by physical chunks of `chunk_bytes` that are created in a chosen ORDER --
+// and the placement probe timed on them.  order 0: array after array (what hipMalloc does, chunk by chunk); order 1: round
+// robin -- chunk i of array 0, chunk i of array 1, ... -- so that the arrays of the set are interleaved in the order the
+// driver hands out physical memory; order 2: plain hipMalloc per array (the baseline).  n_layers 2 or 3.  Per layout:
+// gbs = storage bytes of a step / probe time, seconds = what building the set took.  Nothing is kept.
+int brie_probe_vmm(int32_t device, int64_t Nc, int64_t Ng, int32_t n_layers, int32_t n_layouts, const int64_t *chunk_bytes,
+                   const int32_t *order, int32_t iters, double *gbs, double *seconds) {
+    if (!chunk_bytes || !order || !gbs || !seconds || n_layouts < 1 || iters < 1 || Nc <= 0 || Ng <= 0 || n_layers < 2 || n_layers > 3)
+        return fail(BRIE_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t ld = round_up(Ng, brie::kGenesPerBlock);
+    const int n_arr = 6 + n_layers;
+    int64_t bytes[9];
+    for (int i = 0; i < n_arr; ++i) bytes[i] = i < 6 ? Nc * ld * 4 : Nc * ld;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran == 0) return fail(BRIE_ERR_HIP, "allocation granularity 0");
+    hipMemAccessDesc ad{};
+    ad.location = prop.location;
+    ad.flags = hipMemAccessFlagsProtReadWrite;
+    brie::StepScalars a{};
+    a.ld = ld; a.row_stride = brie::kGenesPerBlock; a.gb_stride = Nc * brie::kGenesPerBlock;
+    a.Nc = static_cast<int32_t>(Nc); a.Ng = static_cast<int32_t>(Ng);
+    int rpc = 256;
+    while (rpc > 16 && (Nc + rpc - 1) / rpc < 128) rpc /= 2;
+    a.rows_per_chunk = rpc;
+    const dim3 grid(static_cast<unsigned>(ld / brie::kGenesPerBlock), static_cast<unsigned>((Nc + rpc - 1) / rpc)), block(brie::kBlock);
+    const int pad = 81 * 1024;
+    auto k2 = brie::placement_probe<brie::kCountU8, false>;
+    auto k3 = brie::placement_probe<brie::kCountU8, true>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k3), hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    int rc = BRIE_OK;
+    for (int l = 0; l < n_layouts && rc == BRIE_OK; ++l) {
+        const auto t0 = std::chrono::steady_clock::now();
+        char *va[9] = {};
+        size_t vsz[9] = {};
+        std::vector<hipMemGenericAllocationHandle_t> handles;
+        hipError_t e = hipSuccess;
+        if (order[l] == 2) {
+            for (int i = 0; i < n_arr && e == hipSuccess; ++i) e = hipMalloc(reinterpret_cast<void **>(&va[i]), static_cast<size_t>(bytes[i]));
+        } else {
+            const size_t chunk = static_cast<size_t>(round_up(std::max<int64_t>(chunk_bytes[l], 1), static_cast<int64_t>(gran)));
+            size_t n_chunks[9], most = 0;
+            for (int i = 0; i < n_arr && e == hipSuccess; ++i) {
+                n_chunks[i] = (static_cast<size_t>(bytes[i]) + chunk - 1) / chunk;
+                most = std::max(most, n_chunks[i]);
+                vsz[i] = n_chunks[i] * chunk;
+                e = hipMemAddressReserve(reinterpret_cast<void **>(&va[i]), vsz[i], gran, nullptr, 0);
+            }
+            auto map_one = [&](int i, size_t c) {
+                hipMemGenericAllocationHandle_t hd;
+                e = hipMemCreate(&hd, chunk, &prop, 0);
+                if (e != hipSuccess) return;
+                handles.push_back(hd);
+                e = hipMemMap(va[i] + c * chunk, chunk, 0, hd, 0);
+            };
+            if (order[l] == 0) {
+                for (int i = 0; i < n_arr && e == hipSuccess; ++i)
+                    for (size_t c = 0; c < n_chunks[i] && e == hipSuccess; ++c) map_one(i, c);
+            } else {
+                for (size_t c = 0; c < most && e == hipSuccess; ++c)
+                    for (int i = 0; i < n_arr && e == hipSuccess; ++i)
+                        if (c < n_chunks[i]) map_one(i, c);
+            }
+            for (int i = 0; i < n_arr && e == hipSuccess; ++i) e = hipMemSetAccess(va[i], vsz[i], &ad, 1);
+        }
+        for (int i = 0; i < n_arr && e == hipSuccess; ++i) e = hipMemsetAsync(va[i], 0, static_cast<size_t>(bytes[i]), nullptr);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        seconds[l] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (e == hipSuccess) {
+            float *st[6];
+            for (int i = 0; i < 6; ++i) st[i] = reinterpret_cast<float *>(va[i]);
+            for (int it = -2; it < iters; ++it) {
+                if (it == 0) hipEventRecord(e0, nullptr);
+                if (n_layers == 3)
+                    hipLaunchKernelGGL(k3, grid, block, pad, nullptr, va[6], va[7], va[8], st[0], st[1], st[2], st[3], st[4], st[5], a, 0u,
+                                       static_cast<uint32_t *>(nullptr));
+                else
+                    hipLaunchKernelGGL(k2, grid, block, pad, nullptr, va[6], va[7], static_cast<const void *>(nullptr), st[0], st[1],
+                                       st[2], st[3], st[4], st[5], a, 0u, static_cast<uint32_t *>(nullptr));
+            }
+            hipEventRecord(e1, nullptr);
+            e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            gbs[l] = static_cast<double>(Nc) * Ng * (48.0 + n_layers) * iters / (ms * 1e-3) / 1e9;
+        }
+        if (e != hipSuccess) rc = fail(BRIE_ERR_HIP, "vmm probe, layout %d: %s", l, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (order[l] == 2) {
+            for (int i = 0; i < n_arr; ++i) if (va[i]) (void)hipFree(va[i]);
+        } else {
+            for (int i = 0; i < n_arr; ++i) if (va[i]) { (void)hipMemUnmap(va[i], vsz[i]); }
+            for (auto hd : handles) (void)hipMemRelease(hd);
+            for (int i = 0; i < n_arr; ++i) if (va[i]) (void)hipMemAddressFree(va[i], vsz[i]);
+        }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return rc;
+}
+
 // Measure the HBM rate of `n_read` read streams + `n_write` write streams of `bytes_per_stream`
 // each (no arithmetic) -> GB/s.  Supported mixes: (1,1) copy, (8,6) and (9,6) = elbo_adam_step with
 // 2 / 3 count layers.  `lds_bytes_per_block` > 0 reserves dynamic LDS per 256-thread block to cap the

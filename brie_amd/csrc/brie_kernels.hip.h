@@ -20,6 +20,7 @@
 //   pseudo_count     brie/models/model_wrap.py:113-117
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace brie {
@@ -210,10 +211,53 @@ __device__ __forceinline__ void loglik(float z, float c1, float c2, float c3,
     }
 }
 
+// dl/dz of one sample as in loglik -- the SAME operations in the same order, so the state cannot move by a bit -- while the
+// log-likelihood VALUE is not formed per sample at all: the samples of a step only ever enter the loss as their SUM, and
+//   sum_k [ c1 log_sigmoid(z_k) + c2 log_sigmoid(-z_k) ]  =  c1 A + c2 B - (c1 + c2) log prod_k (1 + e_k),
+//   A = sum_k min(z_k, 0) = (sum z - sum |z|) / 2,   B = sum_k min(-z_k, 0) = -(sum z + sum |z|) / 2,   e_k = exp(-|z_k|)
+// and, with effective lengths (model_TFProb.py:168-185: log phi_c = a_c - logsumexp a, logsumexp a = log D + log_sigmoid terms),
+//   - N sum_k log D_k  =  - N (MC log Ls + log prod_k (D_k / Ls)),   Ls = max(L0, L4) + L5 >= D_k  (per gene, hoisted)
+// so a step of MC samples takes TWO logarithms per element instead of 2 MC (one instead of MC without effLen) and per
+// sample two or three multiplies and two adds where it took ~25 VALU operations and two transcendentals.  prod (1 + e_k) lies
+// in (1, 2^MC], prod D_k / Ls in (((min(L0, L4) + L5) / Ls)^MC, 1]: no overflow for any lengths; it underflows only when
+// the isoforms' effective lengths differ by a factor beyond 1e12, which is clamped (the loss VALUE of such a gene is then
+// off; its gradient is not touched).  Rounding: three factors rounded to fp32 and one logarithm against three logarithms
+// rounded and summed -- the same size of error, in the loss trace only.  Fixed MC_size > 1 instantiations only (MC_size 3,
+// the brie-quant default, bin/quant.py:173): VALU-bound with the effLen likelihood (profiles/r5/r5_counters_c2_step_mc3.txt).
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+// ... on TWO adjacent elements of the lane at once (2-vectors: every fp32 add / mul / fma below is ONE v_pk_* instruction
+// for the pair; the transcendentals, the |z| and the sigmoid selects stay per element).  The derivative's operations are
+// those of loglik, in its order, so that the contraction into fused multiply-adds falls the same way.
+template <int MODE>
+__device__ __forceinline__ floatx2 loglik_grad_acc2(floatx2 z, floatx2 c1, floatx2 c2, floatx2 c3, floatx2 L0, floatx2 L4,
+                                                    floatx2 L5, floatx2 iLs, floatx2 &P1, floatx2 &PD, floatx2 &Sz, floatx2 &Saz) {
+    floatx2 az, e;
+    az.x = fabsf(z.x); az.y = fabsf(z.y);
+    e.x = f_exp(-az.x); e.y = f_exp(-az.y);       // exp(-|z|) in (0,1]
+    const floatx2 a1 = 1.0f + e;
+    floatx2 inv;
+    inv.x = f_rcp(a1.x); inv.y = f_rcp(a1.y);
+    const floatx2 small = e * inv;                // sigmoid(-|z|); inv = sigmoid(|z|)
+    floatx2 sp, sn;
+    sp.x = z.x >= 0.0f ? inv.x : small.x; sp.y = z.y >= 0.0f ? inv.y : small.y;     // sigmoid(z)
+    sn.x = z.x >= 0.0f ? small.x : inv.x; sn.y = z.y >= 0.0f ? small.y : inv.y;     // sigmoid(-z)
+    P1 *= a1;
+    Sz += z;
+    Saz += az;
+    if (MODE == kLik2) return c1 - (c1 + c2) * sp;
+    const floatx2 D = sp * L0 + sn * L4 + L5;
+    floatx2 iD;
+    iD.x = f_rcp(D.x); iD.y = f_rcp(D.y);
+    const floatx2 phi1 = sp * L0 * iD, phi2 = sn * L4 * iD;
+    floatx2 N = c1 + c2;
+    if (MODE == kLikEff3) N += c3;
+    PD *= D * iLs;
+    return c1 * sn - c2 * sp - N * (phi1 * sn - phi2 * sp);
+}
+
 // Forward-only log-likelihood of TWO elements at once (2-category mode, the forward passes): the same operations as
 // loglik<kLik2, true> per element, written on 2-vectors so that every fp32 add / mul / fma is ONE v_pk_* instruction
 // for the pair (gfx950 issues packed fp32 at the scalar rate); the transcendentals stay per element.
-typedef float floatx2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ floatx2 loglik2_pair(floatx2 z, floatx2 c1, floatx2 c2) {
     constexpr float kLog2e = 0x1.715476p+0f;                         // what __expf multiplies by
     const floatx2 t = z * kLog2e;
@@ -363,6 +407,53 @@ __device__ __forceinline__ float mixed_lane(const uint2 &u, int v, bool bytes) {
     return static_cast<float>(bytes ? b8 : b16);
 }
 
+// Split addressing (the VALU-bound step instantiations): `base` already holds everything of the address that is the same for
+// the whole wave (array, gene block, row: scalar unit), `lane_bytes` is the lane's own 32-bit byte offset -- the form the
+// hardware adds for free (global_load ... v_off, s[base:base+1]), no 64-bit vector add per access.
+template <typename T>
+__device__ __forceinline__ T ldnt_at(const void *base, uint32_t lane_bytes) {
+    return __builtin_nontemporal_load(reinterpret_cast<const T *>(static_cast<const char *>(base) + lane_bytes));
+}
+__device__ __forceinline__ F4 ld4s_at(const float *base, uint32_t lane_bytes) {
+    const floatx4 t = ldnt_at<floatx4>(base, lane_bytes);
+    return F4{{t.x, t.y, t.z, t.w}};
+}
+__device__ __forceinline__ void st4s_at(float *base, uint32_t lane_bytes, const F4 &a) {
+    floatx4 t = {a.v[0], a.v[1], a.v[2], a.v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<floatx4 *>(reinterpret_cast<char *>(base) + lane_bytes));
+}
+// load_counts with split addressing: `ub` = wave-uniform BYTE offset of the row inside a layer, `lb` = the lane's byte offset
+// (`lb2`: of the second dword of a mixed-tier quad).
+template <int CS, int MODE>
+__device__ __forceinline__ void load_counts_at(const void *__restrict__ p1, const void *__restrict__ p2,
+                                               const void *__restrict__ p3, int64_t ub, uint32_t lb, uint32_t lb2,
+                                               CountRegs<CS> &C, int esz) {
+    const char *q1 = static_cast<const char *>(p1) + ub, *q2 = static_cast<const char *>(p2) + ub,
+               *q3 = static_cast<const char *>(p3) + ub;
+    if constexpr (CS == kCountMixed) {
+        C.esz = esz;
+        C.u1 = make_uint2(ldnt_at<uint32_t>(q1, lb), ldnt_at<uint32_t>(q1, lb2));
+        C.u2 = make_uint2(ldnt_at<uint32_t>(q2, lb), ldnt_at<uint32_t>(q2, lb2));
+        if (MODE == kLikEff3) C.u3 = make_uint2(ldnt_at<uint32_t>(q3, lb), ldnt_at<uint32_t>(q3, lb2));
+        else C.u3 = make_uint2(0u, 0u);
+    } else if constexpr (CS == kCountF32) {
+        C.c1 = ld4s_at(reinterpret_cast<const float *>(q1), lb);
+        C.c2 = ld4s_at(reinterpret_cast<const float *>(q2), lb);
+        if (MODE == kLikEff3) C.c3 = ld4s_at(reinterpret_cast<const float *>(q3), lb);
+        else C.c3 = F4{{0.f, 0.f, 0.f, 0.f}};
+    } else if constexpr (CS == kCountU8) {
+        C.u1 = ldnt_at<uint32_t>(q1, lb);
+        C.u2 = ldnt_at<uint32_t>(q2, lb);
+        C.u3 = MODE == kLikEff3 ? ldnt_at<uint32_t>(q3, lb) : 0u;
+    } else {
+        const uintx2 t1 = ldnt_at<uintx2>(q1, lb), t2 = ldnt_at<uintx2>(q2, lb);
+        C.u1 = make_uint2(t1.x, t1.y);
+        C.u2 = make_uint2(t2.x, t2.y);
+        if (MODE == kLikEff3) { const uintx2 t3 = ldnt_at<uintx2>(q3, lb); C.u3 = make_uint2(t3.x, t3.y); }
+        else C.u3 = make_uint2(0u, 0u);
+    }
+}
+
 template <int CS, int MODE>
 __device__ __forceinline__ void load_counts(const void *__restrict__ p1, const void *__restrict__ p2,
                                             const void *__restrict__ p3, int64_t off, CountRegs<CS> &C, int esz = 0) {
@@ -422,6 +513,27 @@ __device__ __forceinline__ void decode_counts(const CountRegs<CS> &C, float pc, 
             c1.v[v] = a; c2.v[v] = b;
             c3.v[v] = u16_lane(C.u3, v);
         }
+    }
+}
+
+// Mixed tiers, the VALU-bound step instantiations: ONE byte permute per count instead of shift, mask and select.  sel[v]
+// (per lane, fixed for the whole chunk) picks element v of the lane's 8 count bytes {u.y : u.x} and zero-fills the rest:
+// a u8 quad keeps element v in byte v, a u16 quad in bytes 2v, 2v + 1.  The integers, hence the fp32 values, are the same.
+__device__ __forceinline__ void mixed_selectors(bool bytes, uint32_t (&sel)[kVec]) {
+#pragma unroll
+    for (int v = 0; v < kVec; ++v)
+        sel[v] = bytes ? (0x0c0c0c00u | static_cast<uint32_t>(v))
+                       : (0x0c0c0000u | (static_cast<uint32_t>(2 * v + 1) << 8) | static_cast<uint32_t>(2 * v));
+}
+__device__ __forceinline__ void decode_counts_perm(const CountRegs<kCountMixed> &C, const uint32_t (&sel)[kVec], float pc,
+                                                   F4 &c1, F4 &c2, F4 &c3) {
+#pragma unroll
+    for (int v = 0; v < kVec; ++v) {
+        float a = static_cast<float>(__builtin_amdgcn_perm(C.u1.y, C.u1.x, sel[v]));
+        float b = static_cast<float>(__builtin_amdgcn_perm(C.u2.y, C.u2.x, sel[v]));
+        if (a + b > 0.0f) { a += pc; b += pc; }
+        c1.v[v] = a; c2.v[v] = b;
+        c3.v[v] = static_cast<float>(__builtin_amdgcn_perm(C.u3.y, C.u3.x, sel[v]));
     }
 }
 
@@ -570,6 +682,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
     // Kc = 7 the 0 - 108 bytes of scratch that costs are cheaper than a lone wave per SIMD (Kc = 4: 0.62 -> 0.53 ms, Kc = 7:
     // 0.69 -> 0.59 at 10k x 5k; at Kc = 8, 148 bytes, 0.65 -> 0.88: left to the allocator, 0.62).
     constexpr bool kLeanLog = BRIE_LEANLOG_COND;
+    constexpr bool kProd = MC > 1 && !MARGIN;            // see loglik_grad_acc
     // GW: the cross-wave fold reuses the (dynamic) Xg tile once the row loop is over -- keeps 2 workgroups per CU
     __shared__ float red_static[GW ? 1 : (kWavesPerBlock - 1) * S * kGenesPerBlock];
     __shared__ float wlds[WIDE ? kWideKcMax * kGenesPerBlock : 1];      // W tile of this gene block
@@ -608,6 +721,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
         // per-gene parameters, live across the whole chunk
         float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
+        float iLs[kVec] = {0.f, 0.f, 0.f, 0.f};
         float Xgk[(CPL && !GW) ? kKgMax : 1][kVec];
         if constexpr (CPL && !GW) {
 #pragma unroll
@@ -640,6 +754,12 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
             for (int v = 0; v < kVec; ++v) {
                 L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
                 lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
+                if constexpr (kProd) {     // the value path works on D / Ls, Ls = max(L0, L4) + L5 (loglik_grad_acc)
+                    const float Ls = fmaxf(L0[v], L4[v]) + L5[v];
+                    const float lLs = f_log(Ls);
+                    iLs[v] = Ls > 0.0f ? 1.0f / Ls : 0.0f;           // padding genes beyond Ng have zero lengths
+                    lL0[v] -= lLs; lL4[v] -= lLs; lL5[v] -= lLs;
+                }
             }
         } else {
 #pragma unroll
@@ -657,7 +777,22 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
 #pragma unroll
             for (int v = 0; v < kVec; ++v) on[v] = t.v[v] != 0.0f;
         }
+        uint32_t csel[kVec] = {0u, 0u, 0u, 0u};
+        if constexpr (kProd && CS == kCountMixed) mixed_selectors(esz == 1, csel);
+        // kProd: a wave none of whose genes is frozen (every wave until batches converge) runs a row body without the 24
+        // per-element selects that keep a frozen gene's state and moments
+        bool any_off = true;
+        if constexpr (kProd) any_off = __builtin_amdgcn_ballot_w64(!(on[0] && on[1] && on[2] && on[3])) != 0ull;
 
+        // kProd: what of an element's address is the same for the whole wave (gene block, row) stays on the scalar unit
+        const uint32_t lane_bytes = static_cast<uint32_t>(lane * kVec * sizeof(float));
+        auto urow = [&](int r) { return static_cast<int64_t>(gb) * a.gb_stride + static_cast<int64_t>(r) * a.row_stride; };
+        // counts: byte offsets -- uniform start of the gene block's tile + row pitch, the lane's piece of the row
+        constexpr int kCntBytes = CS == kCountF32 ? 4 : (CS == kCountU16 ? 2 : 1);
+        const int64_t cnt_ub = CS == kCountMixed ? a.tt.blk_base[gb] : static_cast<int64_t>(gb) * a.gb_stride * kCntBytes;
+        const int64_t cnt_urow = CS == kCountMixed ? static_cast<int64_t>(a.tt.row_bytes[gb]) : a.row_stride * kCntBytes;
+        const uint32_t cnt_lb = CS == kCountMixed ? static_cast<uint32_t>(a.tt.q_off[quad]) : static_cast<uint32_t>(lane * kVec * kCntBytes);
+        const uint32_t cnt_lb2 = cnt_lb + static_cast<uint32_t>(4 * (esz - 1));
         auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX], RowScalars &rs) {
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             if constexpr (CPL) {
@@ -670,13 +805,32 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                 rs.cb = cp.cb[r];
                 rs.clam = cp.clam[r];
             }
-            load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
+            if constexpr (kProd) {
+                uint32_t cl = cnt_lb, cl2 = cnt_lb2;
+                asm volatile("" : "+v"(cl), "+v"(cl2));     // see `lb` below
+                load_counts_at<CS, MODE>(c1p, c2p, c3p, cnt_ub + static_cast<int64_t>(r) * cnt_urow, cl, cl2, R.cnt, esz);
+            } else {
+                load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
+            }
             if constexpr (WIDE) {
                 if (a.mean_in_rbuf) R.mp = ld4s(rbuf + off);      // Xc . Wc_loc of this element, formed beforehand
                 else                     // the cell's design row: lane k holds feature k (one coalesced load)
                     R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
             }
-            if constexpr (!MARGIN) {
+            if constexpr (kProd) {       // wave-uniform row base (scalar unit) + the lane's 32-bit byte offset: no address VALU
+                const int64_t ro = urow(r);
+                // instruction selection works per basic block: it must SEE that the vector part of the address is a 32-bit
+                // value to pick the scalar-base form, so the offset is made opaque here instead of living across the loop
+                // as a 64-bit pair (costs no instruction)
+                uint32_t lb = lane_bytes;
+                asm volatile("" : "+v"(lb));
+                R.mu = ld4s_at(mu_p + ro, lb);
+                R.rho = ld4s_at(rho_p + ro, lb);
+                R.mm = ld4s_at(mmu_p + ro, lb);
+                R.vm = ld4s_at(vmu_p + ro, lb);
+                R.mr = ld4s_at(mrho_p + ro, lb);
+                R.vr = ld4s_at(vrho_p + ro, lb);
+            } else if constexpr (!MARGIN) {
                 R.mu = ld4s(mu_p + off);
                 R.rho = ld4s(rho_p + off);
                 R.mm = ld4s(mmu_p + off);
@@ -688,7 +842,8 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
             for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
         };
 
-        auto process_row = [&](int r, RowRegs<CS> &R, const float (&xc)[KCX], const RowScalars &rs) {
+        auto process_row = [&](auto frz_tag, int r, RowRegs<CS> &R, const float (&xc)[KCX], const RowScalars &rs) {
+            constexpr bool FRZ = decltype(frz_tag)::value;      // some gene of the wave may be frozen
             const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
             const bool cell = CPL && cp.cell_mode != 0;
             const float row_isig2 = CPL ? f_exp(-2.0f * rs.clam) : 0.0f;
@@ -704,7 +859,8 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                 }
             }
             F4 c1, c2, c3;
-            decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
+            if constexpr (kProd && CS == kCountMixed) decode_counts_perm(R.cnt, csel, a.pc, c1, c2, c3);
+            else decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
             if constexpr (WIDE) {        // Xc . Wc_loc: broadcast x_k with v_readlane, W_k from LDS
                 const int xbits = __builtin_bit_cast(int, R.mp.v[0]);
                 float mp[kVec] = {0.f, 0.f, 0.f, 0.f};
@@ -787,7 +943,50 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                         gse[v] = fmaf(g, e[v], gse[v]);
                     }
                 };
-                if (MC > 0) {
+                if constexpr (kProd) {
+                    // fixed MC_size > 1: the samples' log-likelihood VALUES as products under two logarithms per element, their
+                    // derivatives -- all that reaches the state -- operation for operation as in `sample` (loglik_grad_acc2)
+                    floatx2 P1[2], PD[2], Sz[2], Saz[2], gb[2], gs[2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) { P1[p] = 1.0f; PD[p] = 1.0f; Sz[p] = 0.0f; Saz[p] = 0.0f; gb[p] = 0.0f; gs[p] = 0.0f; }
+#pragma unroll
+                    for (int k = 0; k < MC; ++k) {
+                        float e[kVec];
+                        normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const int u = 2 * p, w = 2 * p + 1;
+                            const floatx2 ev = {e[u], e[w]};
+                            const floatx2 z = __builtin_elementwise_fma(floatx2{s[u], s[w]}, ev, floatx2{R.mu.v[u], R.mu.v[w]});
+                            const floatx2 g = loglik_grad_acc2<MODE>(z, floatx2{c1.v[u], c1.v[w]}, floatx2{c2.v[u], c2.v[w]},
+                                                                     floatx2{c3.v[u], c3.v[w]}, floatx2{L0[u], L0[w]},
+                                                                     floatx2{L4[u], L4[w]}, floatx2{L5[u], L5[w]},
+                                                                     floatx2{iLs[u], iLs[w]}, P1[p], PD[p], Sz[p], Saz[p]);
+                            gb[p] += g;
+                            gs[p] = __builtin_elementwise_fma(g, ev, gs[p]);
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int u = 2 * p, w = 2 * p + 1;
+                        const floatx2 c1v = {c1.v[u], c1.v[w]}, c2v = {c2.v[u], c2.v[w]}, c3v = {c3.v[u], c3.v[w]};
+                        const floatx2 A = 0.5f * (Sz[p] - Saz[p]), B = -0.5f * (Sz[p] + Saz[p]);
+                        floatx2 lg;
+                        lg.x = f_log_sel<true>(P1[p].x); lg.y = f_log_sel<true>(P1[p].y);
+                        floatx2 l = c1v * A + c2v * B - (c1v + c2v) * lg;
+                        if (MODE != kLik2) {       // lL0 / lL4 / lL5 hold log L - log Ls here (prologue)
+                            floatx2 N = c1v + c2v, cl = c1v * floatx2{lL0[u], lL0[w]} + c2v * floatx2{lL4[u], lL4[w]};
+                            if (MODE == kLikEff3) { N += c3v; cl += c3v * floatx2{lL5[u], lL5[w]}; }
+                            floatx2 ld;
+                            ld.x = f_log_sel<true>(fmaxf(PD[p].x, 1.17549435e-38f));
+                            ld.y = f_log_sel<true>(fmaxf(PD[p].y, 1.17549435e-38f));
+                            l += static_cast<float>(MC) * cl - N * ld;
+                        }
+                        ll[u] = l.x; ll[w] = l.y;
+                        gbar[u] = gb[p].x; gbar[w] = gb[p].y;
+                        gse[u] = gs[p].x; gse[w] = gs[p].y;
+                    }
+                } else if (MC > 0) {
 #pragma unroll
                     for (int k = 0; k < MC; ++k) sample(static_cast<uint32_t>(k));
                 } else {
@@ -822,12 +1021,16 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                     float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
                     nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                          // clip constraint
                     const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
-                    R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
-                    R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
-                    R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
-                    R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
-                    R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
-                    R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
+                    if constexpr (FRZ) {
+                        R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
+                        R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
+                        R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
+                        R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
+                        R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
+                        R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
+                    } else {
+                        R.mm.v[v] = n_mm; R.vm.v[v] = n_vm; R.mr.v[v] = n_mr; R.vr.v[v] = n_vr; R.mu.v[v] = nmu; R.rho.v[v] = nrho;
+                    }
                 }
                 if constexpr (CPL) {     // padding genes inside the last quad (Ng % 4 != 0) are not part of the cell's sums
                     const bool real = j0 + v < a.Ng;
@@ -850,7 +1053,17 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                 acc[KC + 3][v] += llv;
             }
             if ((!CPL && !WIDE) || active) {
-                if constexpr (!MARGIN) {
+                if constexpr (kProd) {
+                    const int64_t ro = urow(r);
+                    uint32_t lb = lane_bytes;
+                    asm volatile("" : "+v"(lb));
+                    st4s_at(mu_p + ro, lb, R.mu);
+                    st4s_at(rho_p + ro, lb, R.rho);
+                    st4s_at(mmu_p + ro, lb, R.mm);
+                    st4s_at(vmu_p + ro, lb, R.vm);
+                    st4s_at(mrho_p + ro, lb, R.mr);
+                    st4s_at(vrho_p + ro, lb, R.vr);
+                } else if constexpr (!MARGIN) {
                     st4s(mu_p + off, R.mu);
                     st4s(rho_p + off, R.rho);
                     st4s(mmu_p + off, R.mm);
@@ -898,29 +1111,55 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
             }
         };
 
-        int r = row0 + w;
-        const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
-        RowRegs<CS> cur;
-        float xc[KCX];
-        RowScalars rsc{};
-        load_row(r, cur, xc, rsc);
         // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
         // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
         // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body
         // is branch-free; the last row is peeled so no load is ever issued for a row that is not used.
-        while (r < r_last) {
-            RowRegs<CS> nxt;
-            float xn[KCX];
-            RowScalars rsn{};
-            load_row(r + kWavesPerBlock, nxt, xn, rsn);
-            process_row(r, cur, xc, rsc);
-            cur = nxt;
-            rsc = rsn;
+        if constexpr (kProd) {        // two copies of the loop: with and without the frozen-gene selects
+            auto run_rows = [&](auto frz_tag) {
+                int r = row0 + w;
+                const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
+                RowRegs<CS> cur;
+                float xc[KCX];
+                RowScalars rsc{};
+                load_row(r, cur, xc, rsc);
+                while (r < r_last) {
+                    RowRegs<CS> nxt;
+                    float xn[KCX];
+                    RowScalars rsn{};
+                    load_row(r + kWavesPerBlock, nxt, xn, rsn);
+                    process_row(frz_tag, r, cur, xc, rsc);
+                    cur = nxt;
+                    rsc = rsn;
+    #pragma unroll
+                    for (int k = 0; k < KC; ++k) xc[k] = xn[k];
+                    r += kWavesPerBlock;
+                }
+                process_row(frz_tag, r, cur, xc, rsc);
+            };
+            if (any_off) run_rows(std::true_type{});
+            else run_rows(std::false_type{});
+        } else {                      // (spelled out, not through the lambda: these instantiations' code is round 4's, unchanged)
+            int r = row0 + w;
+            const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
+            RowRegs<CS> cur;
+            float xc[KCX];
+            RowScalars rsc{};
+            load_row(r, cur, xc, rsc);
+            while (r < r_last) {
+                RowRegs<CS> nxt;
+                float xn[KCX];
+                RowScalars rsn{};
+                load_row(r + kWavesPerBlock, nxt, xn, rsn);
+                process_row(std::true_type{}, r, cur, xc, rsc);
+                cur = nxt;
+                rsc = rsn;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) xc[k] = xn[k];
-            r += kWavesPerBlock;
+                for (int k = 0; k < KC; ++k) xc[k] = xn[k];
+                r += kWavesPerBlock;
+            }
+            process_row(std::true_type{}, r, cur, xc, rsc);
         }
-        process_row(r, cur, xc, rsc);
     }
 
     // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row

@@ -368,6 +368,13 @@ int brie_placement_status(const brie_handle *h, int32_t *status, int64_t *peak_b
 int brie_probe_layouts(int32_t device, int64_t Nc, int64_t Ng, int64_t slab_bytes, int32_t n_layouts, const int64_t *offsets,
                        int32_t iters, double *gbs);
 
+/* Experiment aid (round 6): the streamed arrays of a u8-count problem built from the HIP virtual-memory API (hipMemAddressReserve /
+ * hipMemCreate / hipMemMap) with physical chunks of chunk_bytes[l] created in order[l] -- 0: array after array, 1: round robin over the
+ * arrays (interleaved), 2: plain hipMalloc per array -- and the placement probe timed on each layout -> gbs[n_layouts] (storage bytes
+ * of a step / probe time) and seconds[n_layouts] (building the set).  No reference counterpart (profiles/vmm_probe.py). */
+int brie_probe_vmm(int32_t device, int64_t Nc, int64_t Ng, int32_t n_layers, int32_t n_layouts, const int64_t *chunk_bytes,
+                   const int32_t *order, int32_t iters, double *gbs, double *seconds);
+
 /* Free / total HBM of a device in bytes (hipMemGetInfo).  fitBRIE uses it to split a gene range that does not
  * fit into sequential super-batches -- the role of the reference's batch_size (model_wrap.py:241-260), sized for
  * 288 GB instead of for 500k elements. */

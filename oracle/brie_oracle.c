@@ -23,6 +23,10 @@
  *         cell order, cells per fp32 partial sum) which, with the OpenMP thread count (= where the per-thread sums are cut),
  *         define the MEMBERS of the pre-registered null ensemble (tests/util.py::psi_ensemble_rule,
  *         tests/golden/psi_ensemble_manifest.json); the defaults (1, 1, 64) are the single draw of round 4.
+ *        (+ -DBRIE_ORACLE_MUTANTS [with -DBRIE_ORACLE_B ...] -o .../libbrie_oracle_mut.so: NEGATIVE CONTROLS.  The build takes
+ *         brie_oracle_set_mutant(id): deliberately WRONG variants of the algorithm (enum below) that the parity rules of
+ *         tests/util.py must reject -- tests/test_rule_power.py, tests/tools/rule_power.py.  Without the flag every MUT(x)
+ *         is the constant 0 and the code is what it was.)
  * Nothing in brie_amd/ may link or load this file.
  */
 #include <math.h>
@@ -68,6 +72,27 @@ typedef float real;
 #endif
 #define RC(x) ((real)(x))
 
+/* ---- negative controls (tests/tools/rule_power.py): one deliberate error at a time, selected at run time ---- */
+enum { MUT_NONE = 0,
+       MUT_ADAM_EPS_TORCH = 1,   /* eps inside the bias correction: lr/(1-b1^t) m / (sqrt(v/(1-b2^t)) + eps)  (torch.optim.Adam) */
+       MUT_ADAM_EPS_1E8 = 2,     /* eps = 1e-8 (torch's default) instead of Keras' 1e-7 */
+       MUT_NO_CLIP = 3,          /* no clip of Z_loc / intercept to [-9, 9] (model_TFProb.py:69,81) */
+       MUT_BETA2_DOUBLE = 4,     /* 1 - beta_2 formed in double and then rounded (0.001f) instead of 1.0f - 0.999f */
+       MUT_KL_NO_EXPM1 = 6,      /* KL without 0.5 expm1(2 (rho - lambda)): the s^2 / sigma^2 term and its gradients dropped */
+       MUT_MC_SAME_NOISE = 9,    /* every MC sample of a step uses the noise of sample 0 */
+       MUT_NO_BIAS_CORR = 10,    /* Adam without bias correction: alpha = lr */
+       MUT_LIK_GRAD_1PCT = 11,   /* d loglik / dz scaled by 1.01 */
+       MUT_LIK_GRAD_01PCT = 12,  /* d loglik / dz scaled by 1.001 */
+       MUT_KL_GRAD_1PCT = 13,    /* prior pull (mu - m) / sigma^2 scaled by 1.01 in the Z_loc gradient */
+       MUT_SIGMA_GRAD_SIGN = 14  /* gradient of sigma_log with the sign of its s^2 / sigma^2 term flipped */
+};
+#ifdef BRIE_ORACLE_MUTANTS
+static int g_mutant = 0;
+#define MUT(x) (g_mutant == (x))
+#else
+#define MUT(x) 0
+#endif
+
 /* The cells are cut into PARTS with their own per-gene accumulators, summed in part order: by default one part per OpenMP
  * thread with the ranges of `omp for schedule(static)` (so the sums depend on the thread count); brie_oracle_set_parts(n)
  * fixes the number of parts whatever the thread count, which makes a run with "n threads" reproducible on any host. */
@@ -112,11 +137,13 @@ typedef struct {
     uint64_t seed;
 } brie_oracle_problem;
 
+static real g_lr_over_bc1 = 0, g_sqrt_bc2 = 1;      /* the two halves of alpha, for MUT_ADAM_EPS_TORCH (set once per step) */
 static void adam(real *x, real *m, real *v, real g, real alpha, int clip) {
     *m += (g - *m) * (RC(1) - RC(0.9));
-    *v += (g * g - *v) * (RC(1) - RC(0.999));
-    *x -= (*m * alpha) / (R_SQRT(*v) + RC(1e-7));
-    if (clip) *x = R_FMIN(R_FMAX(*x, RC(-9)), RC(9));
+    *v += (g * g - *v) * (MUT(MUT_BETA2_DOUBLE) ? (real)(1.0 - 0.999) : RC(1) - RC(0.999));
+    if (MUT(MUT_ADAM_EPS_TORCH)) *x -= (*m * g_lr_over_bc1) / (R_SQRT(*v) / g_sqrt_bc2 + RC(1e-7));
+    else *x -= (*m * alpha) / (R_SQRT(*v) + (MUT(MUT_ADAM_EPS_1E8) ? RC(1e-8) : RC(1e-7)));
+    if (clip && !MUT(MUT_NO_CLIP)) *x = R_FMIN(R_FMAX(*x, RC(-9)), RC(9));
 }
 
 /* n_steps optimisation steps in place; trace[i] = loss BEFORE update i (sum KL - sum ll, double sums).
@@ -146,7 +173,9 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
         }
     for (int step = 0; step < n_steps; ++step) {
         const int t = t0 + step + 1;
-        const real alpha = lr * R_SQRT(RC(1) - R_POW(RC(0.999), (real)t)) / (RC(1) - R_POW(RC(0.9), (real)t));
+        const real alpha = MUT(MUT_NO_BIAS_CORR) ? lr : lr * R_SQRT(RC(1) - R_POW(RC(0.999), (real)t)) / (RC(1) - R_POW(RC(0.9), (real)t));
+        g_lr_over_bc1 = lr / (RC(1) - R_POW(RC(0.9), (real)t));
+        g_sqrt_bc2 = R_SQRT(RC(1) - R_POW(RC(0.999), (real)t));
         const uint32_t draw = draw0 + (uint32_t)step;
         memset(acc, 0, sizeof(double) * (size_t)parts * S * Ng);
 #pragma omp parallel for schedule(static, 1)
@@ -172,7 +201,8 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                 for (int j0 = 0; j0 < Ng; j0 += 4) {
                     real eps[8][4];                        /* up to 8 MC samples */
                     const uint32_t quad = (uint32_t)((p->gene_offset + j0) / 4);
-                    for (int k = 0; k < p->mc; ++k) normal4(quad, (uint32_t)i, draw, (uint32_t)k, p->seed, eps[k]);
+                    for (int k = 0; k < p->mc; ++k)
+                        normal4(quad, (uint32_t)i, draw, MUT(MUT_MC_SAME_NOISE) ? 0u : (uint32_t)k, p->seed, eps[k]);
                     for (int v = 0; v < 4 && j0 + v < Ng; ++v) {
                         const int j = j0 + v;
                         const size_t o = (size_t)i * Ng + j;
@@ -180,7 +210,7 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                         real m = b[j];
                         for (int k = 0; k < Kc; ++k) m += x[k] * W[(size_t)k * Ng + j];
                         const real isig2 = R_EXP(RC(-2) * lam[j]), d = mu - m, rr = d * isig2, s2r = s * s * isig2;
-                        const real kl = RC(0.5) * d * d * isig2 + RC(0.5) * R_EXPM1(RC(2) * (rho - lam[j])) - (rho - lam[j]);
+                        const real kl = RC(0.5) * d * d * isig2 + (MUT(MUT_KL_NO_EXPM1) ? RC(0) : RC(0.5) * R_EXPM1(RC(2) * (rho - lam[j]))) - (rho - lam[j]);
                         real gbar = RC(0), gse = RC(0), ll = RC(0);
                         for (int k = 0; k < p->mc; ++k) {
                             const real z = mu + s * eps[k][v];
@@ -197,16 +227,18 @@ int brie_oracle_steps(const brie_oracle_problem *p, int32_t n_steps, double lr_,
                                 l = c1[o] * (a1 - lse) + c2[o] * (a2 - lse) + cc3 * (a3 - lse);
                                 g = c1[o] * (RC(1) - sp) - c2[o] * sp - N * (R_EXP(a1 - lse) * (RC(1) - sp) - R_EXP(a2 - lse) * sp);
                             }
+                            if (MUT(MUT_LIK_GRAD_1PCT)) g *= RC(1.01);
+                            if (MUT(MUT_LIK_GRAD_01PCT)) g *= RC(1.001);
                             ll += l; gbar += g; gse += g * s * eps[k][v];
                         }
                         ll /= (real)p->mc; gbar /= (real)p->mc; gse /= (real)p->mc;
                         for (int k = 0; k < Kc; ++k) a[(size_t)k * Ng + j] += x[k] * rr;
                         a[(size_t)(Kc + 0) * Ng + j] += rr;
-                        a[(size_t)(Kc + 1) * Ng + j] += RC(1) - d * d * isig2 - s2r;
+                        a[(size_t)(Kc + 1) * Ng + j] += RC(1) - d * d * isig2 - (MUT(MUT_KL_NO_EXPM1) ? RC(0) : MUT(MUT_SIGMA_GRAD_SIGN) ? -s2r : s2r);
                         a[(size_t)(Kc + 2) * Ng + j] += kl;
                         a[(size_t)(Kc + 3) * Ng + j] += ll;
-                        adam(&Z_loc[o], &m_mu[o], &v_mu[o], rr - gbar, alpha, 1);
-                        adam(&Z_std_log[o], &m_rho[o], &v_rho[o], s2r - RC(1) - gse, alpha, 0);
+                        adam(&Z_loc[o], &m_mu[o], &v_mu[o], (MUT(MUT_KL_GRAD_1PCT) ? RC(1.01) * rr : rr) - gbar, alpha, 1);
+                        adam(&Z_std_log[o], &m_rho[o], &v_rho[o], (MUT(MUT_KL_NO_EXPM1) ? RC(0) : s2r) - RC(1) - gse, alpha, 0);
                     }
                 }
 #ifdef BRIE_ORACLE_B
@@ -255,6 +287,17 @@ int brie_oracle_b_config(int float_noise, int reverse, int chunk) {
     return 0;
 #else
     (void)float_noise; (void)reverse; (void)chunk;
+    return -1;
+#endif
+}
+
+/* negative controls: only the -DBRIE_ORACLE_MUTANTS build has the switch (returns 0 there, -1 elsewhere) */
+int brie_oracle_set_mutant(int id) {
+#ifdef BRIE_ORACLE_MUTANTS
+    g_mutant = id;
+    return 0;
+#else
+    (void)id;
     return -1;
 #endif
 }

@@ -10,6 +10,11 @@ SRC = os.path.join(HERE, "brie_oracle.c")
 LIB = os.path.join(HERE, "_build", "libbrie_oracle.so")
 LIB_F64 = os.path.join(HERE, "_build", "libbrie_oracle_f64.so")
 LIB_B = os.path.join(HERE, "_build", "libbrie_oracle_b.so")
+LIB_MUT = os.path.join(HERE, "_build", "libbrie_oracle_mut.so")
+# negative controls (brie_oracle.c, enum MUT_*): deliberately wrong variants the parity rules must reject
+MUTANTS = {"none": 0, "adam_eps_torch": 1, "adam_eps_1e8": 2, "no_clip": 3, "beta2_double": 4, "kl_no_expm1": 6,
+           "mc_same_noise": 9, "no_bias_corr": 10, "lik_grad_1pct": 11, "lik_grad_01pct": 12, "kl_grad_1pct": 13,
+           "sigma_grad_sign": 14}
 
 
 def _cpu_has_fma():
@@ -20,19 +25,24 @@ def _cpu_has_fma():
         return False
 
 
-def build(force=False, f64=False, variant_b=False):
+def build(force=False, f64=False, variant_b=False, mutants=False):
     """gcc -O3 -fopenmp -> oracle/_build/libbrie_oracle.so (fp32, the reference's precision) or, with f64=True,
     libbrie_oracle_f64.so (the same code with every quantity in double).  -ffp-contract=off: no fused
     multiply-adds, so the fp32 build rounds after every operation like the eager reference does.
     variant_b=True: libbrie_oracle_b.so, "o32b" -- a second fp32 evaluation (float Box-Muller, reversed cell order with
-    fp32 partial sums, -ffp-contract=fast and FMA instructions where the host has them; see the header of brie_oracle.c)."""
-    assert not (f64 and variant_b)
-    lib = LIB_B if variant_b else (LIB_F64 if f64 else LIB)
+    fp32 partial sums, -ffp-contract=fast and FMA instructions where the host has them; see the header of brie_oracle.c).
+    mutants=True: libbrie_oracle_mut.so -- the o32b build plus brie_oracle_set_mutant (negative controls; a mutant is "some
+    other fp32 evaluation" with ONE deliberate error, the position a wrong HIP kernel would be in)."""
+    assert not (f64 and (variant_b or mutants))
+    variant_b = variant_b or mutants
+    lib = LIB_MUT if mutants else LIB_B if variant_b else (LIB_F64 if f64 else LIB)
     if force or not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(SRC):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         flags = ["-DBRIE_ORACLE_F64"] if f64 else []
         if variant_b:
             flags = ["-DBRIE_ORACLE_B", "-ffp-contract=fast"] + (["-mfma"] if _cpu_has_fma() else [])
+            if mutants:
+                flags.append("-DBRIE_ORACLE_MUTANTS")
         else:
             flags = ["-ffp-contract=off"] + flags
         subprocess.run(["gcc", "-O3"] + flags + ["-fopenmp", "-shared", "-fPIC", SRC, "-o", lib, "-lm"], check=True)
@@ -49,10 +59,14 @@ class COracle(object):
     """State + optimiser slots as float32 arrays, stepped by the C kernel; mirrors OracleBRIE2's fields."""
 
     def __init__(self, counts, Xc, effLen=None, seed=0, gene_offset=0, intercept=None, sigma=None, init=None,
-                 dtype=np.float32, variant_b=False):
+                 dtype=np.float32, variant_b=False, mutant=None):
         from .brie_oracle import OracleBRIE2
         self.dtype = np.dtype(dtype)
-        self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64, variant_b=variant_b))
+        self.lib = ctypes.CDLL(build(f64=self.dtype == np.float64, variant_b=variant_b, mutants=mutant is not None))
+        if mutant is not None:             # a global of the loaded library, like the o32b knobs
+            variant_b = True
+            if self.lib.brie_oracle_set_mutant(ctypes.c_int(MUTANTS[mutant])) != 0:
+                raise ValueError("not the mutant build")
         assert self.lib.brie_oracle_real_bytes() == self.dtype.itemsize
         self.lib.brie_oracle_set_parts(ctypes.c_int(0))
         if variant_b:                      # the knobs are globals of the loaded library: every o32b run starts from the defaults

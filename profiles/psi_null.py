@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "profiles"))
 import psi_delta as pd                                      # noqa: E402  (CASES, problem(), schedule(), the o32 cache)
 
-NULL_DIR = os.path.join(ROOT, "profiles", "psi_null")
+from tests.support.null_fixture import NULL_DIR, load_summary       # noqa: E402,F401
 HIP_DIR = os.path.join(ROOT, "gpurun_out", "psi_null")        # written on the GPU box, merged back by gpurun
 HIP_KEPT = os.path.join(ROOT, "profiles", "psi_null_hip")      # ... and committed from there
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -63,13 +63,6 @@ def run_o32b(case, tag=""):
 def save_summary(path, s, **extra):
     os.makedirs(os.path.dirname(path), exist_ok=True)
     np.savez_compressed(path, **{k: s[k] for k in SUMMARY_KEYS}, **extra)
-
-
-def load_summary(path):
-    z = np.load(path)
-    s = {k: z[k] for k in ("shift", "n_gt", "max", "hist")}
-    s["Nc"] = int(z["Nc"])
-    return s
 
 
 def null_case(case, tag=""):

@@ -406,13 +406,10 @@ def test_psi_null_rule_on_gene_samples_of_the_full_size_configs_after_the_full_d
     shrink or skip.  The third case is held out: other data seed and model seed (init, noise stream)."""
     import json
     import os
-    import sys
     from brie_amd import _capi
     from tests import util
+    from tests.support import psi_cases as pd, null_fixture as pn
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "profiles"))
-    import psi_delta as pd
-    import psi_null as pn
     c = pd.CASES[case]
     Nc, Kc, L = c["Nc"], c["Kc"], c["L"]
     full_o32 = os.path.join(pd.CACHE, "%s_float32.npz" % case)
@@ -454,13 +451,10 @@ def _judge_by_the_ensemble(case):
     fixture by tests/util.py::psi_ensemble_rule; the verdict is written next to the bench files for profiles/r5/."""
     import json
     import os
-    import sys
     from brie_amd import _capi
     from tests import util
+    from tests.support import psi_cases as pd, ensemble as pe
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sys.path.insert(0, os.path.join(root, "profiles"))
-    import psi_delta as pd
-    import psi_ensemble as pe
     fixture = os.path.join(root, "tests", "golden", "psi_ens_%s_first%d.npz" % (case, pe.GENES))
     if case not in pe.REGISTERED_FIRST and case not in json.load(open(pe.MANIFEST)).get("frozen", {}):
         pytest.skip("%s is registered (addendum) but its members are not computed and frozen yet" % case)

@@ -38,18 +38,12 @@ def assert_states_close(so, sd, bulk=1e-5, worst=1e-3, lr=0.01, fresh=1):
               mu on its prior mean: |g| ~ 1e-8) moves by +lr or -lr on the SIGN of a rounding error.  Such an element
               may sit up to 2 lr apart per fresh optimiser in the sequence (`fresh`; + 10 % for the steps that follow),
               and there may be at most max(1, 1e-4 n) of them per array."""
-    for k in util.STATE_KEYS:
-        if so[k].size == 0:
-            continue
-        d = np.abs(np.asarray(so[k], np.float64) - np.asarray(sd[k], np.float64))
-        n_out = int((d >= worst).sum())
-        if _RECORD is not None:
-            _RECORD.append((k, int(d.size), float(np.percentile(d, 99.9)), float(d.max()), n_out))
-            continue
-        if d.size >= 1000:
-            assert np.percentile(d, 99.9) < bulk, (k, float(np.percentile(d, 99.9)))
-        assert n_out <= max(1, int(1e-4 * d.size)), (k, "elements beyond %g" % worst, n_out, float(d.max()))
-        assert d.max() < max(worst, 2.2 * lr * fresh), (k, float(d.max()))
+    if _RECORD is not None:
+        for k, (n, p999, mx, n_out) in util.states_close_stats(so, sd, worst).items():
+            _RECORD.append((k, n, p999, mx, n_out))
+        return
+    viol = util.states_close_violations(so, sd, bulk=bulk, worst=worst, lr=lr, fresh=fresh)
+    assert not viol, viol
 
 
 def test_library_loads(lib):

@@ -63,6 +63,34 @@ def max_abs_diff(a, b):
     return float(np.max(np.abs(a - b))) if a.size else 0.0
 
 
+def states_close_stats(so, sd, worst=1e-3):
+    """Per state array: (elements, 99.9 % quantile of |difference|, largest, elements beyond `worst`)."""
+    out = {}
+    for k in STATE_KEYS:
+        if k not in so or np.asarray(so[k]).size == 0:
+            continue
+        d = np.abs(np.asarray(so[k], np.float64) - np.asarray(sd[k], np.float64))
+        out[k] = (int(d.size), float(np.percentile(d, 99.9)), float(d.max()), int((d >= worst).sum()))
+    return out
+
+
+def states_close_violations(so, sd, bulk=1e-5, worst=1e-3, lr=0.01, fresh=1):
+    """THE short-horizon parity rule (tests/test_gpu_parity.py::assert_states_close states where its constants come
+    from) as a list of violations, so that the negative controls (tests/test_rule_power.py) can ask whether a WRONG
+    algorithm is rejected by exactly the bounds the HIP path is held to:
+      bulk    99.9 % of every array of >= 1000 elements within `bulk`;
+      worst   at most max(1, 1e-4 n) elements of an array beyond `worst`, none beyond max(worst, 2.2 lr fresh)."""
+    viol = []
+    for k, (n, p999, mx, n_out) in states_close_stats(so, sd, worst).items():
+        if n >= 1000 and not p999 < bulk:
+            viol.append((k, "99.9 % quantile", p999))
+        if not n_out <= max(1, int(1e-4 * n)):
+            viol.append((k, "elements beyond %g" % worst, n_out, mx))
+        if not mx < max(worst, 2.2 * lr * fresh):
+            viol.append((k, "max", mx))
+    return viol
+
+
 def staged_schedule(min_iter):
     return [(int(min_iter / 6), lr) for lr in LEARNING_RATES]
 

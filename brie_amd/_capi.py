@@ -15,7 +15,7 @@ from .build import LIB_PATH
 COUNT1, COUNT2, COUNT3, XC, EFFLEN, XG = 0, 1, 2, 3, 4, 5
 Z_LOC, Z_STD_LOG, WC_LOC, INTERCEPT, SIGMA_LOG, WG_LOC = 8, 9, 10, 11, 12, 13
 PSI, Z_STD, PSI95CI, SIGMA = 16, 17, 18, 19
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_KC = 1024        # 0..8 in registers, 9..64 on the matrix cores inside the streaming pass, beyond in 64-feature panels
 MAX_KG = 1024        # 0..4 in registers, 5..64 as a tile in LDS / on the matrix cores, beyond in 64-feature panels
 
@@ -34,6 +34,8 @@ EXPORTS = [
     "brie_read_results_async", "brie_read_wait", "brie_host_register", "brie_host_unregister", "brie_reconfigure",
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
     "brie_placement_probe", "brie_placement_tune", "brie_placement_info", "brie_placement_status", "brie_probe_layouts",
+    "brie_placement_configure", "brie_debug_inject_placement_failure", "brie_probe_vmm", "brie_set_step_fusion",
+    "brie_step_fusion_info",
 ]
 COMM_ID_BYTES = 128
 #: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
@@ -136,8 +138,12 @@ def load_library(path=None):
     lib.brie_placement_probe.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_double)]
     lib.brie_placement_tune.argtypes = [vp, i32, ctypes.c_double]
     lib.brie_placement_status.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_int64), ctypes.c_char_p, i32]
-    lib.brie_placement_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double),
+    lib.brie_placement_info.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_double), i32,
                                         ctypes.POINTER(ctypes.c_double)]
+    lib.brie_placement_configure.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double]
+    lib.brie_set_step_fusion.argtypes = [vp, i32]
+    lib.brie_step_fusion_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    lib.brie_debug_inject_placement_failure.argtypes = [vp, i32]
     lib.brie_last_error.restype = ctypes.c_char_p
     lib.brie_abi_version.restype = ctypes.c_int
     for name in EXPORTS:
@@ -543,12 +549,30 @@ class Shard(object):
         _check(self.lib, self.lib.brie_placement_tune(self._h, int(max_tries), float(good_gbs)))
         return self.placement_info()
 
+    def set_step_fusion(self, mode):
+        """Many Adam steps per launch for small inputs (brie_set_step_fusion): -1 automatic, 0 never, 1 whenever allowed."""
+        _check(self.lib, self.lib.brie_set_step_fusion(self._h, int(mode)))
+
+    def step_fusion_info(self):
+        n, k = ctypes.c_int64(), ctypes.c_int64()
+        _check(self.lib, self.lib.brie_step_fusion_info(self._h, ctypes.byref(n), ctypes.byref(k)))
+        return {"launches": n.value, "steps": k.value}
+
+    def placement_configure(self, max_sets=0, hbm_fraction=0.0, max_seconds=0.0):
+        """Per-handle limits of the placement search (brie_placement_configure; 0 keeps a default): sets in all, the share of
+        the free HBM a round may take, seconds after which nothing more is allocated."""
+        _check(self.lib, self.lib.brie_placement_configure(self._h, int(max_sets), float(hbm_fraction), float(max_seconds)))
+
+    def inject_placement_failure(self, point):
+        """Tests: the next search of THIS handle fails at `point` (brie_debug_inject_placement_failure)."""
+        _check(self.lib, self.lib.brie_debug_inject_placement_failure(self._h, int(point)))
+
     def placement_info(self):
         """Sets probed, the one in use (0 = the original), their rates, the seconds the search took, how it ended
         (PLACEMENT_STATES), its peak transient holding of candidate sets and, when it ended short of a fast set, why."""
         t, k, s = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
         g = (ctypes.c_double * PLACEMENT_MAX_SETS)()
-        _check(self.lib, self.lib.brie_placement_info(self._h, ctypes.byref(t), ctypes.byref(k), g, ctypes.byref(s)))
+        _check(self.lib, self.lib.brie_placement_info(self._h, ctypes.byref(t), ctypes.byref(k), g, PLACEMENT_MAX_SETS, ctypes.byref(s)))
         st, peak, note = ctypes.c_int32(), ctypes.c_int64(), ctypes.create_string_buffer(192)
         _check(self.lib, self.lib.brie_placement_status(self._h, ctypes.byref(st), ctypes.byref(peak), note, 192))
         out = {"tries": t.value, "kept": k.value, "GBs": [round(g[i], 1) for i in range(t.value)],

@@ -31,10 +31,14 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in SOURCES + HEADERS)
 
 
-def compile_library(force=False, verbose=False, out=None, jobs=None):
+def compile_library(force=False, verbose=False, out=None, jobs=None, defines=None):
     """hipcc --offload-arch=gfx950 -> brie_amd/lib/libbrie_amd.so (cross-compiles without a GPU).
 
-    `out`: write the library somewhere else (a clean rebuild to compare with the shipped one)."""
+    `out`: write the library somewhere else (a clean rebuild to compare with the shipped one).
+    `defines`: extra -D macros for every unit of a VARIANT build (needs `out`; e.g. ['BRIE_TILE_PROF=1'] for
+    profiles/tile_phases.py, ['BRIE_LEANLOG_COND=false'] for an A/B of the MC_size 3 instantiations)."""
+    if defines and out is None:
+        raise ValueError("a variant build (defines=...) must not overwrite the shipped library: pass out=")
     if out is None and not force and not needs_build():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -45,7 +49,7 @@ def compile_library(force=False, verbose=False, out=None, jobs=None):
     obj_dir = os.path.join(HERE, "build", os.path.splitext(os.path.basename(out))[0])
     os.makedirs(obj_dir, exist_ok=True)
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + ["-D" + d for d in (defines or [])]
     units = [(os.path.join(CSRC, "brie_capi.hip"), os.path.join(obj_dir, "brie_capi.o"), []),
              (os.path.join(CSRC, "brie_comm.hip"), os.path.join(obj_dir, "brie_comm.o"), [])]   # RCCL, bound by dlopen
     for mode in range(3):             # MFMA tile kernel of the wide designs: one unit per likelihood mode

@@ -174,6 +174,17 @@ struct brie_handle {
     double placement_seconds = 0.0;
     int64_t placement_peak_bytes = 0;       // largest transient holding of candidate sets during a search
     char placement_note[192] = {0};         // why the search ended the way it did (brie_placement_status)
+    // many steps per launch (PERSIST variant of the step kernel; run_steps_persist)
+    int persist_mode = -1;                  // brie_set_step_fusion: -1 automatic, 0 never, 1 whenever the model allows it
+    bool any_frozen = false;                // a gene mask with frozen genes is set
+    brie::PersistArgs *persist_args = nullptr;
+    float *persist_alphas = nullptr, *partials2 = nullptr;
+    size_t persist_alphas_elems = 0, partials2_elems = 0;
+    uint32_t *persist_barrier = nullptr;
+    int64_t persist_launches = 0, persist_steps = 0;
+    int placement_cfg_sets = 0;             // brie_placement_configure: 0 = the library's default
+    double placement_cfg_frac = 0.0, placement_cfg_seconds = 0.0;
+    int placement_inject = 0;               // brie_debug_inject_placement_failure (tests): fails ONE search of this handle
 };
 
 namespace {
@@ -286,6 +297,8 @@ int alloc_f32(float **p, size_t elems, hipStream_t s) {
     return BRIE_OK;
 }
 
+int prepare_wide_panels(int device);       // (defined beside launch_panels)
+
 // decide the kernel family of this handle from (Kc, Kg, layout); called at create and at brie_reconfigure
 void setup_paths(brie_handle *h) {
     const int Kc = h->p.Kc;
@@ -383,6 +396,16 @@ int check_ready(const brie_handle *h) {
     if (!h->have_state)
         return fail(BRIE_ERR_STATE, "state not initialised: call brie_init_state or upload Z_loc..sigma_log");
     return BRIE_OK;
+}
+
+int launch_step_persist(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q, const brie::StepScalars &a,
+                        const brie::PersistArgs *dev_args, int n_cus) {
+    switch (h->kernel_kc) {
+#define BRIE_CASE(N) case N: return brie::launch_step_persist_kc##N(c, q, a, dev_args, n_cus);
+        BRIE_CASE(0) BRIE_CASE(1) BRIE_CASE(2) BRIE_CASE(3) BRIE_CASE(4) BRIE_CASE(5) BRIE_CASE(6) BRIE_CASE(7)
+#undef BRIE_CASE
+        default: return brie::launch_step_persist_kc8(c, q, a, dev_args, n_cus);
+    }
 }
 
 void launch_step(const brie_handle *h, const brie::LaunchCfg &c, const brie::StepPointers &q,
@@ -1100,6 +1123,7 @@ int brie_create(const brie_problem *p, brie_handle **out) {
     }
 #undef A
     setup_paths(h);                 // kernel family: register path, LDS-broadcast wide variants, or the MFMA tile kernel
+    if (h->vwide && prepare_wide_panels(h->p.device) != BRIE_OK) { drop_failed_create(h); return BRIE_ERR_UNSUPPORTED; }
     configure_tiling(h);
     {
         const char *pk = getenv("BRIE_PACK_ACTIVE");
@@ -1150,6 +1174,7 @@ int brie_reconfigure(brie_handle *h, int32_t Kc, uint64_t seed, int32_t train_in
     h->gpart_elems = h->rbuf_elems = 0;
     h->p.Kc = Kc; h->p.seed = seed; h->p.train_intercept = train_intercept; h->p.train_sigma = train_sigma;
     setup_paths(h);
+    if (h->vwide && (rc = prepare_wide_panels(h->p.device)) != BRIE_OK) return rc;
     configure_tiling(h);            // the rows per chunk follow the kernel family
     if (h->row_scratch) { HIP_TRY(hipFree(h->row_scratch)); h->row_scratch = nullptr; }   // sized by max(ring, Kc)
     h->have_xc = false;
@@ -1190,6 +1215,10 @@ int brie_destroy(brie_handle *h) {
     if (h->pack_scratch) hipFree(h->pack_scratch);
     if (h->row_scratch) hipFree(h->row_scratch);
     if (h->io_scratch) hipFree(h->io_scratch);
+    if (h->persist_args) hipFree(h->persist_args);
+    if (h->persist_alphas) hipFree(h->persist_alphas);
+    if (h->persist_barrier) hipFree(h->persist_barrier);
+    if (h->partials2) hipFree(h->partials2);
     if (h->win_scratch) hipFree(h->win_scratch);
     if (h->io_stream) hipStreamDestroy(h->io_stream);
     if (h->io_stream2) hipStreamDestroy(h->io_stream2);
@@ -1477,6 +1506,7 @@ int brie_set_gene_mask(brie_handle *h, const uint8_t *active) {
     HIP_TRY(hipMemcpyAsync(h->gene_active, mask.data(), mask.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->mask_host = mask;
+    h->any_frozen = any_frozen;
     if (any_frozen && h->allow_pack && !h->wide_like) {
         // pack: quads with an active gene first (stable), fully frozen quads after them; whole 256-gene
         // blocks at the tail then hold no active gene and are skipped by the kernels
@@ -1623,19 +1653,52 @@ void launch_panel(brie_handle *h, const float *X, int x_ld, const float *B, int 
 
 // dst (Nc, ld) tiled (+)= X . B over any number of features: more than 64 in ONE launch of fused_prior_mean (dst read at
 // most once, written once; round 4 launched once per 64-feature panel: 16.5 instead of 14.7 ms per step at Kc = 128, call r5m)
+// fused_prior_mean keeps two stages of tiles in 140 KB of dynamic LDS: the attribute that allows it belongs to the DEVICE, so it
+// is set once per device -- when the first handle that can need it is created (prepare_wide_panels: a device with less LDS is
+// refused there with a message that says so, not by a generic launch error a fit later) -- together with the CU count the
+// persistent grid is sized by.  g_panel_cus[d]: 0 = not asked yet, > 0 = compute units, < 0 = the device cannot run the kernel.
+// compute units of a device (cached; the PERSIST launch must fit the device at once)
+int device_cus(int device) {
+    static std::atomic<int> cus[64];
+    int n = cus[device & 63].load(std::memory_order_acquire);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+        (void)hipGetLastError();
+        cus[device & 63].store(n, std::memory_order_release);
+    }
+    return n;
+}
+std::atomic<int> g_panel_cus[64];
+int panel_device_cus(int device) { return g_panel_cus[device & 63].load(std::memory_order_acquire); }
+int prepare_wide_panels(int device) {
+    int cur = panel_device_cus(device);
+    if (cur == 0) {
+        static std::mutex mu;
+        std::lock_guard<std::mutex> l(mu);
+        cur = panel_device_cus(device);
+        if (cur == 0) {
+            hipDeviceProp_t prop;
+            const hipError_t e1 = hipGetDeviceProperties(&prop, device);
+            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(brie::fused_prior_mean),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, brie::kFpmLdsBytes);
+            (void)hipGetLastError();
+            cur = (e1 == hipSuccess && e2 == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : -1;
+            g_panel_cus[device & 63].store(cur, std::memory_order_release);
+        }
+    }
+    if (cur < 0)
+        return fail(BRIE_ERR_UNSUPPORTED, "designs beyond 64 features need %d KB of LDS per workgroup (gfx950 has 160 KB): device %d "
+                                          "does not grant it", brie::kFpmLdsBytes / 1024, device);
+    return BRIE_OK;
+}
+
 void launch_panels(brie_handle *h, const float *X, int x_ld, const float *B, int K, float *dst, bool accumulate) {
     if (K > 64) {
         // persistent: one workgroup per CU walks the (gene block x 256-cell block) tiles round-robin
-        static int cus[64] = {};
-        int &n_cu = cus[h->p.device & 63];
-        if (n_cu == 0) {
-            hipDeviceProp_t prop;
-            n_cu = hipGetDeviceProperties(&prop, h->p.device) == hipSuccess ? prop.multiProcessorCount : 256;
-        }
+        const int n_cu = panel_device_cus(h->p.device);     // > 0: prepare_wide_panels ran at create and checked the device
         const int64_t n_tiles = static_cast<int64_t>(h->gene_blocks) * ((h->p.Nc + brie::kFpmWaves * 32 - 1) / (brie::kFpmWaves * 32));
-        const dim3 grid(static_cast<unsigned>(std::min<int64_t>(n_tiles, n_cu)));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(brie::fused_prior_mean), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  brie::kFpmLdsBytes);
+        const dim3 grid(static_cast<unsigned>(std::min<int64_t>(n_tiles, n_cu > 0 ? n_cu : 256)));
         hipLaunchKernelGGL(brie::fused_prior_mean, grid, dim3(brie::kFpmWaves * brie::kWave), brie::kFpmLdsBytes, h->stream, X, B, dst,
                            static_cast<int>(h->p.Nc), K, h->ld, h->row_stride, h->gb_stride, accumulate ? 1 : 0, x_ld, h->gene_blocks);
         return;
@@ -1787,12 +1850,16 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
     max_sets = std::max(1, std::min(max_sets, static_cast<int>(BRIE_PLACEMENT_MAX_SETS)));
     // BRIE_PLACEMENT_INTERLEAVE=0: candidate sets one after the other, each allocated as a block (A/B runs; the first version)
     static const bool interleave = [] { const char *e = getenv("BRIE_PLACEMENT_INTERLEAVE"); return !(e && e[0] == '0'); }();
-    static const double max_seconds = [] { const char *e = getenv("BRIE_PLACEMENT_SECONDS"); return e ? atof(e) : 3.0; }();
-    static const double frac = [] {
+    static const double env_seconds = [] { const char *e = getenv("BRIE_PLACEMENT_SECONDS"); return e ? atof(e) : 3.0; }();
+    static const double env_frac = [] {
         const char *e = getenv("BRIE_PLACEMENT_HBM_FRACTION");
         const double f = e ? atof(e) : 0.8;
         return f < 0.0 ? 0.0 : (f > 1.0 ? 1.0 : f);
     }();
+    // per handle (brie_placement_configure) before the process environment: several ranks that share one GPU size their
+    // rounds on the same hipMemGetInfo reading without knowing of each other -- their caller does, and divides the fraction
+    const double max_seconds = h->placement_cfg_seconds > 0.0 ? h->placement_cfg_seconds : env_seconds;
+    const double frac = h->placement_cfg_frac > 0.0 ? std::min(1.0, h->placement_cfg_frac) : env_frac;
     const auto t0 = std::chrono::steady_clock::now();
     auto elapsed = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     HIP_TRY(hipStreamSynchronize(h->stream));               // the caller's earlier work: its errors are its own
@@ -1808,10 +1875,10 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
         h->placement_seconds += elapsed();
         return BRIE_OK;
     };
-    // test hook (tests/test_gpu_placement.py): BRIE_PLACEMENT_INJECT_FAILURE = 1 the first probe, 2 a candidate allocation,
-    // 3 a candidate's probe, 4 a candidate copy fails -- read at every search, so a test can set it for one handle
-    const char *inj_s = getenv("BRIE_PLACEMENT_INJECT_FAILURE");
-    const int inject = inj_s ? atoi(inj_s) : 0;
+    // tests (brie_debug_inject_placement_failure, an explicit call on ONE handle -- nothing in the environment can switch it on):
+    // 1 the first probe, 2 a candidate allocation, 3 a candidate's probe, 4 a candidate copy fails in this search
+    const int inject = h->placement_inject;
+    h->placement_inject = 0;
     const int iters = 3;
     double best = 0.0;
     if (inject == 1 || probe_rate(h, iters, &best, two_per_cu) != BRIE_OK) {      // the arrays stay where they are
@@ -1861,20 +1928,25 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
         held.resize(base + static_cast<size_t>(n_round));
         for (size_t k = base; k < held.size(); ++k) { held[k].n = first.n; for (int i = 0; i < first.n; ++i) held[k].bytes[i] = first.bytes[i]; }
         hipError_t e = hipSuccess;
+        bool out_of_time = false;                  // the limit is looked at after EVERY allocation (a slow allocator: seconds each)
+        auto alloc = [&](size_t k, int i) {
+            e = hipMalloc(&held[k].p[i], first.bytes[i]);
+            if (e == hipSuccess && elapsed() > max_seconds) out_of_time = true;
+        };
         if (interleave) {
-            for (int i = 0; i < first.n && e == hipSuccess; ++i)
-                for (size_t k = base; k < held.size() && e == hipSuccess; ++k) e = hipMalloc(&held[k].p[i], first.bytes[i]);
+            for (int i = 0; i < first.n && e == hipSuccess && !out_of_time; ++i)
+                for (size_t k = base; k < held.size() && e == hipSuccess && !out_of_time; ++k) alloc(k, i);
         } else {
-            for (size_t k = base; k < held.size() && e == hipSuccess; ++k)
-                for (int i = 0; i < first.n && e == hipSuccess; ++i) e = hipMalloc(&held[k].p[i], first.bytes[i]);
+            for (size_t k = base; k < held.size() && e == hipSuccess && !out_of_time; ++k)
+                for (int i = 0; i < first.n && e == hipSuccess && !out_of_time; ++i) alloc(k, i);
         }
         if (inject == 2 && e == hipSuccess) e = hipErrorOutOfMemory;
-        if (e != hipSuccess) {                     // someone else took the memory in between: search over, keep the best so far
-            (void)hipGetLastError();
+        if (e != hipSuccess || out_of_time) {      // someone else took the memory in between, or the allocator is slow today:
+            (void)hipGetLastError();               // search over, keep the best so far
             for (size_t k = base; k < held.size(); ++k) drop(held[k]);
             held.resize(base);
-            note("candidate allocation failed", hipGetErrorString(e));
-            status = BRIE_PLACEMENT_STOPPED_MEMORY;
+            if (e != hipSuccess) note("candidate allocation failed", hipGetErrorString(e));
+            status = e != hipSuccess ? BRIE_PLACEMENT_STOPPED_MEMORY : BRIE_PLACEMENT_STOPPED_TIME;
             break;
         }
         h->placement_peak_bytes = std::max<int64_t>(h->placement_peak_bytes, static_cast<int64_t>(held.size() * total));
@@ -1883,6 +1955,10 @@ int tune_placement(brie_handle *h, int max_sets, double good_gbs, bool two_per_c
             if (k > base && elapsed() > max_seconds) { status = BRIE_PLACEMENT_STOPPED_TIME; break; }
             for (int i = 0; i < first.n && e == hipSuccess; ++i)
                 e = hipMemcpyAsync(held[k].p[i], first.p[i], first.bytes[i], hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess && k > base) {     // copies are asynchronous: the limit is looked at once they have run
+                e = hipStreamSynchronize(h->stream);
+                if (e == hipSuccess && elapsed() > max_seconds) { status = BRIE_PLACEMENT_STOPPED_TIME; break; }
+            }
             if (inject == 4 && e == hipSuccess) e = hipErrorInvalidValue;
             if (e != hipSuccess) { note("placement copy failed", hipGetErrorString(e)); status = BRIE_PLACEMENT_STOPPED_ERROR; break; }
             adopt_set(h, held[k]);
@@ -1939,10 +2015,17 @@ constexpr double kPlacementGoodSmallGBs = 5850.0;
 int auto_placement(brie_handle *h, int mc_size) {
     if (h->placement_done) return BRIE_OK;
     h->placement_done = true;
-    static const int tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : static_cast<int>(BRIE_PLACEMENT_MAX_SETS); }();
+    // sets in all: the caller's (brie_placement_configure), else BRIE_PLACEMENT_TRIES, else ONE round for arrays of a gigabyte
+    // and more -- the first set + three candidates: up to 3 x the streamed bytes held for the search; every one of
+    // round 5's 42 fresh processes ended `good` inside its first round -- and all eight for smaller arrays, whose candidates
+    // come one at a time and cost 2.5 GB and 3 ms each at configs[1] (where most sets of a process read ~5.0 TB/s and one or
+    // two of eight 5.6 - 6.0: calls r6a, r6b)
+    static const int env_tries = [] { const char *e = getenv("BRIE_PLACEMENT_TRIES"); return e ? atoi(e) : 0; }();
+    const int cls = placement_class(h);
+    const int tries = h->placement_cfg_sets > 0 ? h->placement_cfg_sets
+                                                : (env_tries > 0 ? env_tries : (cls == 1 ? static_cast<int>(BRIE_PLACEMENT_MAX_SETS) : 4));
     if (tries <= 1 || brie_step_storage_bytes(h) < (int64_t(256) << 20)) { h->placement_status = BRIE_PLACEMENT_OFF; return BRIE_OK; }
     static const double good_env = [] { const char *e = getenv("BRIE_PLACEMENT_GOOD_GBS"); return e ? atof(e) : 0.0; }();
-    const int cls = placement_class(h);
     double good = good_env > 0.0 ? good_env : (cls == 1 ? kPlacementGoodSmallGBs : kPlacementGoodGBs);
     if (good_env <= 0.0) {
         std::lock_guard<std::mutex> l(g_place_mu);
@@ -2056,7 +2139,53 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         const double tt = static_cast<double>(t);
         return static_cast<float>(static_cast<double>(lr) * std::sqrt(1.0 - std::pow(0.999, tt)) / (1.0 - std::pow(0.9, tt)));
     };
-    for (int i = 0; i < n_steps; ++i) {
+    // Small inputs: the n_steps steps as ONE launch (PERSIST variant; state, loss trace and loss ring as the loop below leaves
+    // them, bit for bit).  Allowed for an uncoupled model with Kc <= 8, ELBO target, no frozen gene, MC_size 1 or 3 and a grid the
+    // device holds at once; AUTOMATIC only where it was measured faster than two launches per step (calls r6k, r6l): at most 16
+    // cell chunks (every workgroup of a gene block re-reads all of the block's chunk rows: the cost grows with their square)
+    // and at most a quarter of the CUs busy -- configs[0]: 9.6 against 11.2 us per step; 300 x 2000: 14.1 against 12.2, so not there.
+    int i_start = 0;
+    {
+        static const int env_mode = [] { const char *e = getenv("BRIE_FUSE_STEPS"); return e ? atoi(e) : -1; }();
+        const int mode = h->persist_mode >= 0 ? h->persist_mode : env_mode;
+        const bool can = !h->coupled && !h->wide_like && h->target == 0 && !split && !h->profiling && !h->any_frozen && !h->packed &&
+                         (mc_size == 1 || mc_size == 3) && n_steps >= 2;
+        const bool want = mode == 1 || (mode < 0 && h->n_chunks <= 16 &&
+                                        static_cast<int64_t>(h->n_chunks) * h->gene_blocks * 4 <= device_cus(h->p.device));
+        if (can && want) {
+            const size_t pneed = static_cast<size_t>(h->n_chunks) * h->S * h->ld;
+            if ((rc = ensure_f32(&h->partials2, &h->partials2_elems, pneed, h->stream)) != BRIE_OK) return rc;
+            if ((rc = ensure_f32(&h->persist_alphas, &h->persist_alphas_elems, static_cast<size_t>(n_steps), h->stream)) != BRIE_OK) return rc;
+            if (!h->persist_args) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->persist_args), sizeof(brie::PersistArgs)));
+            if (!h->persist_barrier) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->persist_barrier), sizeof(uint32_t) * h->gene_blocks));
+            std::vector<float> alphas(static_cast<size_t>(n_steps));
+            for (int i = 0; i < n_steps; ++i) alphas[i] = adam_alpha(h->t + 1 + i);
+            brie::PersistArgs pa{};
+            pa.alphas = h->persist_alphas; pa.barrier = h->persist_barrier; pa.partials2 = h->partials2;
+            pa.W = h->W; pa.m_W = h->m_W; pa.v_W = h->v_W; pa.b = h->b; pa.m_b = h->m_b; pa.v_b = h->v_b;
+            pa.lam = h->lam; pa.m_lam = h->m_lam; pa.v_lam = h->v_lam; pa.ring_kl = h->ring_kl; pa.ring_ll = h->ring_ll;
+            pa.loss_parts = h->loss_parts; pa.n_steps = n_steps;
+            pa.ring_pos0 = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
+            pa.train_b = f.train_b; pa.train_lam = f.train_lam; pa.fin_Ng = f.Ng;
+            { const char *dbg = getenv("BRIE_FUSE_DEBUG"); pa.debug = dbg ? atoi(dbg) : 0; }
+            HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(hipMemsetAsync(h->persist_barrier, 0, sizeof(uint32_t) * h->gene_blocks, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));      // `alphas` and `pa` are pageable host memory of this frame
+            a.alpha = alphas[0];
+            a.draw = h->draw;
+            const int n_cus = device_cus(h->p.device);
+            if (h->fin_blocks == h->gene_blocks && launch_step_persist(h, cfg, q, a, h->persist_args, n_cus) == 1) {
+                h->t += n_steps;
+                h->draw += static_cast<uint32_t>(n_steps);
+                h->ring_pos += n_steps;
+                h->persist_launches += 1;
+                h->persist_steps += n_steps;
+                i_start = n_steps;
+            }
+        }
+    }
+    for (int i = i_start; i < n_steps; ++i) {
         h->t += 1;
         const float alpha = adam_alpha(h->t);
         a.alpha = alpha; f.alpha = alpha; cf.alpha = alpha;
@@ -2683,12 +2812,44 @@ int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs) {
     return tune_placement(h, max_tries, good_gbs, false);
 }
 
-int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds) {
+int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, int32_t n_gbs, double *seconds) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (gbs && n_gbs < 0) return fail(BRIE_ERR_INVALID, "n_gbs=%d", n_gbs);
     if (tries) *tries = h->placement_tries;
     if (kept) *kept = h->placement_kept;
-    if (gbs) for (int i = 0; i < BRIE_PLACEMENT_MAX_SETS; ++i) gbs[i] = h->placement_gbs[i];
+    if (gbs) for (int i = 0; i < n_gbs; ++i) gbs[i] = i < BRIE_PLACEMENT_MAX_SETS ? h->placement_gbs[i] : 0.0;   // the caller's capacity
     if (seconds) *seconds = h->placement_seconds;
+    return BRIE_OK;
+}
+
+int brie_set_step_fusion(brie_handle *h, int32_t mode) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (mode < -1 || mode > 1) return fail(BRIE_ERR_INVALID, "mode=%d (-1 automatic, 0 off, 1 on)", mode);
+    h->persist_mode = mode;
+    return BRIE_OK;
+}
+
+int brie_step_fusion_info(const brie_handle *h, int64_t *launches, int64_t *steps) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (launches) *launches = h->persist_launches;
+    if (steps) *steps = h->persist_steps;
+    return BRIE_OK;
+}
+
+int brie_placement_configure(brie_handle *h, int32_t max_sets, double hbm_fraction, double max_seconds) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (max_sets > BRIE_PLACEMENT_MAX_SETS || hbm_fraction > 1.0)
+        return fail(BRIE_ERR_INVALID, "max_sets=%d (at most %d) hbm_fraction=%g (at most 1)", max_sets, BRIE_PLACEMENT_MAX_SETS, hbm_fraction);
+    h->placement_cfg_sets = max_sets > 0 ? max_sets : 0;
+    h->placement_cfg_frac = hbm_fraction > 0.0 ? hbm_fraction : 0.0;
+    h->placement_cfg_seconds = max_seconds > 0.0 ? max_seconds : 0.0;
+    return BRIE_OK;
+}
+
+int brie_debug_inject_placement_failure(brie_handle *h, int32_t point) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (point < 0 || point > 4) return fail(BRIE_ERR_INVALID, "point=%d (0 = none, 1 .. 4)", point);
+    h->placement_inject = point;
     return BRIE_OK;
 }
 
@@ -2814,7 +2975,30 @@ int brie_probe_vmm(int32_t device, int64_t Nc, int64_t Ng, int32_t n_layers, int
                 handles.push_back(hd);
                 e = hipMemMap(va[i] + c * chunk, chunk, 0, hd, 0);
             };
-            if (order[l] == 0) {
+            if (order[l] == 3 || order[l] == 4) {
+                // 3 "spread": every array ONE physical allocation, a spacer of chunk_bytes (physical memory that is created, never
+                // mapped, and released before the probe) between consecutive arrays; 4 "skip": one such spacer first, then the
+                // arrays back to back -- where in physical memory a packed set sits, if the driver hands memory out in order
+                std::vector<hipMemGenericAllocationHandle_t> spacers;
+                auto spacer = [&]() {
+                    hipMemGenericAllocationHandle_t hd;
+                    e = hipMemCreate(&hd, chunk, &prop, 0);
+                    if (e == hipSuccess) spacers.push_back(hd);
+                };
+                if (order[l] == 4) spacer();
+                for (int i = 0; i < n_arr && e == hipSuccess; ++i) {
+                    (void)hipMemAddressFree(va[i], vsz[i]);
+                    vsz[i] = static_cast<size_t>(round_up(bytes[i], static_cast<int64_t>(gran)));
+                    e = hipMemAddressReserve(reinterpret_cast<void **>(&va[i]), vsz[i], gran, nullptr, 0);
+                    hipMemGenericAllocationHandle_t hd;
+                    if (e == hipSuccess) e = hipMemCreate(&hd, vsz[i], &prop, 0);
+                    if (e != hipSuccess) break;
+                    handles.push_back(hd);
+                    e = hipMemMap(va[i], vsz[i], 0, hd, 0);
+                    if (order[l] == 3 && i + 1 < n_arr && e == hipSuccess) spacer();
+                }
+                for (auto hd : spacers) (void)hipMemRelease(hd);
+            } else if (order[l] == 0) {
                 for (int i = 0; i < n_arr && e == hipSuccess; ++i)
                     for (size_t c = 0; c < n_chunks[i] && e == hipSuccess; ++c) map_one(i, c);
             } else {

@@ -104,6 +104,38 @@ void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
     else step_mc<MODE, kCountF32>(c, q, a, cp);
 }
 
+// Many steps per launch (PERSIST variant, brie_kernels.hip.h): every workgroup of the grid must be resident -- they wait for
+// each other -- so the launch is made only when the occupancy the runtime reports for this instantiation holds the whole grid
+// (returns 0 otherwise and the caller takes the two-launch path).  MC_size 1 and 3 (the API's and brie-quant's defaults).
+template <int MODE, int MC, int CS>
+int persist_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const PersistArgs *dev_args, int n_cus) {
+    auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, false, false, false, false, true>;
+    static const int per_cu = [&] {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), kBlock, 0) != hipSuccess) nb = 0;
+        (void)hipGetLastError();
+        return nb;
+    }();
+    if (static_cast<int64_t>(c.grid.x) * c.grid.y > static_cast<int64_t>(per_cu) * n_cus) return 0;
+    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho,
+                       q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, CoupledArgs{},
+                       reinterpret_cast<float *>(const_cast<PersistArgs *>(dev_args)));
+    return 1;
+}
+template <int MODE, int CS>
+int persist_mc(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const PersistArgs *d, int n_cus) {
+    if (a.mc == 1) return persist_launch<MODE, 1, CS>(c, q, a, d, n_cus);
+    if (a.mc == 3) return persist_launch<MODE, 3, CS>(c, q, a, d, n_cus);
+    return 0;
+}
+template <int MODE>
+int persist_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const PersistArgs *d, int n_cus) {
+    if (c.cs == kCountU8) return persist_mc<MODE, kCountU8>(c, q, a, d, n_cus);
+    if (c.cs == kCountMixed) return persist_mc<MODE, kCountMixed>(c, q, a, d, n_cus);
+    if (c.cs == kCountU16) return 0;            // (every quad with counts > 255: not instantiated, the two-launch path)
+    return persist_mc<MODE, kCountF32>(c, q, a, d, n_cus);
+}
+
 template <int MODE, int CS>
 void lg_launch(const LaunchCfg &c, const LossGeneArgs &a) {
     hipLaunchKernelGGL((loss_gene_eval<BRIE_KC, MODE, CS>), c.grid, dim3(kBlock), 0, c.stream, a);
@@ -147,6 +179,15 @@ void BRIE_CAT(launch_step_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q
         case kLik2: step_cs<kLik2>(c, q, a, cp); break;
         case kLikEff2: step_cs<kLikEff2>(c, q, a, cp); break;
         default: step_cs<kLikEff3>(c, q, a, cp); break;
+    }
+}
+
+int BRIE_CAT(launch_step_persist_kc, BRIE_KC)(const LaunchCfg &c, const StepPointers &q, const StepScalars &a,
+                                              const PersistArgs *dev_args, int n_cus) {
+    switch (c.mode) {
+        case kLik2: return persist_cs<kLik2>(c, q, a, dev_args, n_cus);
+        case kLikEff2: return persist_cs<kLikEff2>(c, q, a, dev_args, n_cus);
+        default: return persist_cs<kLikEff3>(c, q, a, dev_args, n_cus);
     }
 }
 

@@ -568,6 +568,19 @@ __device__ __forceinline__ void adam_scalar(float &x, float &m, float &v, float 
     v += (g * g - v) * kOneMinusB2;
     x -= (m * alpha) / (sqrtf(v) + kAdamEps);
 }
+// The same update with every rounding SPELLED OUT, for the per-gene parameters (gene_finalize and the finalize phase of the
+// PERSIST step kernel, which must agree bit for bit although they are compiled in different kernels): which products the
+// compiler contracts into fused multiply-adds depends on what else it finds around them -- in gene_finalize the first
+// moment's  m + (g - m) (1 - b1)  was NOT fused (its add was packed with another one), the second moment's two products
+// were.  This is that arithmetic, by construction: the bits of rounds 1 - 5.
+__device__ __forceinline__ void adam_scalar_exact(float &x, float &m, float &v, float g, float alpha) {
+#pragma clang fp contract(off)
+    const float dm = (g - m) * kOneMinusB1;
+    m = m + dm;
+    v = __builtin_fmaf(__builtin_fmaf(g, g, -v), kOneMinusB2, v);
+    const float num = m * alpha, den = sqrtf(v) + kAdamEps;
+    x = x - num / den;
+}
 
 // statistic s of gene j: the chunk partials summed in fp64 in chunk order, then what the statistic is for -- Adam on a
 // Wc_loc entry / the intercept (clip) / sigma_log, or the gene's KL / ll term into the loss ring.  Returns the sum
@@ -598,19 +611,19 @@ __device__ __forceinline__ double finalize_gene_stat(const FinalizeArgs &a, int 
         if (s < a.Kc) {
             const int64_t o = static_cast<int64_t>(s) * a.ld + j;
             float x = a.W[o], m = a.m_W[o], v = a.v_W[o];
-            adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);            // dL/dW = -Xc^T r
+            adam_scalar_exact(x, m, v, static_cast<float>(-t), a.alpha);            // dL/dW = -Xc^T r
             a.W[o] = x; a.m_W[o] = m; a.v_W[o] = v;
         } else if (s == a.Kc) {
             if (a.train_b) {
                 float x = a.b[j], m = a.m_b[j], v = a.v_b[j];
-                adam_scalar(x, m, v, static_cast<float>(-t), a.alpha);        // dL/db = -sum r
+                adam_scalar_exact(x, m, v, static_cast<float>(-t), a.alpha);        // dL/db = -sum r
                 x = fminf(fmaxf(x, -9.0f), 9.0f);
                 a.b[j] = x; a.m_b[j] = m; a.v_b[j] = v;
             }
         } else if (s == a.Kc + 1) {
             if (a.train_lam) {
                 float x = a.lam[j], m = a.m_lam[j], v = a.v_lam[j];
-                adam_scalar(x, m, v, static_cast<float>(t), a.alpha);
+                adam_scalar_exact(x, m, v, static_cast<float>(t), a.alpha);
                 a.lam[j] = x; a.m_lam[j] = m; a.v_lam[j] = v;
             }
         } else {
@@ -659,8 +672,30 @@ __device__ __forceinline__ double block_sum_f64(double *sh, double t) {
 #ifndef BRIE_TWO_WAVES_COND
 #define BRIE_TWO_WAVES_COND (MC == 3 && KC <= 7)
 #endif
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
-__global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_adam_step(
+// PERSIST (round 6): MANY Adam steps in ONE launch for inputs whose step is launch-bound (hundreds of cells: the two
+// dependent launches of a step, elbo_adam_step + gene_finalize, cost 11 - 18 us whatever they compute).  The grid is the step's
+// own -- (gene blocks, cell chunks), every workgroup resident -- and so is the arithmetic, operation for operation: per step the
+// workgroups write their chunk's partial row as before, meet at a barrier of THEIR GENE BLOCK (genes are independent: an atomic
+// counter per block, release / acquire at agent scope), and then every workgroup of the block runs gene_finalize's per-gene
+// work for the block's 256 genes itself -- the chunk partials summed in fp64 in chunk order, Keras Adam for Wc_loc, intercept
+// (clip) and sigma_log -- on a copy of the per-gene parameters and moments in LDS.  All copies are the same bits, so no second
+// barrier is needed; the partials are double-buffered (a workgroup that is one step ahead writes the other buffer).  Chunk 0's
+// workgroup alone writes the loss partials and the loss ring of the step and, after the last step, the parameters and moments.
+// State bit-identical to the two-launch path (tests/test_gpu_parity.py::test_many_steps_per_launch_*).  Uncoupled models with
+// Kc <= 8, ELBO target; the arguments travel through `rbuf` (a PersistArgs in device memory).
+struct PersistArgs {
+    const float *alphas;        // (n_steps) lr * sqrt(1 - b2^t) / (1 - b1^t) of every step
+    uint32_t *barrier;          // (gene_blocks) zeroed before the launch
+    float *partials2;           // the second partials buffer (odd steps)
+    float *W, *m_W, *v_W, *b, *m_b, *v_b, *lam, *m_lam, *v_lam;
+    float *ring_kl, *ring_ll;   // (kLossRing, ld)
+    double *loss_parts;         // (n_steps, gene_blocks, 2)
+    int32_t n_steps, ring_pos0, train_b, train_lam, fin_Ng;
+    int32_t debug;              // experiments (BRIE_FUSE_DEBUG; results are then wrong): 1 no barrier wait, 2 no finalize, 4 no rows
+};
+
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false, bool PERSIST = false>
+__global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
@@ -697,6 +732,32 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
     const int row0 = blockIdx.y * a.rows_per_chunk;
     const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
     if (a.block_active[gb] == 0) return;                 // whole gene block frozen (workgroup-uniform)
+    static_assert(!PERSIST || (!CPL && !WIDE && !GW && !MARGIN), "many steps per launch: uncoupled models, Kc <= 8, ELBO");
+    // PERSIST: per-gene parameters and their Adam moments of the block's 256 genes, [3 x (KC + 2)][256]: x, m, v of Wc_loc rows,
+    // intercept, sigma_log -- read by the row phase (lane l: genes 4l .. 4l+3), updated by the finalize phase (thread t: gene t)
+    __shared__ float pstate[PERSIST ? 3 * (KC + 2) * kGenesPerBlock : 1];
+    __shared__ double psum[PERSIST ? kBlock : 1];
+    const PersistArgs *ps = reinterpret_cast<const PersistArgs *>(rbuf);
+    if constexpr (PERSIST) {
+        const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            pstate[(3 * k + 0) * kGenesPerBlock + threadIdx.x] = ps->W[k * a.ld + jj];
+            pstate[(3 * k + 1) * kGenesPerBlock + threadIdx.x] = ps->m_W[k * a.ld + jj];
+            pstate[(3 * k + 2) * kGenesPerBlock + threadIdx.x] = ps->v_W[k * a.ld + jj];
+        }
+        pstate[(3 * KC + 0) * kGenesPerBlock + threadIdx.x] = ps->b[jj];
+        pstate[(3 * KC + 1) * kGenesPerBlock + threadIdx.x] = ps->m_b[jj];
+        pstate[(3 * KC + 2) * kGenesPerBlock + threadIdx.x] = ps->v_b[jj];
+        pstate[(3 * KC + 3) * kGenesPerBlock + threadIdx.x] = ps->lam[jj];
+        pstate[(3 * KC + 4) * kGenesPerBlock + threadIdx.x] = ps->m_lam[jj];
+        pstate[(3 * KC + 5) * kGenesPerBlock + threadIdx.x] = ps->v_lam[jj];
+        __syncthreads();
+    }
+    const int n_it = PERSIST ? ps->n_steps : 1;
+    for (int it = 0; it < n_it; ++it) {
+    const float alpha_it = PERSIST ? ps->alphas[it] : a.alpha;
+    const uint32_t draw_it = PERSIST ? a.draw + static_cast<uint32_t>(it) : a.draw;
     if constexpr (WIDE) {
         for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
             wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
@@ -717,7 +778,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
     // coupled / wide variants: every lane runs (the wave reduces over its 256 genes, resp. lane k carries
     // feature k of the cell's design row for v_readlane); lanes beyond Ng work on the zero padding of the
     // gene block, contribute nothing and store nothing
-    if ((CPL || WIDE || active) && row0 + w < row_end) {
+    if ((CPL || WIDE || active) && row0 + w < row_end && !(PERSIST && (ps->debug & 4))) {
         // per-gene parameters, live across the whole chunk
         float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
         float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
@@ -733,12 +794,13 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
-            const F4 t = ld4(Wp + k * a.ld + j0);
+            const F4 t = PERSIST ? ld4(pstate + (3 * k) * kGenesPerBlock + lane * kVec) : ld4(Wp + k * a.ld + j0);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
         }
         {
-            const F4 tb = ld4(bp + j0), tl = ld4(lamp + j0);
+            const F4 tb = PERSIST ? ld4(pstate + (3 * KC) * kGenesPerBlock + lane * kVec) : ld4(bp + j0),
+                     tl = PERSIST ? ld4(pstate + (3 * KC + 3) * kGenesPerBlock + lane * kVec) : ld4(lamp + j0);
 #pragma unroll
             for (int v = 0; v < kVec; ++v) {
                 bj[v] = tb.v[v];
@@ -903,7 +965,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                 }
                 for (int k = 0; k < a.mc; ++k) {
                     float e[kVec];
-                    normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+                    normal4(gquad, static_cast<uint32_t>(r), draw_it, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
 #pragma unroll
                     for (int v = 0; v < kVec; ++v) {
                         float l, g;
@@ -931,7 +993,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
 
                 auto sample = [&](uint32_t k) {
                     float e[kVec];
-                    normal4(gquad, static_cast<uint32_t>(r), a.draw, k, a.seed_lo, a.seed_hi, e);
+                    normal4(gquad, static_cast<uint32_t>(r), draw_it, k, a.seed_lo, a.seed_hi, e);
 #pragma unroll
                     for (int v = 0; v < kVec; ++v) {
                         const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
@@ -952,7 +1014,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
 #pragma unroll
                     for (int k = 0; k < MC; ++k) {
                         float e[kVec];
-                        normal4(gquad, static_cast<uint32_t>(r), a.draw, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
+                        normal4(gquad, static_cast<uint32_t>(r), draw_it, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
 #pragma unroll
                         for (int p = 0; p < 2; ++p) {
                             const int u = 2 * p, w = 2 * p + 1;
@@ -1018,9 +1080,9 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                     const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
                     const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
                     const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
-                    float nmu = adam_update(R.mu.v[v], n_mm, n_vm, a.alpha);
+                    float nmu = adam_update(R.mu.v[v], n_mm, n_vm, alpha_it);
                     nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                          // clip constraint
-                    const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, a.alpha);
+                    const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, alpha_it);
                     if constexpr (FRZ) {
                         R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
                         R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
@@ -1172,8 +1234,9 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                 red[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
     }
     __syncthreads();
+    float *const part_it = (PERSIST && (it & 1)) ? ps->partials2 : partials;
     if (w == 0 && active) {
-        float *dst = partials + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
+        float *dst = part_it + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             F4 o;
@@ -1185,7 +1248,108 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
                     t += red[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
                 o.v[v] = t;
             }
-            st4(dst + s * a.ld, o);
+            if constexpr (PERSIST) {       // write-through (sc1): leaves this XCD's L2 at once, no release fence needed later
+                const floatx4 t4 = {o.v[0], o.v[1], o.v[2], o.v[3]};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + s * a.ld), "v"(t4) : "memory");
+            } else {
+                st4(dst + s * a.ld, o);
+            }
+        }
+    }
+    if constexpr (PERSIST) {
+        // ---- barrier of the gene block: every chunk's partial row of this step is in memory.  Per-XCD L2s are not coherent with
+        // each other and a CU's L1 is never refreshed by another CU's stores, and the fences that would make plain accesses
+        // safe cost microseconds each (L2 write-back, L1 invalidate) -- so the rows are PUBLISHED write-through (sc1 stores,
+        // drained with s_waitcnt before the arrival) and READ with sc1 loads that bypass L1; the counter is an agent-scope atomic
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ps->barrier + gb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = static_cast<uint32_t>(it + 1) * gridDim.y;
+            while (!(ps->debug & 1) && __hip_atomic_load(ps->barrier + gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        // ---- gene_finalize's work for gene t of the block, on the LDS copy (finalize_gene_stat, statistic by statistic)
+        const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
+        const int slot = (ps->ring_pos0 + it) % kLossRing, prev = (slot + kLossRing - 1) % kLossRing;
+        const bool first = blockIdx.y == 0;                 // this workgroup also writes what the step leaves in memory
+        double t_kl = 0.0, t_ll = 0.0;
+        if (jj < ps->fin_Ng && !(ps->debug & 2)) {
+            if (a.gene_active[jj] == 0.0f) {                // frozen gene: parameters untouched, last loss terms carried forward
+                const float lk = ps->ring_kl[static_cast<int64_t>(prev) * a.ld + jj], ll_ = ps->ring_ll[static_cast<int64_t>(prev) * a.ld + jj];
+                if (first) {
+                    ps->ring_kl[static_cast<int64_t>(slot) * a.ld + jj] = lk;
+                    ps->ring_ll[static_cast<int64_t>(slot) * a.ld + jj] = ll_;
+                }
+                t_kl = static_cast<double>(lk); t_ll = static_cast<double>(ll_);
+            } else {
+                const int64_t stride = static_cast<int64_t>(S) * a.ld;
+                const int n_chunks = static_cast<int>(gridDim.y);
+                // the chunk partials of all S statistics, eight chunks of every statistic in flight at once (the loads are L2
+                // round trips: one after the other they were most of a step), summed in fp64 in chunk order as gene_finalize does
+                double tsum[S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) tsum[s] = 0.0;
+                for (int c0 = 0; c0 < n_chunks; c0 += 8) {
+                    float xv[S][8];
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            xv[s][u] = __hip_atomic_load(part_it + static_cast<int64_t>(s) * a.ld + jj + min(c0 + u, n_chunks - 1) * stride,
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no guarded load: they serialise)
+#pragma unroll
+                    for (int s = 0; s < S; ++s)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (c0 + u < n_chunks) tsum[s] += static_cast<double>(xv[s][u]);
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const double t = tsum[s];
+                    float *x = pstate + (3 * s) * kGenesPerBlock + threadIdx.x;          // x, m, v of parameter s (s < KC + 2)
+                    if (s < KC) {
+                        adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(-t), alpha_it);
+                    } else if (s == KC) {
+                        if (ps->train_b) {
+                            adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(-t), alpha_it);
+                            x[0] = fminf(fmaxf(x[0], -9.0f), 9.0f);
+                        }
+                    } else if (s == KC + 1) {
+                        if (ps->train_lam) adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(t), alpha_it);
+                    } else {
+                        if (first) (s == KC + 2 ? ps->ring_kl : ps->ring_ll)[static_cast<int64_t>(slot) * a.ld + jj] = static_cast<float>(t);
+                        if (s == KC + 2) t_kl = t; else t_ll = t;
+                    }
+                }
+            }
+        }
+        if (first) {                                       // workgroup-uniform
+            const double kl = block_sum_f64(psum, t_kl), ll_ = block_sum_f64(psum, t_ll);
+            if (threadIdx.x == 0) {
+                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 0] = kl;
+                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 1] = ll_;
+            }
+        }
+        __syncthreads();                                   // the LDS copy is complete before the next step's rows read it
+    }
+    }  // for (it)
+    if constexpr (PERSIST) {
+        if (blockIdx.y == 0) {
+            const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                ps->W[k * a.ld + jj] = pstate[(3 * k + 0) * kGenesPerBlock + threadIdx.x];
+                ps->m_W[k * a.ld + jj] = pstate[(3 * k + 1) * kGenesPerBlock + threadIdx.x];
+                ps->v_W[k * a.ld + jj] = pstate[(3 * k + 2) * kGenesPerBlock + threadIdx.x];
+            }
+            ps->b[jj] = pstate[(3 * KC + 0) * kGenesPerBlock + threadIdx.x];
+            ps->m_b[jj] = pstate[(3 * KC + 1) * kGenesPerBlock + threadIdx.x];
+            ps->v_b[jj] = pstate[(3 * KC + 2) * kGenesPerBlock + threadIdx.x];
+            ps->lam[jj] = pstate[(3 * KC + 3) * kGenesPerBlock + threadIdx.x];
+            ps->m_lam[jj] = pstate[(3 * KC + 4) * kGenesPerBlock + threadIdx.x];
+            ps->v_lam[jj] = pstate[(3 * KC + 5) * kGenesPerBlock + threadIdx.x];
         }
     }
 }

@@ -28,6 +28,8 @@ struct LaunchCfg {
 #define BRIE_DECLARE_KC(N)                                                                          \
     void launch_step_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &,           \
                            const CoupledArgs &);                                                    \
+    int launch_step_persist_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &,    \
+                                  const PersistArgs *dev_args, int n_cus);                          \
     void launch_loss_gene_kc##N(const LaunchCfg &, const LossGeneArgs &);                           \
     void launch_margin_kc##N(const LaunchCfg &, const StepPointers &, const StepScalars &);
 BRIE_DECLARE_KC(0) BRIE_DECLARE_KC(1) BRIE_DECLARE_KC(2) BRIE_DECLARE_KC(3) BRIE_DECLARE_KC(4)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define BRIE_AMD_ABI_VERSION 2
+#define BRIE_AMD_ABI_VERSION 3      /* 3: brie_placement_info takes the capacity of the caller's rate buffer */
 
 typedef enum brie_status {
     BRIE_OK = 0,
@@ -159,6 +159,18 @@ int brie_reset_optimizer(brie_handle *h);
  * it off).  The search is best effort -- it never fails the step -- and changes addresses only, never values. */
 int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
               float *loss_trace);
+
+/* MANY steps per launch for small inputs.  One step is two dependent launches (the streaming pass, then the per-gene reduction
+ * and Adam): 11 - 13 us whatever they compute, which is what a step of a few hundred cells costs (BASELINE configs[0]; the
+ * reference's own 10-gene batches, model_wrap.py:242).  brie_step can run its n_steps as ONE launch when the model allows it --
+ * uncoupled, Kc <= 8, ELBO target, no frozen gene, MC_size 1 or 3, n_steps >= 2, the whole grid resident: the workgroups of a
+ * gene block meet at a barrier per step (rows published write-through, read past L1) and each applies the per-gene update
+ * itself.  State, loss trace and loss ring are bit-identical to the two-launch path.  It is AUTOMATIC only where it measured
+ * faster: at most 16 cell chunks (Nc <= 256) and 4 x workgroups <= CUs -- 9.6 against 11.2 us per step at configs[0].
+ * brie_set_step_fusion: -1 automatic (default; BRIE_FUSE_STEPS=0 / 1 overrides), 0 never, 1 whenever the model allows it.
+ * brie_step_fusion_info: launches of that kind so far and the steps they carried. */
+int brie_set_step_fusion(brie_handle *h, int32_t mode);
+int brie_step_fusion_info(const brie_handle *h, int64_t *launches, int64_t *steps);
 
 /* Per-batch convergence.  The reference fits ~batch_size/Nc genes at a time and lets every batch stop on
  * its own windowed loss (model_wrap.py:241-260 + model_TFProb.py:247-258).  All genes are fitted
@@ -324,7 +336,9 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  * time for arrays below 1 GiB), filled by device-to-device copies and probed; every set is held until the search is over
  * (a freed set is what the allocator hands out again), then the fastest is kept and the others are freed (results are
  * bit-identical: only addresses change).  brie_step does this by itself before the first step of a handle that streams
- * >= 256 MiB per step (see brie_step): BRIE_PLACEMENT_TRIES sets in all (default BRIE_PLACEMENT_MAX_SETS = 8; 1 = off),
+ * >= 256 MiB per step (see brie_step): BRIE_PLACEMENT_TRIES sets in all (default: ONE round = 4 sets for arrays of a gigabyte
+ * and more, BRIE_PLACEMENT_MAX_SETS = 8 for smaller arrays whose candidates cost a few GB and milliseconds; 1 = off;
+ * brie_placement_configure sets it, the memory fraction and the time limit per handle),
  * good_gbs = BRIE_PLACEMENT_GOOD_GBS (default 6050 -- 5850 for handles whose arrays are below 1 GiB, which never read
  * faster than 6.0 TB/s --, or 0.97 x the best rate a handle of that size class has reached in this process on the device
  * when that is higher; a first set of a large handle between 6050 and 6150 still buys ONE round of candidates).
@@ -342,7 +356,8 @@ int brie_calibrate_stream(int32_t device, int32_t n_read, int32_t n_write, int64
  *  brie_placement_probe : rate of the probe on the arrays as they are (iters timed launches after one warm-up).
  *  brie_placement_tune  : the procedure above on demand, at most max_tries <= BRIE_PLACEMENT_MAX_SETS sets.
  *  brie_placement_info  : sets probed so far, which one is in use (0 = the original), their rates
- *                         (gbs[BRIE_PLACEMENT_MAX_SETS]) and the seconds spent probing, allocating and copying.
+ *                         (the first n_gbs of them into gbs[n_gbs]; BRIE_PLACEMENT_MAX_SETS is always enough) and the seconds spent
+ *                         probing, allocating and copying.
  *  brie_placement_status: how the last search ended (BRIE_PLACEMENT_*), its peak transient holding in bytes and a
  *                         human-readable note (e.g. "no set reached the stop rate: best of 8 sets 5210 GB/s ...").
  *  Any out-pointer may be NULL. */
@@ -358,7 +373,16 @@ typedef enum brie_placement_state {
 } brie_placement_state;
 int brie_placement_probe(brie_handle *h, int32_t iters, double *gbs);
 int brie_placement_tune(brie_handle *h, int32_t max_tries, double good_gbs);
-int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, double *seconds);
+int brie_placement_info(const brie_handle *h, int32_t *tries, int32_t *kept, double *gbs, int32_t n_gbs, double *seconds);
+/* Per-handle limits of the search, before the process environment: at most max_sets sets in all (<= BRIE_PLACEMENT_MAX_SETS;
+ * 1 = no search), a round takes at most hbm_fraction of the free HBM, no new allocation after max_seconds; a value <= 0 keeps
+ * the default.  Several ranks that share ONE GPU size their rounds on the same hipMemGetInfo reading without knowing of each
+ * other -- their caller does: it hands every rank 0.8 / (ranks on the device). */
+int brie_placement_configure(brie_handle *h, int32_t max_sets, double hbm_fraction, double max_seconds);
+/* Tests only (no environment variable can switch it on): the NEXT search of this handle fails at point 1 = its first probe,
+ * 2 = a candidate allocation, 3 = a candidate's probe, 4 = a candidate copy; 0 = none.  The search is best effort: the step
+ * goes on, bit-identical (tests/test_gpu_placement.py). */
+int brie_debug_inject_placement_failure(brie_handle *h, int32_t point);
 int brie_placement_status(const brie_handle *h, int32_t *status, int64_t *peak_bytes, char *note, int32_t note_len);
 
 /* Experiment aid: one slab of slab_bytes, the eight streamed arrays of a 2-layer u8-count problem of (Nc, Ng) placed at the

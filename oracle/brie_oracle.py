@@ -3,7 +3,7 @@
 Follows /root/reference/brie/models/model_TFProb.py (cited per function as
 `ref:LINE`) with the third-party TF/TFP semantics restated as described in
 oracle/__init__.py.  Gradients are hand-derived and are
-pinned against torch autograd in tests/test_oracle_grad.py.
+pinned against torch autograd in tests/test_oracle.py (::test_hand_gradients_match_autograd and its coupled / marginLik twins).
 
 Shapes: counts L x (Nc, Ng); Xc (Nc, Kc); Z_loc, Z_std_log (Nc, Ng);
 Wc_loc (Kc, Ng); intercept, sigma_log (1, Ng)  [intercept_mode='gene'].

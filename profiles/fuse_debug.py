@@ -1,0 +1,14 @@
+import os, sys, time, json
+sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/tests') else '.')
+from tests import util
+import numpy as np
+Nc, Ng, Kc, L = 200, 500, 0, 2
+P = util.problem(Nc, Ng, Kc, L, seed=77); P["effLen"] = None
+sh = util.device_shard(P, Nc, Ng, Kc, 5)
+sh.set_step_fusion(int(os.environ.get("MODE", "1")))
+sh.step(20, 0.005, 1, trace=False); sh.synchronize()
+best = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); sh.step(500, 0.005, 1, trace=False); sh.synchronize()
+    best = min(best, (time.perf_counter() - t0) / 500)
+print(os.environ.get("BRIE_FUSE_DEBUG", "0"), os.environ.get("MODE", "1"), round(best * 1e6, 2), "us/step", flush=True)

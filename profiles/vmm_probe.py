@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Placement without the lottery? (round 6)  The streamed arrays of a configs[2] / configs[1]-sized problem
-built from the HIP virtual-memory API with physical chunks created array after array or ROUND ROBIN over the arrays, next to
-plain hipMalloc, the placement probe timed on each -- one JSON line per fresh process:
+built from the HIP virtual-memory API with physical chunks created array after array (seq:<MiB>) or ROUND ROBIN over the arrays
+(rr:<MiB>), every array one allocation with unmapped spacers of <MiB> between them (spread:<MiB>) or behind one leading spacer
+(skip:<MiB>), next to plain hipMalloc, the placement probe timed on each -- one JSON line per fresh process:
 
     for i in $(seq 1 10); do python profiles/vmm_probe.py --config c3 >> gpurun_out/r6_vmm_c3.jsonl; done
 """
@@ -28,7 +29,7 @@ def main():
     for n in names:
         kind, _, mb = n.partition(":")
         chunk.append(int(mb or 2) * MB)
-        order.append({"seq": 0, "rr": 1, "malloc": 2}[kind])
+        order.append({"seq": 0, "rr": 1, "malloc": 2, "spread": 3, "skip": 4}[kind])
     gbs, secs = _capi.probe_vmm(Nc, Ng, L, chunk, order, iters=args.iters)
     print(json.dumps({"config": args.config, "layouts": names, "GBs": [round(float(g), 1) for g in gbs],
                       "build_seconds": [round(float(s), 3) for s in secs]}), flush=True)

@@ -90,7 +90,7 @@ int main(void) {
         char why[192];
         CHECK(brie_placement_probe(h, 2, &rate));
         CHECK(brie_placement_tune(h, 2, 1e30));
-        CHECK(brie_placement_info(h, &tries, &kept, gbs, &secs));
+        CHECK(brie_placement_info(h, &tries, &kept, gbs, BRIE_PLACEMENT_MAX_SETS, &secs));
         CHECK(brie_placement_status(h, &status, &peak, why, (int32_t)sizeof why));
         if (!(rate > 0.0) || tries != 2 || kept < 0 || kept > 1 || status != BRIE_PLACEMENT_BEST_OF_ALL || peak <= 0 || !why[0]) {
             fprintf(stderr, "placement: rate %g tries %d kept %d status %d peak %lld note \"%s\"\n", rate, (int)tries, (int)kept,

@@ -47,7 +47,7 @@ def assert_states_close(so, sd, bulk=1e-5, worst=1e-3, lr=0.01, fresh=1):
 
 
 def test_library_loads(lib):
-    assert lib.brie_abi_version() == 2
+    assert lib.brie_abi_version() == 3
 
 
 @pytest.mark.parametrize("gene_offset", [0, 1024])
@@ -666,10 +666,18 @@ def test_very_wide_cell_design_runs_in_panels(lib, Kc, L, MC, mode, Kg):
         sh.reset_optimizer()
         tr_o = o.minimize(P["counts_pc"], P["Xc"], 3, 0.01, 3, target="marginLik")
         np.testing.assert_allclose(sh.step(3, 0.01, 3), tr_o, rtol=1e-4)
-        # (the bulk tight, a sign event of Keras Adam's first steps -- +-lr whatever |g| is -- bounded and counted: with 257
-        #  x 520 weights one entry of 133 640 sat 6.9e-4 off after the three steps, call r5y)
         d = np.abs(sh.read(_capi.WC_LOC).astype(np.float64) - o.Wc_loc)
-        assert (d <= 2e-4).mean() >= 0.9999 and d.max() <= 3 * 0.01, (float(d.max()), float((d > 2e-4).mean()))
+        if Kc < 257:                                       # the designs that held this before round 5 keep it
+            assert d.max() <= 2e-4, float(d.max())
+        else:
+            # a sign event of Keras Adam's first steps (+-lr whatever |g| is): with 257 x 520 weights ONE entry of 133 640 sat
+            # 6.9e-4 off after the three steps (call r5y).  At most two such entries, none beyond 2 lr, and each must BE a
+            # sign event: a weight whose gradient the oracle itself sees near zero (|m| of its Adam slot far below the bulk)
+            out = np.argwhere(d > 2e-4)
+            assert len(out) <= 2 and d.max() <= 2 * 0.01, (len(out), float(d.max()))
+            m_abs = np.abs(np.asarray(o.slots["Wc_loc"].m, np.float64))
+            for k, j in out:
+                assert m_abs[k, j] <= 0.05 * np.median(m_abs), (int(k), int(j), float(m_abs[k, j]), float(np.median(m_abs)))
     with pytest.raises(NotImplementedError):
         _capi.Shard(Nc, Ng, 1025)
     sh.close()
@@ -895,6 +903,68 @@ def test_randomised_shapes_and_switches(lib, i, kind, Nc, Ng, Kc, Kg, L, MC, eff
     lg_o = o.eval_loss_gene(P["counts_pc"], P["Xc"], 3, target=target)          # 3-draw per-gene loss, updated state
     np.testing.assert_allclose(sh.loss_gene(3), lg_o, rtol=2e-4, atol=2e-3)
     sh.close()
+
+
+def _fusable_cases():
+    """The plain / fixed members of the random family (uncoupled, Kc <= 8, ELBO) + shapes of the kind brie-quant sees."""
+    out = [(i, Nc, Ng, Kc, L, MC if MC in (1, 3) else (1 if i % 2 else 3), eff, kind == "fixed")
+           for i, kind, Nc, Ng, Kc, Kg, L, MC, eff in _random_cases(63) if kind in ("plain", "fixed")]
+    out += [(100, 200, 500, 0, 2, 1, False, False), (101, 200, 500, 1, 2, 3, False, False), (102, 300, 2000, 2, 3, 3, True, False),
+            (103, 96, 1300, 8, 2, 1, True, False), (104, 1000, 300, 3, 3, 1, True, False)]
+    return out
+
+
+@pytest.mark.parametrize("i,Nc,Ng,Kc,L,MC,eff,fixed", _fusable_cases())
+def test_many_steps_per_launch_are_bit_identical_to_the_two_launch_path(lib, i, Nc, Ng, Kc, L, MC, eff, fixed):
+    """for small inputs brie_step runs its n steps as ONE launch (the PERSIST variant: barrier of the gene
+    block per step, the per-gene Adam inside the kernel).  Against a second handle held to the two-launch path: loss traces,
+    every state array, the loss ring and -- through further steps on both paths crosswise -- the Adam moments, bit for bit,
+    over the stages of a staged fit (fresh optimiser per stage, model_TFProb.py:234-241), with a frozen-gene interlude that
+    must fall back to the two-launch path by itself."""
+    from brie_amd import _capi
+    P = util.problem(Nc, Ng, Kc, L, seed=3000 + i)
+    if not eff:
+        P["effLen"] = None
+    elif P["effLen"] is None:
+        P["effLen"] = np.random.default_rng(i).uniform(50, 400, (Ng, 6)).astype(np.float32)
+    kw = dict(intercept=0.25, sigma=1.5) if fixed else {}
+    a = util.device_shard(P, Nc, Ng, Kc, 7000 + i, **kw)          # two launches per step
+    b = util.device_shard(P, Nc, Ng, Kc, 7000 + i, **kw)          # one launch per brie_step
+    a.set_step_fusion(0)
+    b.set_step_fusion(1)
+
+    def same(what):
+        sa, sb = util.device_state(a), util.device_state(b)
+        for k in util.STATE_KEYS:
+            assert np.array_equal(sa[k], sb[k]), (what, k, util.max_abs_diff(sa[k], sb[k]))
+
+    for n, lr in ((5, 0.001), (7, 0.02), (2, 0.005)):
+        a.reset_optimizer(); b.reset_optimizer()
+        ta, tb = a.step(n, lr, MC), b.step(n, lr, MC)
+        assert np.array_equal(ta, tb), (n, lr, ta, tb)
+        same("stage of %d steps" % n)
+    info = b.step_fusion_info()
+    assert info == {"launches": 3, "steps": 14} and a.step_fusion_info()["launches"] == 0, info
+    assert np.array_equal(a.read_loss_window(9), b.read_loss_window(9))                 # the loss ring of the last stages
+    # the moments: continue WITHOUT a fresh optimiser, paths swapped
+    a.set_step_fusion(1); b.set_step_fusion(0)
+    assert np.array_equal(a.step(3, 0.01, MC), b.step(3, 0.01, MC))
+    same("continued, paths swapped")
+    np.testing.assert_array_equal(a.loss_gene(2), b.loss_gene(2))
+    # frozen genes: the fused path steps aside (the carried losses of skipped blocks are the two-launch path's business)
+    if Ng >= 8:
+        mask = np.ones(Ng, np.uint8)
+        mask[: Ng // 2] = 0
+        a.set_gene_mask(mask); b.set_gene_mask(mask)
+        before = a.step_fusion_info()["launches"]
+        assert np.array_equal(a.step(2, 0.01, MC), b.step(2, 0.01, MC))
+        assert a.step_fusion_info()["launches"] == before
+        same("with frozen genes")
+        a.set_gene_mask(None); b.set_gene_mask(None)
+        assert np.array_equal(a.step(2, 0.01, MC), b.step(2, 0.01, MC))
+        assert a.step_fusion_info()["launches"] == before + 1
+        same("mask cleared")
+    a.close(); b.close()
 
 
 @pytest.mark.parametrize("Nc,Ng,Kc,L,MC,cuts", [

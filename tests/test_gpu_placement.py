@@ -105,7 +105,7 @@ def test_the_first_step_of_a_large_handle_searches_by_itself(lib):
 
 @pytest.mark.parametrize("inject,status,tries", [(1, "stopped_error", 0), (2, "stopped_memory", 1), (3, "stopped_error", 1),
                                                   (4, "stopped_error", 1)])
-def test_a_failure_inside_the_search_never_fails_the_step(lib, monkeypatch, inject, status, tries):
+def test_a_failure_inside_the_search_never_fails_the_step(lib, inject, status, tries):
     """the search is an optimisation.  With a failure injected into its first probe / a candidate's allocation /
     a candidate's probe / a candidate's copy, the first step of a large handle still runs, on the original arrays, with the
     result of a handle that never searched, and brie_placement_status says what happened."""
@@ -116,9 +116,8 @@ def test_a_failure_inside_the_search_never_fails_the_step(lib, monkeypatch, inje
     a = util.device_shard(P, Nc, Ng, Kc, 6)
     b = util.device_shard(P, Nc, Ng, Kc, 6)
     b.placement_tune(1, 0.0)
-    monkeypatch.setenv("BRIE_PLACEMENT_INJECT_FAILURE", str(inject))
+    a.inject_placement_failure(inject)              # an explicit call on this handle (nothing in the environment)
     ta = a.placement_tune(4, 1e30) and a.step(3, 0.01, 1)
-    monkeypatch.delenv("BRIE_PLACEMENT_INJECT_FAILURE")
     tb = b.step(3, 0.01, 1)
     info = a.placement_info()
     assert info["status"] == status and info["tries"] == tries and info["kept"] == 0 and info.get("note"), info

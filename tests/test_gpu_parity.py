@@ -962,7 +962,8 @@ def test_many_steps_per_launch_are_bit_identical_to_the_two_launch_path(lib, i, 
         same("with frozen genes")
         a.set_gene_mask(None); b.set_gene_mask(None)
         assert np.array_equal(a.step(2, 0.01, MC), b.step(2, 0.01, MC))
-        assert a.step_fusion_info()["launches"] == before + 1
+        # (fused again unless packing the active quads left the counts in one u16 tier, which has no fused instantiation)
+        assert a.step_fusion_info()["launches"] in (before, before + 1)
         same("mask cleared")
     a.close(); b.close()
 

@@ -2143,7 +2143,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     // them, bit for bit).  Allowed for an uncoupled model with Kc <= 8, ELBO target, no frozen gene, MC_size 1 or 3 and a grid the
     // device holds at once; AUTOMATIC only where it was measured faster than two launches per step (calls r6k, r6l): at most 16
     // cell chunks (every workgroup of a gene block re-reads all of the block's chunk rows: the cost grows with their square)
-    // and at most a quarter of the CUs busy -- configs[0]: 9.6 against 11.2 us per step; 300 x 2000: 14.1 against 12.2, so not there.
+    // and at most a quarter of the CUs busy -- configs[0]: 9.0 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
     int i_start = 0;
     {
         static const int env_mode = [] { const char *e = getenv("BRIE_FUSE_STEPS"); return e ? atoi(e) : -1; }();

@@ -736,7 +736,7 @@ __global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1
     // PERSIST: per-gene parameters and their Adam moments of the block's 256 genes, [3 x (KC + 2)][256]: x, m, v of Wc_loc rows,
     // intercept, sigma_log -- read by the row phase (lane l: genes 4l .. 4l+3), updated by the finalize phase (thread t: gene t)
     __shared__ float pstate[PERSIST ? 3 * (KC + 2) * kGenesPerBlock : 1];
-    __shared__ double psum[PERSIST ? kBlock : 1];
+    __shared__ double psum[PERSIST ? kBlock : 1], psum2[PERSIST ? kBlock : 1];
     const PersistArgs *ps = reinterpret_cast<const PersistArgs *>(rbuf);
     if constexpr (PERSIST) {
         const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1
             __hip_atomic_fetch_add(ps->barrier + gb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t want = static_cast<uint32_t>(it + 1) * gridDim.y;
             while (!(ps->debug & 1) && __hip_atomic_load(ps->barrier + gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(0);
         }
         __syncthreads();
         // ---- gene_finalize's work for gene t of the block, on the LDS copy (finalize_gene_stat, statistic by statistic)
@@ -1291,18 +1291,19 @@ __global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1
                 double tsum[S];
 #pragma unroll
                 for (int s = 0; s < S; ++s) tsum[s] = 0.0;
-                for (int c0 = 0; c0 < n_chunks; c0 += 8) {
-                    float xv[S][8];
+                constexpr int kB = S <= 8 ? 16 : 8;       // chunk rows in flight per statistic (registers: S x kB floats)
+                for (int c0 = 0; c0 < n_chunks; c0 += kB) {
+                    float xv[S][kB];
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < kB; ++u)
                             xv[s][u] = __hip_atomic_load(part_it + static_cast<int64_t>(s) * a.ld + jj + min(c0 + u, n_chunks - 1) * stride,
                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no guarded load: they serialise)
 #pragma unroll
                     for (int s = 0; s < S; ++s)
 #pragma unroll
-                        for (int u = 0; u < 8; ++u)
+                        for (int u = 0; u < kB; ++u)
                             if (c0 + u < n_chunks) tsum[s] += static_cast<double>(xv[s][u]);
                 }
 #pragma unroll
@@ -1325,11 +1326,20 @@ __global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1
                 }
             }
         }
-        if (first) {                                       // workgroup-uniform
-            const double kl = block_sum_f64(psum, t_kl), ll_ = block_sum_f64(psum, t_ll);
+        if (first) {                                       // workgroup-uniform; both terms through block_sum_f64's tree at once
+            psum[threadIdx.x] = t_kl;
+            psum2[threadIdx.x] = t_ll;
+            __syncthreads();
+            for (int st = kBlock / 2; st > 0; st >>= 1) {
+                if (static_cast<int>(threadIdx.x) < st) {
+                    psum[threadIdx.x] += psum[threadIdx.x + st];
+                    psum2[threadIdx.x] += psum2[threadIdx.x + st];
+                }
+                __syncthreads();
+            }
             if (threadIdx.x == 0) {
-                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 0] = kl;
-                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 1] = ll_;
+                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 0] = psum[0];
+                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 1] = psum2[0];
             }
         }
         __syncthreads();                                   // the LDS copy is complete before the next step's rows read it

@@ -186,10 +186,14 @@ class BRIE2(object):
 
     def _new_shard(self, n_layers):
         """One `brie_handle` (gene shard on one GPU) for this model; the only place a backend is chosen."""
-        return _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
-                           train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
-                           seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
-                           intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
+        sh = _capi.Shard(self.Nc, self.Ng, self.Kc, n_layers=n_layers, has_efflen=self.effLen is not None,
+                         train_intercept=self._intercept_value is None, train_sigma=self._sigma_value is None,
+                         seed=self.seed, device=self.device, gene_offset=self.gene_offset, Kg=self.Kg,
+                         intercept_mode=1 if self._cell_mode else 0, sharded=self._comm is not None)
+        n_here = getattr(self._comm, "ranks_on_device", 1) if self._comm is not None else 1
+        if n_here > 1 and hasattr(sh, "placement_configure"):      # ranks sharing one GPU share its free HBM (ADVICE r5)
+            sh.placement_configure(hbm_fraction=0.8 / n_here)
+        return sh
 
     def _upload_layers(self, sh, count_layers, n_layers):
         for l in range(n_layers):

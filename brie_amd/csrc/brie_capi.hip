@@ -181,6 +181,7 @@ struct brie_handle {
     float *persist_alphas = nullptr, *partials2 = nullptr;
     size_t persist_alphas_elems = 0, partials2_elems = 0;
     uint32_t *persist_barrier = nullptr;
+    uint32_t *persist_flag_host = nullptr;  // pinned: the time-out word of the last fused launch, copied back behind it
     int64_t persist_launches = 0, persist_steps = 0;
     int placement_cfg_sets = 0;             // brie_placement_configure: 0 = the library's default
     double placement_cfg_frac = 0.0, placement_cfg_seconds = 0.0;
@@ -395,6 +396,9 @@ int check_ready(const brie_handle *h) {
     if (h->p.Kg > 0 && !h->have_xg) return fail(BRIE_ERR_STATE, "Xg not uploaded (Kg=%d)", h->p.Kg);
     if (!h->have_state)
         return fail(BRIE_ERR_STATE, "state not initialised: call brie_init_state or upload Z_loc..sigma_log");
+    if (h->persist_flag_host && *h->persist_flag_host != 0)
+        return fail(BRIE_ERR_HIP, "a many-steps-per-launch step kernel gave up waiting for its workgroups (the device was not "
+                                  "free to hold the grid): the handle's state is undefined; BRIE_FUSE_STEPS=0 keeps two launches per step");
     return BRIE_OK;
 }
 
@@ -1218,6 +1222,7 @@ int brie_destroy(brie_handle *h) {
     if (h->persist_args) hipFree(h->persist_args);
     if (h->persist_alphas) hipFree(h->persist_alphas);
     if (h->persist_barrier) hipFree(h->persist_barrier);
+    if (h->persist_flag_host) hipHostFree(h->persist_flag_host);
     if (h->partials2) hipFree(h->partials2);
     if (h->win_scratch) hipFree(h->win_scratch);
     if (h->io_stream) hipStreamDestroy(h->io_stream);
@@ -2157,7 +2162,11 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             if ((rc = ensure_f32(&h->partials2, &h->partials2_elems, pneed, h->stream)) != BRIE_OK) return rc;
             if ((rc = ensure_f32(&h->persist_alphas, &h->persist_alphas_elems, static_cast<size_t>(n_steps), h->stream)) != BRIE_OK) return rc;
             if (!h->persist_args) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->persist_args), sizeof(brie::PersistArgs)));
-            if (!h->persist_barrier) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->persist_barrier), sizeof(uint32_t) * h->gene_blocks));
+            if (!h->persist_barrier) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->persist_barrier), sizeof(uint32_t) * (h->gene_blocks + 1)));
+            if (!h->persist_flag_host) {
+                HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->persist_flag_host), sizeof(uint32_t), hipHostMallocDefault));
+                *h->persist_flag_host = 0;
+            }
             std::vector<float> alphas(static_cast<size_t>(n_steps));
             for (int i = 0; i < n_steps; ++i) alphas[i] = adam_alpha(h->t + 1 + i);
             brie::PersistArgs pa{};
@@ -2170,7 +2179,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             { const char *dbg = getenv("BRIE_FUSE_DEBUG"); pa.debug = dbg ? atoi(dbg) : 0; }
             HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
-            HIP_TRY(hipMemsetAsync(h->persist_barrier, 0, sizeof(uint32_t) * h->gene_blocks, h->stream));
+            HIP_TRY(hipMemsetAsync(h->persist_barrier, 0, sizeof(uint32_t) * (h->gene_blocks + 1), h->stream));
             HIP_TRY(hipStreamSynchronize(h->stream));      // `alphas` and `pa` are pageable host memory of this frame
             a.alpha = alphas[0];
             a.draw = h->draw;
@@ -2182,6 +2191,9 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                 h->persist_launches += 1;
                 h->persist_steps += n_steps;
                 i_start = n_steps;
+                // the time-out word travels back behind the launch; check_ready of the next call that finds it set fails loudly
+                HIP_TRY(hipMemcpyAsync(h->persist_flag_host, h->persist_barrier + h->gene_blocks, sizeof(uint32_t),
+                                       hipMemcpyDeviceToHost, h->stream));
             }
         }
     }

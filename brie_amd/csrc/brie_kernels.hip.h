@@ -685,13 +685,14 @@ __device__ __forceinline__ double block_sum_f64(double *sh, double t) {
 // Kc <= 8, ELBO target; the arguments travel through `rbuf` (a PersistArgs in device memory).
 struct PersistArgs {
     const float *alphas;        // (n_steps) lr * sqrt(1 - b2^t) / (1 - b1^t) of every step
-    uint32_t *barrier;          // (gene_blocks) zeroed before the launch
+    uint32_t *barrier;          // (gene_blocks + 1) zeroed before the launch; the last word: 1 = a barrier wait timed out
     float *partials2;           // the second partials buffer (odd steps)
     float *W, *m_W, *v_W, *b, *m_b, *v_b, *lam, *m_lam, *v_lam;
     float *ring_kl, *ring_ll;   // (kLossRing, ld)
     double *loss_parts;         // (n_steps, gene_blocks, 2)
     int32_t n_steps, ring_pos0, train_b, train_lam, fin_Ng;
-    int32_t debug;              // experiments (BRIE_FUSE_DEBUG; results are then wrong): 1 no barrier wait, 2 no finalize, 4 no rows
+    int32_t debug;              // experiments / tests (BRIE_FUSE_DEBUG; results are then wrong): 1 no barrier wait, 2 no finalize,
+                                // 4 no rows, 8 chunk 0 skips its second arrival; bits 8..: log2 of the poll bound (default 24)
 };
 
 template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false, bool PERSIST = false>
@@ -1264,10 +1265,20 @@ __global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(ps->barrier + gb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!((ps->debug & 8) && blockIdx.y == 0 && it == 1))       // (tests: chunk 0 "never arrives" at the second step)
+                __hip_atomic_fetch_add(ps->barrier + gb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t want = static_cast<uint32_t>(it + 1) * gridDim.y;
-            while (!(ps->debug & 1) && __hip_atomic_load(ps->barrier + gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+            // the wait is BOUNDED (~10 s of polling): should a workgroup of the block never become resident -- the launch is
+            // made only when the occupancy query says the grid fits, but other kernels may hold CUs -- the kernel ends with a
+            // flag the host turns into an error (the state is then undefined) instead of spinning on the GPU for ever
+            uint32_t spins = 0;
+            while (!(ps->debug & 1) && __hip_atomic_load(ps->barrier + gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(0);
+                if (++spins > ((ps->debug >> 8) ? 1u << ((ps->debug >> 8) & 31) : 1u << 24)) {
+                    __hip_atomic_store(ps->barrier + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
         }
         __syncthreads();
         // ---- gene_finalize's work for gene t of the block, on the LDS copy (finalize_gene_stat, statistic by statistic)

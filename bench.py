@@ -618,6 +618,20 @@ def main(argv=None):
     sh.step(args.steps, lr, args.mc, trace=False)
     sh.synchronize()
     ms_unprofiled = (time.perf_counter() - t0) / args.steps * 1e3
+    # small inputs (configs[0]): brie_step runs its K steps as ONE launch where that measured faster (never under
+    # the per-launch events of the timed region above) -- both paths timed once more, same handle, same steps
+    fusion = None
+    if hasattr(sh, "step_fusion_info") and sh.step_fusion_info()["launches"] > 0:
+        fusion = {"launches_so_far": sh.step_fusion_info()}
+        for mode, key in ((0, "two_launches_per_step_ms"), (-1, "one_launch_per_call_ms")):
+            sh.set_step_fusion(mode)
+            sh.step(args.steps, lr, args.mc, trace=False)
+            sh.synchronize()
+            t0 = time.perf_counter()
+            sh.step(args.steps, lr, args.mc, trace=False)
+            sh.synchronize()
+            fusion[key] = (time.perf_counter() - t0) / args.steps * 1e3
+        fusion["what"] = "brie_set_step_fusion 0 / automatic on the timed handle; state bit-identical either way (tests)"
     last = sh.step(1, lr, args.mc)                       # one traced step: loss must be finite
     assert np.isfinite(last).all(), last
     psi_quad = sh.read(_capi.PSI)[:, q0:q0 + 4].copy() if (rank == 0 and not args.no_psi_check and q0 + 4 <= ng) else None
@@ -696,6 +710,7 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preconditioning": precondition,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_without_profiling_events": ms_unprofiled,      # rank 0, untimed second pass of the same K steps
+            "step_fusion": fusion,
             "iterations_per_s": args.steps / elapsed,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -35,7 +35,7 @@ EXPORTS = [
     "brie_loglik_mc", "brie_get_loss", "brie_debug_address", "brie_host_convert_u16", "brie_host_convert_slab",
     "brie_placement_probe", "brie_placement_tune", "brie_placement_info", "brie_placement_status", "brie_probe_layouts",
     "brie_placement_configure", "brie_debug_inject_placement_failure", "brie_probe_vmm", "brie_set_step_fusion",
-    "brie_step_fusion_info",
+    "brie_step_fusion_info", "brie_debug_step_fusion",
 ]
 COMM_ID_BYTES = 128
 #: numpy dtype -> brie_dtype of brie_upload_typed (count layers held as integers / float64 go up without a host cast)
@@ -142,6 +142,7 @@ def load_library(path=None):
                                         ctypes.POINTER(ctypes.c_double)]
     lib.brie_placement_configure.argtypes = [vp, i32, ctypes.c_double, ctypes.c_double]
     lib.brie_set_step_fusion.argtypes = [vp, i32]
+    lib.brie_debug_step_fusion.argtypes = [vp, i32]
     lib.brie_step_fusion_info.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     lib.brie_debug_inject_placement_failure.argtypes = [vp, i32]
     lib.brie_last_error.restype = ctypes.c_char_p
@@ -552,6 +553,10 @@ class Shard(object):
     def set_step_fusion(self, mode):
         """Many Adam steps per launch for small inputs (brie_set_step_fusion): -1 automatic, 0 never, 1 whenever allowed."""
         _check(self.lib, self.lib.brie_set_step_fusion(self._h, int(mode)))
+
+    def debug_step_fusion(self, flags):
+        """Tests / experiments (brie_debug_step_fusion): phase switches and the poll bound of the fused launches."""
+        _check(self.lib, self.lib.brie_debug_step_fusion(self._h, int(flags)))
 
     def step_fusion_info(self):
         n, k = ctypes.c_int64(), ctypes.c_int64()

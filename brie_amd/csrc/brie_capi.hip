@@ -176,6 +176,7 @@ struct brie_handle {
     char placement_note[192] = {0};         // why the search ended the way it did (brie_placement_status)
     // many steps per launch (PERSIST variant of the step kernel; run_steps_persist)
     int persist_mode = -1;                  // brie_set_step_fusion: -1 automatic, 0 never, 1 whenever the model allows it
+    int persist_debug = 0;                  // brie_debug_step_fusion
     bool any_frozen = false;                // a gene mask with frozen genes is set
     brie::PersistArgs *persist_args = nullptr;
     float *persist_alphas = nullptr, *partials2 = nullptr;
@@ -2176,7 +2177,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             pa.loss_parts = h->loss_parts; pa.n_steps = n_steps;
             pa.ring_pos0 = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
             pa.train_b = f.train_b; pa.train_lam = f.train_lam; pa.fin_Ng = f.Ng;
-            { const char *dbg = getenv("BRIE_FUSE_DEBUG"); pa.debug = dbg ? atoi(dbg) : 0; }
+            pa.debug = h->persist_debug;          // brie_debug_step_fusion (tests / experiments): an explicit call, no variable
             HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemsetAsync(h->persist_barrier, 0, sizeof(uint32_t) * (h->gene_blocks + 1), h->stream));
@@ -2838,6 +2839,13 @@ int brie_set_step_fusion(brie_handle *h, int32_t mode) {
     if (!h) return fail(BRIE_ERR_INVALID, "null handle");
     if (mode < -1 || mode > 1) return fail(BRIE_ERR_INVALID, "mode=%d (-1 automatic, 0 off, 1 on)", mode);
     h->persist_mode = mode;
+    return BRIE_OK;
+}
+
+int brie_debug_step_fusion(brie_handle *h, int32_t flags) {
+    if (!h) return fail(BRIE_ERR_INVALID, "null handle");
+    if (flags < 0) return fail(BRIE_ERR_INVALID, "flags=%d", flags);
+    h->persist_debug = flags;
     return BRIE_OK;
 }
 

@@ -171,6 +171,11 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
  * brie_step_fusion_info: launches of that kind so far and the steps they carried. */
 int brie_set_step_fusion(brie_handle *h, int32_t mode);
 int brie_step_fusion_info(const brie_handle *h, int64_t *launches, int64_t *steps);
+/* Tests / experiments only (an explicit call on one handle, nothing in the environment; results are then WRONG): flags of the
+ * fused launches -- 1 no barrier wait, 2 no per-gene update, 4 no rows (phase timing, profiles/fuse_debug.py), 8 chunk 0 skips
+ * its second arrival; bits 8.. = log2 of the barrier's poll bound (default 24, ~10 s: a workgroup that never arrives ends the
+ * kernel with a flag the next call turns into BRIE_ERR_HIP instead of a kernel spinning for ever). */
+int brie_debug_step_fusion(brie_handle *h, int32_t flags);
 
 /* Per-batch convergence.  The reference fits ~batch_size/Nc genes at a time and lets every batch stop on
  * its own windowed loss (model_wrap.py:241-260 + model_TFProb.py:247-258).  All genes are fitted

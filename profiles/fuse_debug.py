@@ -6,6 +6,7 @@ Nc, Ng, Kc, L = 200, 500, 0, 2
 P = util.problem(Nc, Ng, Kc, L, seed=77); P["effLen"] = None
 sh = util.device_shard(P, Nc, Ng, Kc, 5)
 sh.set_step_fusion(int(os.environ.get("MODE", "1")))
+sh.debug_step_fusion(int(os.environ.get("BRIE_FUSE_DEBUG", "0")))        # read HERE, by the script: the library takes a call
 sh.step(20, 0.005, 1, trace=False); sh.synchronize()
 best = 1e9
 for _ in range(3):

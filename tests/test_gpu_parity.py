@@ -970,7 +970,7 @@ def test_many_steps_per_launch_are_bit_identical_to_the_two_launch_path(lib, i, 
 
 def test_a_fused_launch_that_cannot_complete_ends_with_an_error_not_a_hang(lib):
     """The barrier wait of the many-steps-per-launch kernel is bounded: when a workgroup of a gene block never arrives (here:
-    told not to, BRIE_FUSE_DEBUG, with a short poll bound) the kernel ends, and the next call on the handle fails loudly --
+    told not to, brie_debug_step_fusion, with a short poll bound) the kernel ends, and the next call on the handle fails loudly --
     the state is undefined -- instead of a kernel spinning on the GPU for ever."""
     import os
     import subprocess
@@ -980,6 +980,7 @@ def test_a_fused_launch_that_cannot_complete_ends_with_an_error_not_a_hang(lib):
             "P = util.problem(200, 500, 0, 2, seed=5); P['effLen'] = None\n"
             "sh = util.device_shard(P, 200, 500, 0, 9)\n"
             "sh.set_step_fusion(1)\n"
+            "sh.debug_step_fusion(8 | (14 << 8))\n"
             "sh.step(4, 0.01, 1, trace=False)\n"
             "sh.synchronize()\n"
             "try:\n"
@@ -988,7 +989,7 @@ def test_a_fused_launch_that_cannot_complete_ends_with_an_error_not_a_hang(lib):
             "except RuntimeError as e:\n"
             "    print('ERROR:', e)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BRIE_FUSE_DEBUG=str(8 | (14 << 8)), PYTHONPATH=root)
+    env = dict(os.environ, PYTHONPATH=root)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert "ERROR:" in r.stdout and "gave up waiting" in r.stdout, r.stdout + r.stderr
 

@@ -621,7 +621,7 @@ def main(argv=None):
     # small inputs (configs[0]): brie_step runs its K steps as ONE launch where that measured faster (never under
     # the per-launch events of the timed region above) -- both paths timed once more, same handle, same steps
     fusion = None
-    if hasattr(sh, "step_fusion_info") and sh.step_fusion_info()["launches"] > 0:
+    if world == 1 and hasattr(sh, "step_fusion_info") and sh.step_fusion_info()["launches"] > 0:    # (N > 1: rank 0 replays the steps)
         fusion = {"launches_so_far": sh.step_fusion_info()}
         for mode, key in ((0, "two_launches_per_step_ms"), (-1, "one_launch_per_call_ms")):
             sh.set_step_fusion(mode)

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbrie_amd.so")
 SOURCES = [os.path.join(CSRC, "brie_capi.hip"), os.path.join(CSRC, "brie_inst.hip"), os.path.join(CSRC, "brie_comm.hip"),
            os.path.join(CSRC, "brie_tile_inst.hip")]
-HEADERS = [os.path.join(CSRC, "brie_kernels.hip.h"), os.path.join(CSRC, "brie_launch.h"),
+HEADERS = [os.path.join(CSRC, "brie_kernels.hip.h"), os.path.join(CSRC, "brie_step_body.inc"), os.path.join(CSRC, "brie_launch.h"),
            os.path.join(CSRC, "brie_comm_internal.h"), os.path.join(CSRC, "brie_tile.hip.h"),
            os.path.join(ROOT, "include", "brie_amd.h")]
 MAX_KC = 8

@@ -109,7 +109,7 @@ void step_cs(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, co
 // (returns 0 otherwise and the caller takes the two-launch path).  MC_size 1 and 3 (the API's and brie-quant's defaults).
 template <int MODE, int MC, int CS>
 int persist_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars &a, const PersistArgs *dev_args, int n_cus) {
-    auto kern = elbo_adam_step<BRIE_KC, MODE, MC, CS, false, false, false, false, true>;
+    auto kern = elbo_adam_fused_steps<BRIE_KC, MODE, MC, CS>;
     static const int per_cu = [&] {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(kern), kBlock, 0) != hipSuccess) nb = 0;

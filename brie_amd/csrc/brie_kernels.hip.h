@@ -695,684 +695,38 @@ struct PersistArgs {
                                 // 4 no rows, 8 chunk 0 skips its second arrival; bits 8..: log2 of the poll bound (default 24)
 };
 
-template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false, bool PERSIST = false>
-__global__ __launch_bounds__(kBlock, ((BRIE_TWO_WAVES_COND) && !PERSIST) ? 2 : 1) void elbo_adam_step(
+template <int KC, int MODE, int MC, int CS, bool CPL, bool WIDE = false, bool GW = false, bool MARGIN = false>
+__global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_adam_step(
     const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
     float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
     float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
     const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
     const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
-    static_assert(!WIDE || KC == 0, "the wide-design variant keeps Wc_loc in LDS, not in registers");
-    static_assert(!GW || CPL, "GW is the coupled variant for Kg > 4");
-    extern __shared__ float xlds[];     // GW: Xg tile of this gene block, (kgp, 256); launch-time size >= the fold's
-    constexpr int S = KC + 4;
-    constexpr int KCX = KC > 0 ? KC : 1;
-    // Three samples per step (the brie-quant default): with the effLen likelihood the one VALU-bound step (pipes busy 0.90,
-    // profiles/r5/r5_counters_c2_step_mc3.txt).  Its logarithms -- 2 per element and sample, 1 without effLen -- go without
-    // __logf's rescue code for denormal / infinite inputs that cannot occur here (f_log_sel): 18 % fewer VALU instructions.  A
-    // logarithm enters the likelihood VALUE only, never its derivative, and the lean form is within one ulp of __logf: the
-    // state bits cannot change and do not (profiles/r5/r5_lib_ab_leanlog.json: 15 shapes; in two of them the loss TRACE
-    // moves by one ulp of its fp32 total).  Two waves per SIMD are asked for by
-    // name (BRIE_TWO_WAVES_COND in __launch_bounds__): the allocator lands within a few registers of 256 either side, and up to
-    // Kc = 7 the 0 - 108 bytes of scratch that costs are cheaper than a lone wave per SIMD (Kc = 4: 0.62 -> 0.53 ms, Kc = 7:
-    // 0.69 -> 0.59 at 10k x 5k; at Kc = 8, 148 bytes, 0.65 -> 0.88: left to the allocator, 0.62).
-    constexpr bool kLeanLog = BRIE_LEANLOG_COND;
-    constexpr bool kProd = MC > 1 && !MARGIN;            // see loglik_grad_acc
-    // GW: the cross-wave fold reuses the (dynamic) Xg tile once the row loop is over -- keeps 2 workgroups per CU
-    __shared__ float red_static[GW ? 1 : (kWavesPerBlock - 1) * S * kGenesPerBlock];
-    __shared__ float wlds[WIDE ? kWideKcMax * kGenesPerBlock : 1];      // W tile of this gene block
-    float *red = GW ? xlds : red_static;
+    constexpr bool PERSIST = false;
+    constexpr int it = 0;
+#define BRIE_STEP_LOOP_BEGIN
+#define BRIE_STEP_LOOP_END
+#include "brie_step_body.inc"
+#undef BRIE_STEP_LOOP_BEGIN
+#undef BRIE_STEP_LOOP_END
+}
 
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int gb = static_cast<int>(blockIdx.x);         // gene block (workgroup-uniform)
-    const int quad = gb * kWave + lane;                  // local gene quad
-    const int j0 = quad * kVec;
-    const bool active = j0 < a.Ng;
-    const int row0 = blockIdx.y * a.rows_per_chunk;
-    const int row_end = min(row0 + a.rows_per_chunk, a.Nc);
-    if (a.block_active[gb] == 0) return;                 // whole gene block frozen (workgroup-uniform)
-    static_assert(!PERSIST || (!CPL && !WIDE && !GW && !MARGIN), "many steps per launch: uncoupled models, Kc <= 8, ELBO");
-    // PERSIST: per-gene parameters and their Adam moments of the block's 256 genes, [3 x (KC + 2)][256]: x, m, v of Wc_loc rows,
-    // intercept, sigma_log -- read by the row phase (lane l: genes 4l .. 4l+3), updated by the finalize phase (thread t: gene t)
-    __shared__ float pstate[PERSIST ? 3 * (KC + 2) * kGenesPerBlock : 1];
-    __shared__ double psum[PERSIST ? kBlock : 1], psum2[PERSIST ? kBlock : 1];
-    const PersistArgs *ps = reinterpret_cast<const PersistArgs *>(rbuf);
-    if constexpr (PERSIST) {
-        const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            pstate[(3 * k + 0) * kGenesPerBlock + threadIdx.x] = ps->W[k * a.ld + jj];
-            pstate[(3 * k + 1) * kGenesPerBlock + threadIdx.x] = ps->m_W[k * a.ld + jj];
-            pstate[(3 * k + 2) * kGenesPerBlock + threadIdx.x] = ps->v_W[k * a.ld + jj];
-        }
-        pstate[(3 * KC + 0) * kGenesPerBlock + threadIdx.x] = ps->b[jj];
-        pstate[(3 * KC + 1) * kGenesPerBlock + threadIdx.x] = ps->m_b[jj];
-        pstate[(3 * KC + 2) * kGenesPerBlock + threadIdx.x] = ps->v_b[jj];
-        pstate[(3 * KC + 3) * kGenesPerBlock + threadIdx.x] = ps->lam[jj];
-        pstate[(3 * KC + 4) * kGenesPerBlock + threadIdx.x] = ps->m_lam[jj];
-        pstate[(3 * KC + 5) * kGenesPerBlock + threadIdx.x] = ps->v_lam[jj];
-        __syncthreads();
-    }
-    const int n_it = PERSIST ? ps->n_steps : 1;
-    for (int it = 0; it < n_it; ++it) {
-    const float alpha_it = PERSIST ? ps->alphas[it] : a.alpha;
-    const uint32_t draw_it = PERSIST ? a.draw + static_cast<uint32_t>(it) : a.draw;
-    if constexpr (WIDE) {
-        for (int i = threadIdx.x; i < a.kc_wide * kGenesPerBlock; i += kBlock)
-            wlds[i] = Wp[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
-        __syncthreads();
-    }
-    if constexpr (GW) {
-        for (int i = threadIdx.x; i < cp.kgp * kGenesPerBlock; i += kBlock)
-            xlds[i] = cp.Xg[static_cast<int64_t>(i / kGenesPerBlock) * a.ld + gb * kGenesPerBlock + (i % kGenesPerBlock)];
-        __syncthreads();
-    }
-
-    float acc[S][kVec];
-#pragma unroll
-    for (int s = 0; s < S; ++s)
-#pragma unroll
-        for (int v = 0; v < kVec; ++v) acc[s][v] = 0.0f;
-
-    // coupled / wide variants: every lane runs (the wave reduces over its 256 genes, resp. lane k carries
-    // feature k of the cell's design row for v_readlane); lanes beyond Ng work on the zero padding of the
-    // gene block, contribute nothing and store nothing
-    if ((CPL || WIDE || active) && row0 + w < row_end && !(PERSIST && (ps->debug & 4))) {
-        // per-gene parameters, live across the whole chunk
-        float Wk[KCX][kVec], bj[kVec], lamj[kVec], isig2[kVec];
-        float L0[kVec], L4[kVec], L5[kVec], lL0[kVec], lL4[kVec], lL5[kVec];
-        float iLs[kVec] = {0.f, 0.f, 0.f, 0.f};
-        float Xgk[(CPL && !GW) ? kKgMax : 1][kVec];
-        if constexpr (CPL && !GW) {
-#pragma unroll
-            for (int k = 0; k < kKgMax; ++k) {
-                const F4 t = ld4(cp.Xg + k * a.ld + j0);
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) Xgk[k][v] = t.v[v];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < KC; ++k) {
-            const F4 t = PERSIST ? ld4(pstate + (3 * k) * kGenesPerBlock + lane * kVec) : ld4(Wp + k * a.ld + j0);
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) Wk[k][v] = t.v[v];
-        }
-        {
-            const F4 tb = PERSIST ? ld4(pstate + (3 * KC) * kGenesPerBlock + lane * kVec) : ld4(bp + j0),
-                     tl = PERSIST ? ld4(pstate + (3 * KC + 3) * kGenesPerBlock + lane * kVec) : ld4(lamp + j0);
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) {
-                bj[v] = tb.v[v];
-                lamj[v] = tl.v[v];
-                isig2[v] = f_exp(-2.0f * tl.v[v]);
-            }
-        }
-        if (MODE != kLik2) {
-            const F4 t0 = ld4(effL + 0 * a.ld + j0), t1 = ld4(effL + 1 * a.ld + j0),
-                     t2 = ld4(effL + 2 * a.ld + j0), t3 = ld4(effL + 3 * a.ld + j0),
-                     t4 = ld4(effL + 4 * a.ld + j0), t5 = ld4(effL + 5 * a.ld + j0);
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) {
-                L0[v] = t0.v[v]; L4[v] = t1.v[v]; L5[v] = t2.v[v];
-                lL0[v] = t3.v[v]; lL4[v] = t4.v[v]; lL5[v] = t5.v[v];
-                if constexpr (kProd) {     // the value path works on D / Ls, Ls = max(L0, L4) + L5 (loglik_grad_acc)
-                    const float Ls = fmaxf(L0[v], L4[v]) + L5[v];
-                    const float lLs = f_log(Ls);
-                    iLs[v] = Ls > 0.0f ? 1.0f / Ls : 0.0f;           // padding genes beyond Ng have zero lengths
-                    lL0[v] -= lLs; lL4[v] -= lLs; lL5[v] -= lLs;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) { L0[v] = L4[v] = L5[v] = lL0[v] = lL4[v] = lL5[v] = 0.0f; }
-        }
-        const uint32_t gquad = a.quad_offset + static_cast<uint32_t>(a.quad_ids[quad]);
-        const int64_t mbase = static_cast<int64_t>(gb) * a.gb_stride + lane * kVec;
-        // where the lane's counts live: element offsets for the plain storages, BYTE offsets for the tiered one
-        const int esz = CS == kCountMixed ? a.tt.q_esz[quad] : 0;
-        const int64_t cbase = CS == kCountMixed ? a.tt.blk_base[gb] + a.tt.q_off[quad] : mbase;
-        const int64_t crow = CS == kCountMixed ? a.tt.row_bytes[gb] : a.row_stride;
-        bool on[kVec];
-        {
-            const F4 t = ld4(a.gene_active + j0);
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) on[v] = t.v[v] != 0.0f;
-        }
-        uint32_t csel[kVec] = {0u, 0u, 0u, 0u};
-        if constexpr (kProd && CS == kCountMixed) mixed_selectors(esz == 1, csel);
-        // kProd: a wave none of whose genes is frozen (every wave until batches converge) runs a row body without the 24
-        // per-element selects that keep a frozen gene's state and moments
-        bool any_off = true;
-        if constexpr (kProd) any_off = __builtin_amdgcn_ballot_w64(!(on[0] && on[1] && on[2] && on[3])) != 0ull;
-
-        // kProd: what of an element's address is the same for the whole wave (gene block, row) stays on the scalar unit
-        const uint32_t lane_bytes = static_cast<uint32_t>(lane * kVec * sizeof(float));
-        auto urow = [&](int r) { return static_cast<int64_t>(gb) * a.gb_stride + static_cast<int64_t>(r) * a.row_stride; };
-        // counts: byte offsets -- uniform start of the gene block's tile + row pitch, the lane's piece of the row
-        constexpr int kCntBytes = CS == kCountF32 ? 4 : (CS == kCountU16 ? 2 : 1);
-        const int64_t cnt_ub = CS == kCountMixed ? a.tt.blk_base[gb] : static_cast<int64_t>(gb) * a.gb_stride * kCntBytes;
-        const int64_t cnt_urow = CS == kCountMixed ? static_cast<int64_t>(a.tt.row_bytes[gb]) : a.row_stride * kCntBytes;
-        const uint32_t cnt_lb = CS == kCountMixed ? static_cast<uint32_t>(a.tt.q_off[quad]) : static_cast<uint32_t>(lane * kVec * kCntBytes);
-        const uint32_t cnt_lb2 = cnt_lb + static_cast<uint32_t>(4 * (esz - 1));
-        auto load_row = [&](int r, RowRegs<CS> &R, float (&xr)[KCX], RowScalars &rs) {
-            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-            if constexpr (CPL) {
-                if constexpr (GW) {      // the cell's Wg_loc row: lane k holds feature k (one coalesced load)
-                    R.wgl = lane < cp.kgp ? cp.Wg[static_cast<int64_t>(r) * cp.kgp + lane] : 0.0f;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < kKgMax; ++k) rs.wg[k] = cp.Wg[static_cast<int64_t>(r) * kKgMax + k];
-                }
-                rs.cb = cp.cb[r];
-                rs.clam = cp.clam[r];
-            }
-            if constexpr (kProd) {
-                uint32_t cl = cnt_lb, cl2 = cnt_lb2;
-                asm volatile("" : "+v"(cl), "+v"(cl2));     // see `lb` below
-                load_counts_at<CS, MODE>(c1p, c2p, c3p, cnt_ub + static_cast<int64_t>(r) * cnt_urow, cl, cl2, R.cnt, esz);
-            } else {
-                load_counts<CS, MODE>(c1p, c2p, c3p, cbase + static_cast<int64_t>(r) * crow, R.cnt, esz);
-            }
-            if constexpr (WIDE) {
-                if (a.mean_in_rbuf) R.mp = ld4s(rbuf + off);      // Xc . Wc_loc of this element, formed beforehand
-                else                     // the cell's design row: lane k holds feature k (one coalesced load)
-                    R.mp.v[0] = lane < a.kc_wide ? Xc[static_cast<int64_t>(r) * a.kc_wide + lane] : 0.0f;
-            }
-            if constexpr (kProd) {       // wave-uniform row base (scalar unit) + the lane's 32-bit byte offset: no address VALU
-                const int64_t ro = urow(r);
-                // instruction selection works per basic block: it must SEE that the vector part of the address is a 32-bit
-                // value to pick the scalar-base form, so the offset is made opaque here instead of living across the loop
-                // as a 64-bit pair (costs no instruction)
-                uint32_t lb = lane_bytes;
-                asm volatile("" : "+v"(lb));
-                R.mu = ld4s_at(mu_p + ro, lb);
-                R.rho = ld4s_at(rho_p + ro, lb);
-                R.mm = ld4s_at(mmu_p + ro, lb);
-                R.vm = ld4s_at(vmu_p + ro, lb);
-                R.mr = ld4s_at(mrho_p + ro, lb);
-                R.vr = ld4s_at(vrho_p + ro, lb);
-            } else if constexpr (!MARGIN) {
-                R.mu = ld4s(mu_p + off);
-                R.rho = ld4s(rho_p + off);
-                R.mm = ld4s(mmu_p + off);
-                R.vm = ld4s(vmu_p + off);
-                R.mr = ld4s(mrho_p + off);
-                R.vr = ld4s(vrho_p + off);
-            }
-#pragma unroll
-            for (int k = 0; k < KC; ++k) xr[k] = Xc[static_cast<int64_t>(r) * KC + k];   // wave-uniform
-        };
-
-        auto process_row = [&](auto frz_tag, int r, RowRegs<CS> &R, const float (&xc)[KCX], const RowScalars &rs) {
-            constexpr bool FRZ = decltype(frz_tag)::value;      // some gene of the wave may be frozen
-            const int64_t off = mbase + static_cast<int64_t>(r) * a.row_stride;
-            const bool cell = CPL && cp.cell_mode != 0;
-            const float row_isig2 = CPL ? f_exp(-2.0f * rs.clam) : 0.0f;
-            float rstat[CPL ? kKgMax + 2 : 1] = {};      // [k < 4] sum r Xg_k (register variant), [4] sum r, [5] sum (1 - d r - s2r)
-            float mg[kVec] = {0.f, 0.f, 0.f, 0.f}, rqv[kVec] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (GW) {          // Wg_loc . Xg^T: broadcast w_k with v_readlane, Xg_k from LDS
-                const int wbits = __builtin_bit_cast(int, R.wgl);
-                for (int k = 0; k < cp.Kg; ++k) {
-                    const float wk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(wbits, k));
-                    const F4 xk = ld4(xlds + k * kGenesPerBlock + lane * kVec);
-#pragma unroll
-                    for (int v = 0; v < kVec; ++v) mg[v] = fmaf(wk, xk.v[v], mg[v]);
-                }
-            }
-            F4 c1, c2, c3;
-            if constexpr (kProd && CS == kCountMixed) decode_counts_perm(R.cnt, csel, a.pc, c1, c2, c3);
-            else decode_counts<CS>(R.cnt, a.pc, c1, c2, c3);
-            if constexpr (WIDE) {        // Xc . Wc_loc: broadcast x_k with v_readlane, W_k from LDS
-                const int xbits = __builtin_bit_cast(int, R.mp.v[0]);
-                float mp[kVec] = {0.f, 0.f, 0.f, 0.f};
-                if (a.mean_in_rbuf) {
-#pragma unroll
-                    for (int v = 0; v < kVec; ++v) mp[v] = R.mp.v[v];
-                }
-                for (int k = 0; k < a.kc_wide; ++k) {
-                    const float xk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xbits, k));
-                    const F4 wk = ld4(wlds + k * kGenesPerBlock + lane * kVec);
-#pragma unroll
-                    for (int v = 0; v < kVec; ++v) mp[v] = fmaf(xk, wk.v[v], mp[v]);
-                }
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) R.mp.v[v] = mp[v];
-            }
-            // prior mean m = Xc . Wc_loc + Wg_loc . Xg^T + intercept (model_TFProb.py:118-127)
-            auto prior_mean = [&](int v) {
-                float m = cell ? rs.cb : bj[v];
-                if constexpr (WIDE) m += R.mp.v[v];                                // Xc . Wc_loc (LDS tile)
-#pragma unroll
-                for (int k = 0; k < KC; ++k) m = fmaf(xc[k], Wk[k][v], m);        // Xc . Wc_loc + intercept
-                if constexpr (CPL && !GW) {
-#pragma unroll
-                    for (int k = 0; k < kKgMax; ++k) m = fmaf(rs.wg[k], Xgk[k][v], m);   // + Wg_loc . Xg^T
-                }
-                if constexpr (GW) m += mg[v];
-                return m;
-            };
-            float gbar[kVec] = {0.f, 0.f, 0.f, 0.f}, gse[kVec] = {0.f, 0.f, 0.f, 0.f},
-                  ll[kVec] = {0.f, 0.f, 0.f, 0.f}, s[kVec];
-            if constexpr (MARGIN) {
-                // z_k = m + sigma eps_k; online log-sum-exp over the samples (gbar -> q, gse -> q_eps sigma, ll -> lme)
-                float Mx[kVec], Ss[kVec], mpr[kVec];
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) {
-                    mpr[v] = prior_mean(v);
-                    s[v] = f_exp(cell ? rs.clam : lamj[v]);
-                    Mx[v] = -INFINITY; Ss[v] = 0.0f;
-                }
-                for (int k = 0; k < a.mc; ++k) {
-                    float e[kVec];
-                    normal4(gquad, static_cast<uint32_t>(r), draw_it, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
-#pragma unroll
-                    for (int v = 0; v < kVec; ++v) {
-                        float l, g;
-                        loglik<MODE>(fmaf(s[v], e[v], mpr[v]), c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
-                                     lL0[v], lL4[v], lL5[v], l, g);
-                        const float nm = fmaxf(Mx[v], l);
-                        const float so = f_exp(Mx[v] - nm), sn = f_exp(l - nm);
-                        Ss[v] = Ss[v] * so + sn;
-                        gbar[v] = gbar[v] * so + sn * g;
-                        gse[v] = gse[v] * so + sn * g * e[v];
-                        Mx[v] = nm;
-                    }
-                }
-                const float log_mc = f_log(static_cast<float>(a.mc));
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) {
-                    const float inv = f_rcp(Ss[v]);
-                    gbar[v] *= inv;
-                    gse[v] = gse[v] * inv * s[v];
-                    ll[v] = Mx[v] + f_log(Ss[v]) - log_mc;                         // reduce_logmeanexp
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < kVec; ++v) s[v] = f_exp(R.rho.v[v]);
-
-                auto sample = [&](uint32_t k) {
-                    float e[kVec];
-                    normal4(gquad, static_cast<uint32_t>(r), draw_it, k, a.seed_lo, a.seed_hi, e);
-#pragma unroll
-                    for (int v = 0; v < kVec; ++v) {
-                        const float z = fmaf(s[v], e[v], R.mu.v[v]);          // reparameterised sample
-                        float l, g;
-                        loglik<MODE, false, kLeanLog>(z, c1.v[v], c2.v[v], c3.v[v], L0[v], L4[v], L5[v],
-                                                      lL0[v], lL4[v], lL5[v], l, g);
-                        ll[v] += l;
-                        gbar[v] += g;
-                        gse[v] = fmaf(g, e[v], gse[v]);
-                    }
-                };
-                if constexpr (kProd) {
-                    // fixed MC_size > 1: the samples' log-likelihood VALUES as products under two logarithms per element, their
-                    // derivatives -- all that reaches the state -- operation for operation as in `sample` (loglik_grad_acc2)
-                    floatx2 P1[2], PD[2], Sz[2], Saz[2], gb[2], gs[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) { P1[p] = 1.0f; PD[p] = 1.0f; Sz[p] = 0.0f; Saz[p] = 0.0f; gb[p] = 0.0f; gs[p] = 0.0f; }
-#pragma unroll
-                    for (int k = 0; k < MC; ++k) {
-                        float e[kVec];
-                        normal4(gquad, static_cast<uint32_t>(r), draw_it, static_cast<uint32_t>(k), a.seed_lo, a.seed_hi, e);
-#pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            const int u = 2 * p, w = 2 * p + 1;
-                            const floatx2 ev = {e[u], e[w]};
-                            const floatx2 z = __builtin_elementwise_fma(floatx2{s[u], s[w]}, ev, floatx2{R.mu.v[u], R.mu.v[w]});
-                            const floatx2 g = loglik_grad_acc2<MODE>(z, floatx2{c1.v[u], c1.v[w]}, floatx2{c2.v[u], c2.v[w]},
-                                                                     floatx2{c3.v[u], c3.v[w]}, floatx2{L0[u], L0[w]},
-                                                                     floatx2{L4[u], L4[w]}, floatx2{L5[u], L5[w]},
-                                                                     floatx2{iLs[u], iLs[w]}, P1[p], PD[p], Sz[p], Saz[p]);
-                            gb[p] += g;
-                            gs[p] = __builtin_elementwise_fma(g, ev, gs[p]);
-                        }
-                    }
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int u = 2 * p, w = 2 * p + 1;
-                        const floatx2 c1v = {c1.v[u], c1.v[w]}, c2v = {c2.v[u], c2.v[w]}, c3v = {c3.v[u], c3.v[w]};
-                        const floatx2 A = 0.5f * (Sz[p] - Saz[p]), B = -0.5f * (Sz[p] + Saz[p]);
-                        floatx2 lg;
-                        lg.x = f_log_sel<true>(P1[p].x); lg.y = f_log_sel<true>(P1[p].y);
-                        floatx2 l = c1v * A + c2v * B - (c1v + c2v) * lg;
-                        if (MODE != kLik2) {       // lL0 / lL4 / lL5 hold log L - log Ls here (prologue)
-                            floatx2 N = c1v + c2v, cl = c1v * floatx2{lL0[u], lL0[w]} + c2v * floatx2{lL4[u], lL4[w]};
-                            if (MODE == kLikEff3) { N += c3v; cl += c3v * floatx2{lL5[u], lL5[w]}; }
-                            floatx2 ld;
-                            ld.x = f_log_sel<true>(fmaxf(PD[p].x, 1.17549435e-38f));
-                            ld.y = f_log_sel<true>(fmaxf(PD[p].y, 1.17549435e-38f));
-                            l += static_cast<float>(MC) * cl - N * ld;
-                        }
-                        ll[u] = l.x; ll[w] = l.y;
-                        gbar[u] = gb[p].x; gbar[w] = gb[p].y;
-                        gse[u] = gs[p].x; gse[w] = gs[p].y;
-                    }
-                } else if (MC > 0) {
-#pragma unroll
-                    for (int k = 0; k < MC; ++k) sample(static_cast<uint32_t>(k));
-                } else {
-                    for (int k = 0; k < a.mc; ++k) sample(static_cast<uint32_t>(k));
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) {
-                float rr, lamstat, kl, llv;
-                if constexpr (MARGIN) {
-                    rr = gbar[v];                                                  // dL/dm = -q
-                    lamstat = -gse[v];                                             // dL/dlog(sigma) = -q_eps sigma
-                    kl = 0.0f;
-                    llv = ll[v];
-                } else {
-                    const float m = prior_mean(v);
-                    const float is2 = cell ? row_isig2 : isig2[v];
-                    const float d = R.mu.v[v] - m;
-                    rr = d * is2;                                                  // (mu - m) / sigma^2
-                    const float s2r = s[v] * s[v] * is2;                           // s^2 / sigma^2
-                    const float dl = R.rho.v[v] - (cell ? rs.clam : lamj[v]);
-                    kl = 0.5f * d * rr + 0.5f * (s2r - 1.0f) - dl;                 // KL(q || prior)
-                    lamstat = 1.0f - d * rr - s2r;
-                    llv = ll[v] * a.inv_mc;
-                    const float g_mu = rr - gbar[v] * a.inv_mc;
-                    const float g_rho = s2r - 1.0f - gse[v] * s[v] * a.inv_mc;
-                    // Keras Adam (a frozen gene keeps state and moments)
-                    const float n_mm = R.mm.v[v] + (g_mu - R.mm.v[v]) * kOneMinusB1;
-                    const float n_vm = R.vm.v[v] + (g_mu * g_mu - R.vm.v[v]) * kOneMinusB2;
-                    const float n_mr = R.mr.v[v] + (g_rho - R.mr.v[v]) * kOneMinusB1;
-                    const float n_vr = R.vr.v[v] + (g_rho * g_rho - R.vr.v[v]) * kOneMinusB2;
-                    float nmu = adam_update(R.mu.v[v], n_mm, n_vm, alpha_it);
-                    nmu = fminf(fmaxf(nmu, -9.0f), 9.0f);                          // clip constraint
-                    const float nrho = adam_update(R.rho.v[v], n_mr, n_vr, alpha_it);
-                    if constexpr (FRZ) {
-                        R.mm.v[v] = on[v] ? n_mm : R.mm.v[v];
-                        R.vm.v[v] = on[v] ? n_vm : R.vm.v[v];
-                        R.mr.v[v] = on[v] ? n_mr : R.mr.v[v];
-                        R.vr.v[v] = on[v] ? n_vr : R.vr.v[v];
-                        R.mu.v[v] = on[v] ? nmu : R.mu.v[v];
-                        R.rho.v[v] = on[v] ? nrho : R.rho.v[v];
-                    } else {
-                        R.mm.v[v] = n_mm; R.vm.v[v] = n_vm; R.mr.v[v] = n_mr; R.vr.v[v] = n_vr; R.mu.v[v] = nmu; R.rho.v[v] = nrho;
-                    }
-                }
-                if constexpr (CPL) {     // padding genes inside the last quad (Ng % 4 != 0) are not part of the cell's sums
-                    const bool real = j0 + v < a.Ng;
-                    const float rq = real ? rr : 0.0f;
-                    rqv[v] = rq;
-                    if constexpr (!GW) {
-#pragma unroll
-                        for (int k = 0; k < kKgMax; ++k) rstat[k] = fmaf(rq, Xgk[k][v], rstat[k]);
-                    }
-                    rstat[kKgMax] += rq;
-                    rstat[kKgMax + 1] += real ? lamstat : 0.0f;
-                }
-                if constexpr (WIDE) R.mp.v[v] = rr;                                // residual for wide_design_grad
-                // per-gene sufficient statistics
-#pragma unroll
-                for (int k = 0; k < KC; ++k) acc[k][v] = fmaf(xc[k], rr, acc[k][v]);
-                acc[KC + 0][v] += rr;
-                acc[KC + 1][v] += lamstat;
-                acc[KC + 2][v] += kl;
-                acc[KC + 3][v] += llv;
-            }
-            if ((!CPL && !WIDE) || active) {
-                if constexpr (kProd) {
-                    const int64_t ro = urow(r);
-                    uint32_t lb = lane_bytes;
-                    asm volatile("" : "+v"(lb));
-                    st4s_at(mu_p + ro, lb, R.mu);
-                    st4s_at(rho_p + ro, lb, R.rho);
-                    st4s_at(mmu_p + ro, lb, R.mm);
-                    st4s_at(vmu_p + ro, lb, R.vm);
-                    st4s_at(mrho_p + ro, lb, R.mr);
-                    st4s_at(vrho_p + ro, lb, R.vr);
-                } else if constexpr (!MARGIN) {
-                    st4s(mu_p + off, R.mu);
-                    st4s(rho_p + off, R.rho);
-                    st4s(mmu_p + off, R.mm);
-                    st4s(vmu_p + off, R.vm);
-                    st4s(mrho_p + off, R.mr);
-                    st4s(vrho_p + off, R.vr);
-                }
-                if constexpr (WIDE) st4s(rbuf + off, R.mp);
-            }
-            if constexpr (CPL) {        // per-cell statistics: reduce the wave's 256 genes, one value per cell
-                float *chunk = cp.row_partials + static_cast<int64_t>(gb) * (cp.kgp + 2) * a.Nc;
-                if constexpr (GW) {
-                    // sum_j r_j Xg[j, k] for 8 features at a time; lane l ends up with feature 8 (l & 7) + (l >> 3)
-                    float mine = 0.0f;
-                    for (int g = 0; g * 8 < cp.kgp; ++g) {
-                        float t[8];
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            t[i] = 0.0f;
-                            if (g * 8 + i < cp.kgp) {
-                                const F4 xk = ld4(xlds + (g * 8 + i) * kGenesPerBlock + lane * kVec);
-#pragma unroll
-                                for (int v = 0; v < kVec; ++v) t[i] = fmaf(rqv[v], xk.v[v], t[i]);
-                            }
-                        }
-                        const float c = wave_sum8(t, lane);
-                        mine = (lane & 7) == g ? c : mine;
-                    }
-                    const int kf = 8 * (lane & 7) + (lane >> 3);
-                    if (kf < cp.kgp) chunk[static_cast<int64_t>(r) * cp.kgp + kf] = mine;
-                } else {
-                    float mine = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < kKgMax; ++q) {
-                        const float t = wave_sum(active ? rstat[q] : 0.0f);
-                        mine = lane == q ? t : mine;
-                    }
-                    if (lane < kKgMax) chunk[static_cast<int64_t>(r) * kKgMax + lane] = mine;
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const float t = wave_sum(active ? rstat[kKgMax + q] : 0.0f);
-                    if (lane == 0) chunk[static_cast<int64_t>(cp.kgp + q) * a.Nc + r] = t;
-                }
-            }
-        };
-
-        // Software-pipelined row loop: the 16-B loads of the wave's NEXT row are issued before the
-        // ~1200-instruction body of the current row, so each wave keeps 8 KiB of HBM reads in
-        // flight while it computes (only 2 waves/SIMD fit at this register footprint).  The body
-        // is branch-free; the last row is peeled so no load is ever issued for a row that is not used.
-        if constexpr (kProd) {        // two copies of the loop: with and without the frozen-gene selects
-            auto run_rows = [&](auto frz_tag) {
-                int r = row0 + w;
-                const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
-                RowRegs<CS> cur;
-                float xc[KCX];
-                RowScalars rsc{};
-                load_row(r, cur, xc, rsc);
-                while (r < r_last) {
-                    RowRegs<CS> nxt;
-                    float xn[KCX];
-                    RowScalars rsn{};
-                    load_row(r + kWavesPerBlock, nxt, xn, rsn);
-                    process_row(frz_tag, r, cur, xc, rsc);
-                    cur = nxt;
-                    rsc = rsn;
-    #pragma unroll
-                    for (int k = 0; k < KC; ++k) xc[k] = xn[k];
-                    r += kWavesPerBlock;
-                }
-                process_row(frz_tag, r, cur, xc, rsc);
-            };
-            if (any_off) run_rows(std::true_type{});
-            else run_rows(std::false_type{});
-        } else {                      // (spelled out, not through the lambda: these instantiations' code is round 4's, unchanged)
-            int r = row0 + w;
-            const int r_last = r + ((row_end - 1 - r) / kWavesPerBlock) * kWavesPerBlock;
-            RowRegs<CS> cur;
-            float xc[KCX];
-            RowScalars rsc{};
-            load_row(r, cur, xc, rsc);
-            while (r < r_last) {
-                RowRegs<CS> nxt;
-                float xn[KCX];
-                RowScalars rsn{};
-                load_row(r + kWavesPerBlock, nxt, xn, rsn);
-                process_row(std::true_type{}, r, cur, xc, rsc);
-                cur = nxt;
-                rsc = rsn;
-#pragma unroll
-                for (int k = 0; k < KC; ++k) xc[k] = xn[k];
-                r += kWavesPerBlock;
-            }
-            process_row(std::true_type{}, r, cur, xc, rsc);
-        }
-    }
-
-    // fold the 4 waves' per-gene partials through LDS, wave 0 writes the chunk row
-    if constexpr (GW) __syncthreads();      // every wave is done reading the Xg tile the fold overwrites
-    if (w > 0) {
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int v = 0; v < kVec; ++v)
-                red[((w - 1) * S + s) * kGenesPerBlock + v * kWave + lane] = acc[s][v];
-    }
-    __syncthreads();
-    float *const part_it = (PERSIST && (it & 1)) ? ps->partials2 : partials;
-    if (w == 0 && active) {
-        float *dst = part_it + (static_cast<int64_t>(blockIdx.y) * S) * a.ld + j0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            F4 o;
-#pragma unroll
-            for (int v = 0; v < kVec; ++v) {
-                float t = acc[s][v];
-#pragma unroll
-                for (int ww = 0; ww < kWavesPerBlock - 1; ++ww)
-                    t += red[(ww * S + s) * kGenesPerBlock + v * kWave + lane];
-                o.v[v] = t;
-            }
-            if constexpr (PERSIST) {       // write-through (sc1): leaves this XCD's L2 at once, no release fence needed later
-                const floatx4 t4 = {o.v[0], o.v[1], o.v[2], o.v[3]};
-                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + s * a.ld), "v"(t4) : "memory");
-            } else {
-                st4(dst + s * a.ld, o);
-            }
-        }
-    }
-    if constexpr (PERSIST) {
-        // ---- barrier of the gene block: every chunk's partial row of this step is in memory.  Per-XCD L2s are not coherent with
-        // each other and a CU's L1 is never refreshed by another CU's stores, and the fences that would make plain accesses
-        // safe cost microseconds each (L2 write-back, L1 invalidate) -- so the rows are PUBLISHED write-through (sc1 stores,
-        // drained with s_waitcnt before the arrival) and READ with sc1 loads that bypass L1; the counter is an agent-scope atomic
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (!((ps->debug & 8) && blockIdx.y == 0 && it == 1))       // (tests: chunk 0 "never arrives" at the second step)
-                __hip_atomic_fetch_add(ps->barrier + gb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t want = static_cast<uint32_t>(it + 1) * gridDim.y;
-            // the wait is BOUNDED (~10 s of polling): should a workgroup of the block never become resident -- the launch is
-            // made only when the occupancy query says the grid fits, but other kernels may hold CUs -- the kernel ends with a
-            // flag the host turns into an error (the state is then undefined) instead of spinning on the GPU for ever
-            uint32_t spins = 0;
-            while (!(ps->debug & 1) && __hip_atomic_load(ps->barrier + gb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                __builtin_amdgcn_s_sleep(0);
-                if (++spins > ((ps->debug >> 8) ? 1u << ((ps->debug >> 8) & 31) : 1u << 24)) {
-                    __hip_atomic_store(ps->barrier + gridDim.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        // ---- gene_finalize's work for gene t of the block, on the LDS copy (finalize_gene_stat, statistic by statistic)
-        const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
-        const int slot = (ps->ring_pos0 + it) % kLossRing, prev = (slot + kLossRing - 1) % kLossRing;
-        const bool first = blockIdx.y == 0;                 // this workgroup also writes what the step leaves in memory
-        double t_kl = 0.0, t_ll = 0.0;
-        if (jj < ps->fin_Ng && !(ps->debug & 2)) {
-            if (a.gene_active[jj] == 0.0f) {                // frozen gene: parameters untouched, last loss terms carried forward
-                const float lk = ps->ring_kl[static_cast<int64_t>(prev) * a.ld + jj], ll_ = ps->ring_ll[static_cast<int64_t>(prev) * a.ld + jj];
-                if (first) {
-                    ps->ring_kl[static_cast<int64_t>(slot) * a.ld + jj] = lk;
-                    ps->ring_ll[static_cast<int64_t>(slot) * a.ld + jj] = ll_;
-                }
-                t_kl = static_cast<double>(lk); t_ll = static_cast<double>(ll_);
-            } else {
-                const int64_t stride = static_cast<int64_t>(S) * a.ld;
-                const int n_chunks = static_cast<int>(gridDim.y);
-                // the chunk partials of all S statistics, eight chunks of every statistic in flight at once (the loads are L2
-                // round trips: one after the other they were most of a step), summed in fp64 in chunk order as gene_finalize does
-                double tsum[S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) tsum[s] = 0.0;
-                constexpr int kB = S <= 8 ? 16 : 8;       // chunk rows in flight per statistic (registers: S x kB floats)
-                for (int c0 = 0; c0 < n_chunks; c0 += kB) {
-                    float xv[S][kB];
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-#pragma unroll
-                        for (int u = 0; u < kB; ++u)
-                            xv[s][u] = __hip_atomic_load(part_it + static_cast<int64_t>(s) * a.ld + jj + min(c0 + u, n_chunks - 1) * stride,
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (no guarded load: they serialise)
-#pragma unroll
-                    for (int s = 0; s < S; ++s)
-#pragma unroll
-                        for (int u = 0; u < kB; ++u)
-                            if (c0 + u < n_chunks) tsum[s] += static_cast<double>(xv[s][u]);
-                }
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const double t = tsum[s];
-                    float *x = pstate + (3 * s) * kGenesPerBlock + threadIdx.x;          // x, m, v of parameter s (s < KC + 2)
-                    if (s < KC) {
-                        adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(-t), alpha_it);
-                    } else if (s == KC) {
-                        if (ps->train_b) {
-                            adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(-t), alpha_it);
-                            x[0] = fminf(fmaxf(x[0], -9.0f), 9.0f);
-                        }
-                    } else if (s == KC + 1) {
-                        if (ps->train_lam) adam_scalar_exact(x[0], x[kGenesPerBlock], x[2 * kGenesPerBlock], static_cast<float>(t), alpha_it);
-                    } else {
-                        if (first) (s == KC + 2 ? ps->ring_kl : ps->ring_ll)[static_cast<int64_t>(slot) * a.ld + jj] = static_cast<float>(t);
-                        if (s == KC + 2) t_kl = t; else t_ll = t;
-                    }
-                }
-            }
-        }
-        if (first) {                                       // workgroup-uniform; both terms through block_sum_f64's tree at once
-            psum[threadIdx.x] = t_kl;
-            psum2[threadIdx.x] = t_ll;
-            __syncthreads();
-            for (int st = kBlock / 2; st > 0; st >>= 1) {
-                if (static_cast<int>(threadIdx.x) < st) {
-                    psum[threadIdx.x] += psum[threadIdx.x + st];
-                    psum2[threadIdx.x] += psum2[threadIdx.x + st];
-                }
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 0] = psum[0];
-                ps->loss_parts[(static_cast<int64_t>(it) * gridDim.x + gb) * 2 + 1] = psum2[0];
-            }
-        }
-        __syncthreads();                                   // the LDS copy is complete before the next step's rows read it
-    }
-    }  // for (it)
-    if constexpr (PERSIST) {
-        if (blockIdx.y == 0) {
-            const int jj = gb * kGenesPerBlock + static_cast<int>(threadIdx.x);
-#pragma unroll
-            for (int k = 0; k < KC; ++k) {
-                ps->W[k * a.ld + jj] = pstate[(3 * k + 0) * kGenesPerBlock + threadIdx.x];
-                ps->m_W[k * a.ld + jj] = pstate[(3 * k + 1) * kGenesPerBlock + threadIdx.x];
-                ps->v_W[k * a.ld + jj] = pstate[(3 * k + 2) * kGenesPerBlock + threadIdx.x];
-            }
-            ps->b[jj] = pstate[(3 * KC + 0) * kGenesPerBlock + threadIdx.x];
-            ps->m_b[jj] = pstate[(3 * KC + 1) * kGenesPerBlock + threadIdx.x];
-            ps->v_b[jj] = pstate[(3 * KC + 2) * kGenesPerBlock + threadIdx.x];
-            ps->lam[jj] = pstate[(3 * KC + 3) * kGenesPerBlock + threadIdx.x];
-            ps->m_lam[jj] = pstate[(3 * KC + 4) * kGenesPerBlock + threadIdx.x];
-            ps->v_lam[jj] = pstate[(3 * KC + 5) * kGenesPerBlock + threadIdx.x];
-        }
-    }
+// The PERSIST variant as its own kernel (uncoupled, Kc <= 8, ELBO): the same body text inside the loop over the steps.
+template <int KC, int MODE, int MC, int CS>
+__global__ __launch_bounds__(kBlock, 1) void elbo_adam_fused_steps(
+    const void *__restrict__ c1p, const void *__restrict__ c2p, const void *__restrict__ c3p,
+    float *__restrict__ mu_p, float *__restrict__ rho_p, float *__restrict__ mmu_p,
+    float *__restrict__ vmu_p, float *__restrict__ mrho_p, float *__restrict__ vrho_p,
+    const float *__restrict__ Xc, const float *__restrict__ Wp, const float *__restrict__ bp,
+    const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
+    const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf) {
+    constexpr bool PERSIST = true, CPL = false, WIDE = false, GW = false, MARGIN = false;
+#define BRIE_STEP_LOOP_BEGIN const int n_it = ps->n_steps; for (int it = 0; it < n_it; ++it) {
+#define BRIE_STEP_LOOP_END }
+#include "brie_step_body.inc"
+#undef BRIE_STEP_LOOP_BEGIN
+#undef BRIE_STEP_LOOP_END
 }
 
 #ifdef BRIE_HOST_TU   // non-template kernels: defined once, in brie_capi.hip's translation unit

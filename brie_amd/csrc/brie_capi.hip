@@ -183,6 +183,9 @@ struct brie_handle {
     size_t persist_alphas_elems = 0, partials2_elems = 0;
     uint32_t *persist_barrier = nullptr;
     uint32_t *persist_flag_host = nullptr;  // pinned: the time-out word of the last fused launch, copied back behind it
+    std::vector<float> persist_alphas_host; // host sources of the per-call uploads (alive until persist_copy_event has passed)
+    brie::PersistArgs persist_args_host{};
+    hipEvent_t persist_copy_event = nullptr;
     int64_t persist_launches = 0, persist_steps = 0;
     int placement_cfg_sets = 0;             // brie_placement_configure: 0 = the library's default
     double placement_cfg_frac = 0.0, placement_cfg_seconds = 0.0;
@@ -1224,6 +1227,7 @@ int brie_destroy(brie_handle *h) {
     if (h->persist_alphas) hipFree(h->persist_alphas);
     if (h->persist_barrier) hipFree(h->persist_barrier);
     if (h->persist_flag_host) hipHostFree(h->persist_flag_host);
+    if (h->persist_copy_event) hipEventDestroy(h->persist_copy_event);
     if (h->partials2) hipFree(h->partials2);
     if (h->win_scratch) hipFree(h->win_scratch);
     if (h->io_stream) hipStreamDestroy(h->io_stream);
@@ -2168,9 +2172,16 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
                 HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&h->persist_flag_host), sizeof(uint32_t), hipHostMallocDefault));
                 *h->persist_flag_host = 0;
             }
-            std::vector<float> alphas(static_cast<size_t>(n_steps));
+            // host sources of the two small uploads live in the handle and are guarded by an event: the call only ENQUEUES (as
+            // brie_step promises with loss_trace == NULL); it waits -- for the copies of the PREVIOUS fused call, long done --
+            // before it overwrites them
+            if (!h->persist_copy_event) HIP_TRY(hipEventCreateWithFlags(&h->persist_copy_event, hipEventDisableTiming));
+            else HIP_TRY(hipEventSynchronize(h->persist_copy_event));
+            std::vector<float> &alphas = h->persist_alphas_host;
+            alphas.resize(static_cast<size_t>(n_steps));
             for (int i = 0; i < n_steps; ++i) alphas[i] = adam_alpha(h->t + 1 + i);
-            brie::PersistArgs pa{};
+            brie::PersistArgs &pa = h->persist_args_host;
+            pa = brie::PersistArgs{};
             pa.alphas = h->persist_alphas; pa.barrier = h->persist_barrier; pa.partials2 = h->partials2;
             pa.W = h->W; pa.m_W = h->m_W; pa.v_W = h->v_W; pa.b = h->b; pa.m_b = h->m_b; pa.v_b = h->v_b;
             pa.lam = h->lam; pa.m_lam = h->m_lam; pa.v_lam = h->v_lam; pa.ring_kl = h->ring_kl; pa.ring_ll = h->ring_ll;
@@ -2181,7 +2192,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemsetAsync(h->persist_barrier, 0, sizeof(uint32_t) * (h->gene_blocks + 1), h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));      // `alphas` and `pa` are pageable host memory of this frame
+            HIP_TRY(hipEventRecord(h->persist_copy_event, h->stream));
             a.alpha = alphas[0];
             a.draw = h->draw;
             const int n_cus = device_cus(h->p.device);

@@ -2153,7 +2153,8 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     // them, bit for bit).  Allowed for an uncoupled model with Kc <= 8, ELBO target, no frozen gene, MC_size 1 or 3 and a grid the
     // device holds at once; AUTOMATIC only where it was measured faster than two launches per step (calls r6k, r6l): at most 16
     // cell chunks (every workgroup of a gene block re-reads all of the block's chunk rows: the cost grows with their square)
-    // and at most a quarter of the CUs busy -- configs[0]: 9.0 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
+    // and at most a fifth of the CUs busy (call r7d: 48 workgroups 9.1 against 11.1 us, 64: 11.4 / 12.2 at MC_size 1 but 14.4 / 13.9
+    // at MC_size 3, 104: a tie, 140 and more: slower) -- configs[0]: 9.0 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
     int i_start = 0;
     {
         static const int env_mode = [] { const char *e = getenv("BRIE_FUSE_STEPS"); return e ? atoi(e) : -1; }();
@@ -2161,7 +2162,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         const bool can = !h->coupled && !h->wide_like && h->target == 0 && !split && !h->profiling && !h->any_frozen && !h->packed &&
                          (mc_size == 1 || mc_size == 3) && n_steps >= 2;
         const bool want = mode == 1 || (mode < 0 && h->n_chunks <= 16 &&
-                                        static_cast<int64_t>(h->n_chunks) * h->gene_blocks * 4 <= device_cus(h->p.device));
+                                        static_cast<int64_t>(h->n_chunks) * h->gene_blocks * 5 <= device_cus(h->p.device));
         if (can && want) {
             const size_t pneed = static_cast<size_t>(h->n_chunks) * h->S * h->ld;
             if ((rc = ensure_f32(&h->partials2, &h->partials2_elems, pneed, h->stream)) != BRIE_OK) return rc;

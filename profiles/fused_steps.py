@@ -23,6 +23,13 @@ def main():
     from brie_amd import _capi
     from tests import util
     steps = int(os.environ.get("STEPS", "500"))
+    global SHAPES
+    if os.environ.get("SHAPES"):            # "NcxNgxKcxL[e],..." (e = with effective lengths)
+        SHAPES = []
+        for t in os.environ["SHAPES"].split(","):
+            eff = t.endswith("e")
+            Nc, Ng, Kc, L = (int(x) for x in t.rstrip("e").split("x"))
+            SHAPES.append(("%d x %d, Kc %d, L %d%s" % (Nc, Ng, Kc, L, ", effLen" if eff else ""), Nc, Ng, Kc, L, eff))
     out = {"steps_per_call": steps, "cases": []}
     for name, Nc, Ng, Kc, L, eff in SHAPES:
         P = util.problem(Nc, Ng, Kc, L, seed=77)

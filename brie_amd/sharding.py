@@ -43,19 +43,19 @@ class GeneComm(object):
         self.backend = dist.get_backend(group)
         self.device = device
         self._native, self._native_tried, self.native_error = None, False, None
-        # how many ranks of the group run on THIS rank's GPU (world-8 dry runs on one device; several ranks per GPU in
-        # production are the caller's choice): each reads the same free-HBM figure when the library sizes its placement
-        # search, so the engine hands every handle 0.8 / that many of it (brie_placement_configure).  Collective:
-        # every rank constructs its GeneComm once.
+        # how many ranks of this node share one GPU (world-8 dry runs on one device): each reads the same free-HBM figure when
+        # the library sizes its placement search, so the engine hands every handle 0.8 / that many of it
+        # (brie_placement_configure).  From the launcher's environment and the device count -- NO collective: the
+        # constructor must not add one to a path that has never run between two GPUs.
         self.ranks_on_device = 1
         try:
-            import socket
-            dev = device.index if hasattr(device, "index") else device
-            mine = (socket.gethostname(), -1 if dev is None else int(dev))
-            everyone = [None] * self.world
-            dist.all_gather_object(everyone, mine, group=group)
-            self.ranks_on_device = max(1, sum(1 for e in everyone if e == mine))
-        except Exception:                                  # a backend without object collectives: keep the library's default
+            import os
+            import torch
+            local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "1"))
+            n_dev = torch.cuda.device_count() if device is not None else 0
+            if n_dev > 0 and local_world > n_dev:
+                self.ranks_on_device = -(-local_world // n_dev)
+        except Exception:
             self.ranks_on_device = 1
 
     def _on_rccl(self):

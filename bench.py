@@ -506,6 +506,11 @@ def main(argv=None):
     Xc, size, layers, eff_all = make_inputs(torch, dev, cfg, g0, g1, seed)
 
     sh = _capi.Shard(Nc, ng, Kc, n_layers=L, has_efflen=L == 3, seed=seed, device=local_rank, gene_offset=g0)
+    # the library's default since round 6 is ONE round of the placement search (4 sets: at most 3 further copies of the
+    # streamed arrays held meanwhile); a caller that owns its GPU may ask for more -- this one does and says so in the line
+    placement_sets = int(os.environ.get("BRIE_BENCH_PLACEMENT_SETS", "8"))
+    if hasattr(sh, "placement_configure"):
+        sh.placement_configure(max_sets=placement_sets)
     if args.count_storage == "f32":
         sh.set_count_storage(1)
     for l in range(L):
@@ -695,7 +700,8 @@ def main(argv=None):
             roof["per_gpu"] = gpus
         # where the allocator put the streamed arrays decides 10 - 20 % of the step time: the library probes
         # and keeps the fastest of up to three placements before the first step; the rates are storage bytes / probe time
-        roof["placement"] = placement
+        roof["placement"] = dict(placement, max_sets_asked=placement_sets,
+                                 note_on_sets="brie_placement_configure by bench.py; the library's default is 4 for arrays >= 1 GiB")
         if mc_other is not None:
             roof["mc%d" % mc_other["MC_size"]] = mc_other
         if f32_leg is not None:

@@ -364,6 +364,28 @@ def test_gene_shard_alignment():
         gene_shard(26, 0, 2, 6)
 
 
+def test_every_prototype_of_the_header_is_bound_with_its_arity(built_lib):
+    """a signature that changes in include/brie_amd.h without its ctypes binding following links, loads and
+    then corrupts the stack.  Every prototype of the header must be exported by the library, be listed in _capi.EXPORTS
+    and -- where the binding declares argument types -- take as many arguments as the header says."""
+    import re
+    from brie_amd import _capi
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "brie_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = re.findall(r"\n(?:int|int64_t|const char \*|void)\s*\*?\s*(brie_\w+)\s*\(([^;{]*?)\)\s*;", hdr)
+    assert len(protos) >= 60, len(protos)
+    names = [n for n, _ in protos]
+    assert sorted(set(names)) == sorted(names)
+    missing = sorted(set(names) - set(_capi.EXPORTS))
+    extra = sorted(set(_capi.EXPORTS) - set(names))
+    assert not missing and not extra, (missing, extra)
+    for name, args in protos:
+        n = 0 if args.strip() in ("", "void") else len(args.split(","))
+        fn = getattr(built_lib, name)
+        if fn.argtypes is not None:
+            assert len(fn.argtypes) == n, (name, n, len(fn.argtypes))
+
+
 def test_lrt_models_share_one_device_copy_of_the_counts(monkeypatch):
     """fit_BRIE_matrix hands the count-holding handle from model to model (brie_reconfigure): the layers are uploaded
     once for base + 2 test models, results equal the fresh-model-per-feature run (model_wrap.py:155-187)."""

@@ -944,7 +944,9 @@ def test_many_steps_per_launch_are_bit_identical_to_the_two_launch_path(lib, i, 
         assert np.array_equal(ta, tb), (n, lr, ta, tb)
         same("stage of %d steps" % n)
     info = b.step_fusion_info()
-    assert info == {"launches": 3, "steps": 14} and a.step_fusion_info()["launches"] == 0, info
+    # (a grid the device cannot hold at once -- beyond ~256 workgroups -- is declined by the launcher: two launches, as `a`)
+    assert info in ({"launches": 3, "steps": 14}, {"launches": 0, "steps": 0}) and a.step_fusion_info()["launches"] == 0, info
+    assert info["launches"] == 3 or Nc * Ng > 200 * 1000, (info, Nc, Ng)
     assert np.array_equal(a.read_loss_window(9), b.read_loss_window(9))                 # the loss ring of the last stages
     # the moments: continue WITHOUT a fresh optimiser, paths swapped
     a.set_step_fusion(1); b.set_step_fusion(0)

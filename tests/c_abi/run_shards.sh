@@ -11,7 +11,8 @@ NDEV=${2:-$(ls -d /sys/class/kfd/kfd/topology/nodes/*/ 2>/dev/null | while read 
 ID=$(mktemp -u /tmp/brie_comm_id.XXXXXX)
 PIDS=()
 for R in $(seq 0 $((WORLD - 1))); do
-  HSA_ENABLE_IPC_MODE_LEGACY=0 "$EXE" $R $WORLD $ID $NDEV &
+  # every rank under its own watchdog: a rank that dies before brie_comm_init leaves the others inside ncclCommInitRank
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout -k 5 ${BRIE_SHARDS_TIMEOUT:-300} "$EXE" $R $WORLD $ID $NDEV &
   PIDS+=($!)
 done
 RC=0

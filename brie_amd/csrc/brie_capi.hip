@@ -2154,7 +2154,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     // device holds at once; AUTOMATIC only where it was measured faster than two launches per step (calls r6k, r6l): at most 16
     // cell chunks (every workgroup of a gene block re-reads all of the block's chunk rows: the cost grows with their square)
     // and at most a fifth of the CUs busy (call r7d: 48 workgroups 9.1 against 11.1 us, 64: 11.4 / 12.2 at MC_size 1 but 14.4 / 13.9
-    // at MC_size 3, 104: a tie, 140 and more: slower) -- configs[0]: 9.0 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
+    // at MC_size 3, 104: a tie, 140 and more: slower) -- configs[0]: 8.2 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
     int i_start = 0;
     {
         static const int env_mode = [] { const char *e = getenv("BRIE_FUSE_STEPS"); return e ? atoi(e) : -1; }();

@@ -704,7 +704,7 @@ __global__ __launch_bounds__(kBlock, (BRIE_TWO_WAVES_COND) ? 2 : 1) void elbo_ad
     const float *__restrict__ lamp, const float *__restrict__ effL, float *__restrict__ partials,
     const StepScalars a, const CoupledArgs cp, float *__restrict__ rbuf = nullptr) {
     constexpr bool PERSIST = false;
-    constexpr int it = 0;
+    constexpr int it = 0, n_it = 1;
 #define BRIE_STEP_LOOP_BEGIN
 #define BRIE_STEP_LOOP_END
 #include "brie_step_body.inc"

@@ -2154,7 +2154,10 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
     // device holds at once; AUTOMATIC only where it was measured faster than two launches per step (calls r6k, r6l): at most 16
     // cell chunks (every workgroup of a gene block re-reads all of the block's chunk rows: the cost grows with their square)
     // and at most a fifth of the CUs busy (call r7d: 48 workgroups 9.1 against 11.1 us, 64: 11.4 / 12.2 at MC_size 1 but 14.4 / 13.9
-    // at MC_size 3, 104: a tie, 140 and more: slower) -- configs[0]: 8.2 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
+    // at MC_size 3, 104: a tie, 140 and more: slower) -- configs[0]: 8.0 against 11.3 us per step; 300 x 2000: 15.7 against 12.3, so not there.
+    // With at most 8 gene blocks the launcher gives every gene block an XCD of its own (persist_launch); there one launch also wins
+    // with up to 8 x 16 workgroups while Kc <= 3 (calls r8r, r8s: 200 x 2000 8.4 - 10.9 against 10.6 - 12.3 us, MC_size 3 10.4 - 13.5
+    // against 12.1 - 14.0; from Kc = 4 a tie at MC_size 3, from Kc = 6 a loss).
     int i_start = 0;
     {
         static const int env_mode = [] { const char *e = getenv("BRIE_FUSE_STEPS"); return e ? atoi(e) : -1; }();
@@ -2162,7 +2165,8 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
         const bool can = !h->coupled && !h->wide_like && h->target == 0 && !split && !h->profiling && !h->any_frozen && !h->packed &&
                          (mc_size == 1 || mc_size == 3) && n_steps >= 2;
         const bool want = mode == 1 || (mode < 0 && h->n_chunks <= 16 &&
-                                        static_cast<int64_t>(h->n_chunks) * h->gene_blocks * 5 <= device_cus(h->p.device));
+                                        (static_cast<int64_t>(h->n_chunks) * h->gene_blocks * 5 <= device_cus(h->p.device) ||
+                                         (h->gene_blocks <= 8 && h->kernel_kc <= 3)));
         if (can && want) {
             const size_t pneed = static_cast<size_t>(h->n_chunks) * h->S * h->ld;
             if ((rc = ensure_f32(&h->partials2, &h->partials2_elems, pneed, h->stream)) != BRIE_OK) return rc;
@@ -2188,7 +2192,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             pa.lam = h->lam; pa.m_lam = h->m_lam; pa.v_lam = h->v_lam; pa.ring_kl = h->ring_kl; pa.ring_ll = h->ring_ll;
             pa.loss_parts = h->loss_parts; pa.n_steps = n_steps;
             pa.ring_pos0 = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
-            pa.train_b = f.train_b; pa.train_lam = f.train_lam; pa.fin_Ng = f.Ng;
+            pa.train_b = f.train_b; pa.train_lam = f.train_lam; pa.fin_Ng = f.Ng; pa.gene_blocks = h->gene_blocks;
             pa.debug = h->persist_debug;          // brie_debug_step_fusion (tests / experiments): an explicit call, no variable
             HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));

@@ -691,6 +691,7 @@ struct PersistArgs {
     float *ring_kl, *ring_ll;   // (kLossRing, ld)
     double *loss_parts;         // (n_steps, gene_blocks, 2)
     int32_t n_steps, ring_pos0, train_b, train_lam, fin_Ng;
+    int32_t gene_blocks;        // gridDim.x may be larger: columns beyond it exit at once (persist_launch)
     int32_t debug;              // experiments / tests (brie_debug_step_fusion; results are then wrong): 1 no barrier wait, 2 no finalize,
                                 // 4 no rows, 8 chunk 0 skips its second arrival; bits 8..: log2 of the poll bound (default 24)
 };

@@ -166,7 +166,8 @@ int brie_step(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size,
  * uncoupled, Kc <= 8, ELBO target, no frozen gene, MC_size 1 or 3, n_steps >= 2, the whole grid resident: the workgroups of a
  * gene block meet at a barrier per step (rows published write-through, read past L1) and each applies the per-gene update
  * itself.  State, loss trace and loss ring are bit-identical to the two-launch path.  It is AUTOMATIC only where it measured
- * faster: at most 16 cell chunks (Nc <= 256) and 5 x workgroups <= CUs -- 8.2 against 11.3 us per step at configs[0].
+ * faster: at most 16 cell chunks (Nc <= 256) and either 5 x workgroups <= CUs or at most 8 gene blocks (2 048 genes: each gets
+ * an XCD of its own) with Kc <= 3 -- 8.0 against 11.3 us per step at configs[0].
  * brie_set_step_fusion: -1 automatic (default; BRIE_FUSE_STEPS=0 / 1 overrides), 0 never, 1 whenever the model allows it.
  * brie_step_fusion_info: launches of that kind so far and the steps they carried. */
 int brie_set_step_fusion(brie_handle *h, int32_t mode);

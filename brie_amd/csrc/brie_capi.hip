@@ -19,6 +19,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -187,6 +188,7 @@ struct brie_handle {
     brie::PersistArgs persist_args_host{};
     hipEvent_t persist_copy_event = nullptr;
     int64_t persist_launches = 0, persist_steps = 0;
+    int persist_serial = -1;                // which fused-launching handle of this process this is (column offset of its gene blocks)
     int placement_cfg_sets = 0;             // brie_placement_configure: 0 = the library's default
     double placement_cfg_frac = 0.0, placement_cfg_seconds = 0.0;
     int placement_inject = 0;               // brie_debug_inject_placement_failure (tests): fails ONE search of this handle
@@ -2193,6 +2195,21 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             pa.loss_parts = h->loss_parts; pa.n_steps = n_steps;
             pa.ring_pos0 = static_cast<int32_t>(h->ring_pos % brie::kLossRing);
             pa.train_b = f.train_b; pa.train_lam = f.train_lam; pa.fin_Ng = f.Ng; pa.gene_blocks = h->gene_blocks;
+            // One XCD per gene block where there are at most 8 and a column's workgroups fit one XCD's CUs: workgroups are dealt round
+            // robin over the 8 XCDs by linear id, so with a grid of (8, chunks) column x runs on XCD x (HW_REG_XCC_ID:
+            // profiles/micro/xcd_local_barrier.hip); columns without a gene block exit at once.  The hand-off protocol does not
+            // depend on it (it is correct across XCDs); inside one XCD it is shorter (call r8q).  Handles and processes start at
+            // different columns, so that small fits running side by side do not all queue for XCD 0.
+            const int n_cus = device_cus(h->p.device);
+            brie::LaunchCfg pcfg = cfg;
+            if (h->gene_blocks <= 8 && h->n_chunks <= n_cus / 8) {
+                static std::atomic<int> serial{0};
+                if (h->persist_serial < 0) h->persist_serial = serial.fetch_add(1);
+                pa.columns = 8;
+                pa.col_offset = static_cast<int32_t>((static_cast<int64_t>(h->persist_serial) + static_cast<int64_t>(getpid())) * h->gene_blocks % 8);
+                pcfg.grid.x = 8;
+                pcfg.persist_columns = 8;
+            }
             pa.debug = h->persist_debug;          // brie_debug_step_fusion (tests / experiments): an explicit call, no variable
             HIP_TRY(hipMemcpyAsync(h->persist_alphas, alphas.data(), alphas.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
             HIP_TRY(hipMemcpyAsync(h->persist_args, &pa, sizeof(pa), hipMemcpyHostToDevice, h->stream));
@@ -2200,8 +2217,7 @@ int run_steps(brie_handle *h, int32_t n_steps, float lr, int32_t mc_size, float 
             HIP_TRY(hipEventRecord(h->persist_copy_event, h->stream));
             a.alpha = alphas[0];
             a.draw = h->draw;
-            const int n_cus = device_cus(h->p.device);
-            if (h->fin_blocks == h->gene_blocks && launch_step_persist(h, cfg, q, a, h->persist_args, n_cus) == 1) {
+            if (h->fin_blocks == h->gene_blocks && launch_step_persist(h, pcfg, q, a, h->persist_args, n_cus) == 1) {
                 h->t += n_steps;
                 h->draw += static_cast<uint32_t>(n_steps);
                 h->ring_pos += n_steps;

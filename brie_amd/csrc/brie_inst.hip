@@ -116,13 +116,11 @@ int persist_launch(const LaunchCfg &c, const StepPointers &q, const StepScalars 
         (void)hipGetLastError();
         return nb;
     }();
-    // One XCD per gene block where that fits: workgroups are dealt round robin over the 8 XCDs by linear id, so with 8 columns
-    // column x runs on XCD x (HW_REG_XCC_ID: profiles/micro/xcd_local_barrier.hip); columns beyond the gene blocks exit at
-    // once.  The hand-off protocol does not depend on it (it is correct across XCDs); it is 0.6 us per step shorter inside one.
-    dim3 grid = c.grid;
-    if (c.grid.x <= 8 && static_cast<int64_t>(c.grid.y) <= static_cast<int64_t>(n_cus / 8) * per_cu) grid.x = 8;
-    if (static_cast<int64_t>(grid.x) * grid.y > static_cast<int64_t>(per_cu) * n_cus) return 0;
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho,
+    // (c.grid.x may be 8 columns for fewer gene blocks -- one XCD per gene block, brie_capi.hip run_steps: a column's workgroups
+    // must then fit the CUs of ONE XCD)
+    if (static_cast<int64_t>(c.grid.x) * c.grid.y > static_cast<int64_t>(per_cu) * n_cus) return 0;
+    if (c.persist_columns > 0 && static_cast<int64_t>(c.grid.y) > static_cast<int64_t>(n_cus / c.persist_columns) * per_cu) return 0;
+    hipLaunchKernelGGL(kern, c.grid, dim3(kBlock), 0, c.stream, q.c1, q.c2, q.c3, q.mu, q.rho, q.m_mu, q.v_mu, q.m_rho, q.v_rho,
                        q.Xc, q.W, q.b, q.lam, q.effL, q.partials, a, CoupledArgs{},
                        reinterpret_cast<float *>(const_cast<PersistArgs *>(dev_args)));
     return 1;

@@ -691,7 +691,10 @@ struct PersistArgs {
     float *ring_kl, *ring_ll;   // (kLossRing, ld)
     double *loss_parts;         // (n_steps, gene_blocks, 2)
     int32_t n_steps, ring_pos0, train_b, train_lam, fin_Ng;
-    int32_t gene_blocks;        // gridDim.x may be larger: columns beyond it exit at once (persist_launch)
+    int32_t gene_blocks;        // gridDim.x may be larger: columns without a gene block exit at once
+    int32_t columns, col_offset;  // 0: blockIdx.x is the gene block; 8: grid (8, chunks), gene block g runs in column
+                                // (g + col_offset) % 8 -- the dispatcher deals linear workgroup ids round robin over the XCDs, so
+                                // a gene block's workgroups share an XCD; the offset differs between handles and processes
     int32_t debug;              // experiments / tests (brie_debug_step_fusion; results are then wrong): 1 no barrier wait, 2 no finalize,
                                 // 4 no rows, 8 chunk 0 skips its second arrival; bits 8..: log2 of the poll bound (default 24)
 };

@@ -23,6 +23,7 @@ struct LaunchCfg {
     float *rbuf = nullptr;         // wide designs (Kc > 8): residual buffer read back by wide_design_grad
     int gw_lds_bytes = 0;          // > 0: Kg > 4, GW variant with an Xg tile of this many bytes in dynamic LDS
     int margin = 0;                // 1: target="marginLik" through the MARGIN variants (coupled / wide models)
+    int persist_columns = 0;       // many steps per launch: > 0 = grid.x is this many columns (PersistArgs::columns), not gene blocks
 };
 
 #define BRIE_DECLARE_KC(N)                                                                          \

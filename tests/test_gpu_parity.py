@@ -977,23 +977,80 @@ def test_a_fused_launch_that_cannot_complete_ends_with_an_error_not_a_hang(lib):
     import os
     import subprocess
     import sys
-    code = ("import numpy as np\n"
+    code = ("import time\n"
+            "t0 = time.time()\n"
+            "import numpy as np\n"
             "from tests import util\n"
             "P = util.problem(200, 500, 0, 2, seed=5); P['effLen'] = None\n"
             "sh = util.device_shard(P, 200, 500, 0, 9)\n"
+            "print('shard ready', round(time.time() - t0, 2), flush=True)\n"
             "sh.set_step_fusion(1)\n"
             "sh.debug_step_fusion(8 | (14 << 8))\n"
             "sh.step(4, 0.01, 1, trace=False)\n"
             "sh.synchronize()\n"
+            "print('kernel ended', round(time.time() - t0, 2), flush=True)\n"
             "try:\n"
             "    sh.step(2, 0.01, 1)\n"
             "    print('NO ERROR')\n"
             "except RuntimeError as e:\n"
-            "    print('ERROR:', e)\n")
+            "    print('ERROR:', e)\n"
+            "print('done', round(time.time() - t0, 2), flush=True)\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root)
+    import time
+    t0 = time.time()
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    elapsed = time.time() - t0
+    if os.path.isdir(os.path.join(root, "gpurun_out")):
+        with open(os.path.join(root, "gpurun_out", "cannot_complete_child.log"), "w") as f:
+            f.write("elapsed %.1f s\n%s\n%s" % (elapsed, r.stdout, r.stderr[-2000:]))
     assert "ERROR:" in r.stdout and "gave up waiting" in r.stdout, r.stdout + r.stderr
+    # (the poll bound is 2^14 here: the child needs ~2 s.  Two full-suite runs of round 6 -- calls r8y, r8z -- spent 141 s in this
+    # test; three later runs with this log in place took 2 s each.  Candidate: the child's libraries paged in again after the
+    # full-size tests' host buffers had pushed them out of the page cache.  The log is kept for the next time)
+
+
+def test_fused_launches_of_several_handles_side_by_side(lib):
+    """Six handles, a host thread and a stream each, their many-steps-per-launch kernels in flight TOGETHER: every one ends
+    bit-identical to its two-launch twin.  (With at most 8 gene blocks a launch gives each gene block an XCD of its own; the
+    handles start at different columns, so small fits running side by side do not all wait for the same XCD -- and a grid that
+    waits for its workgroups behind another one must still complete.)"""
+    import threading
+    shapes = [(200, 500, 0, 2, 1), (200, 500, 1, 2, 3), (120, 900, 0, 2, 1), (64, 300, 2, 3, 3), (256, 2000, 0, 2, 1), (200, 1500, 3, 3, 3)]
+    twins, fused = [], []
+    for i, (Nc, Ng, Kc, L, MC) in enumerate(shapes):
+        P = util.problem(Nc, Ng, Kc, L, seed=4100 + i)
+        a = util.device_shard(P, Nc, Ng, Kc, 8100 + i)
+        b = util.device_shard(P, Nc, Ng, Kc, 8100 + i)
+        a.set_step_fusion(0)
+        b.set_step_fusion(1)
+        twins.append(a); fused.append(b)
+    for a, (_, _, _, _, MC) in zip(twins, shapes):
+        for _ in range(3):
+            a.step(150, 0.01, MC, trace=False)
+        a.synchronize()
+    errors = []
+
+    def run(b, MC):
+        try:
+            for _ in range(3):
+                b.step(150, 0.01, MC, trace=False)
+            b.synchronize()
+        except Exception as e:                  # noqa: BLE001 -- reported by the asserting thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(b, sh[4])) for b, sh in zip(fused, shapes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for a, b, sh in zip(twins, fused, shapes):
+        assert b.step_fusion_info()["launches"] == 3, (sh, b.step_fusion_info())
+        sa, sb = util.device_state(a), util.device_state(b)
+        for k in util.STATE_KEYS:
+            assert np.array_equal(sa[k], sb[k]), (sh, k, util.max_abs_diff(sa[k], sb[k]))
+        a.close(); b.close()
 
 
 @pytest.mark.parametrize("Nc,Ng,Kc,L,MC,cuts", [
